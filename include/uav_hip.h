@@ -1,0 +1,195 @@
+/*
+ * uav_hip.h — C ABI of libuav_hip.so, the MI355X (gfx950) kernel library behind the
+ * Upscale-A-Video hot path (DDIM loop over UNetVideoModel + video-VAE decode + RAFT /
+ * flow-guided latent propagation).
+ *
+ * The reference (sczhou/Upscale-A-Video) has NO native/FFI layer: its hot path is ATen ops
+ * issued from Python.  The drop-in boundary is therefore the Python object
+ * protocol of `models_video.*`; those classes live in
+ * `upscale-a-video_amd/models_video/` and call the entry points below through ctypes
+ * (`upscale-a-video_amd/uav/_lib.py`).  Each entry point names the reference op(s) it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer borrowed for the call (except the params structs
+ *     themselves, which are host memory read during the call);
+ *   - activations are channels-last: a video tensor (B,C,T,H,W) of the reference is held as
+ *     rows [B*T*H*W][C] (fp16), "image" index = b*T + t;
+ *   - all launches are stream-ordered on `stream` (a hipStream_t passed as void*), the library
+ *     keeps no global state and never allocates; workspaces are caller supplied;
+ *   - return value: 0 on success, negative UAV_E* on invalid arguments, positive = hipError_t
+ *     of a failed launch.  No exceptions cross the ABI.
+ */
+#ifndef UAV_HIP_H
+#define UAV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UAV_ABI_VERSION 1
+
+#define UAV_EINVAL   (-1)   /* bad argument (null pointer, size not supported) */
+#define UAV_EALIGN   (-2)   /* pointer / stride alignment requirement violated */
+#define UAV_ESHAPE   (-3)   /* shape constraint of the kernel violated */
+
+/* ---- library info ------------------------------------------------------------------- */
+int  uav_version(void);
+/* 0 if device `dev` is a gfx950 (MI355X); UAV_EINVAL otherwise. `name_out` (optional, >=64 B). */
+int  uav_device_check(int dev, char* name_out);
+
+/* ---- K1/K2: implicit-GEMM convolution / linear on MFMA (fp16 in, fp32 accumulate) -----
+ * Replaces: InflatedConv3d = per-frame nn.Conv2d (resnet.py:94-101), nn.Conv3d (k,1,1) and
+ * (3,3,3) (resnet.py:332,348,461), Upsample3D/Downsample3D convs (resnet.py:104-197),
+ * every nn.Linear of the transformer blocks (attention.py:97-106,327,355; GEGLU
+ * diffusers_attention.py:801-823), with fused epilogues: bias, per-batch time-embedding add
+ * (resnet.py:272-276), residual add, 1/output_scale_factor (resnet.py:292), GEGLU gate,
+ * skip-concat read from two tensors (unet_blocks.py:563), nearest-2x upsample folded into
+ * the gather (resnet.py:144).
+ *
+ *   out[m][n] = scale * ( sum_{tap,c} A[src(m,tap)][c] * W[n][tap*cin + c]
+ *                         + bias[n] + rowbias[m / rows_per_batch][n] + residual[m][n] )
+ *
+ * A is [n_img*hi*wi][c1] (+ optional second source [..][c2], channel-concatenated).
+ * W is the PACKED weight: fp16 [n_pad][k_pad], k = tap*cin_p + c, rows >= n and k >= K zero.
+ */
+#define UAV_CONV_GEGLU    1u   /* rows of W interleaved [32 value | 32 gate]; out width n/2 */
+#define UAV_CONV_OUT_F32  2u   /* store fp32 instead of fp16 */
+
+typedef struct {
+    const void*  a1;            /* fp16 source 1, rows of c1 channels */
+    const void*  a2;            /* fp16 source 2 (channels c1..c1+c2) or NULL */
+    int32_t      c1, c2;        /* c1+c2 = cin; both multiples of 64, or (c1==8,c2==0) "small" mode */
+    const void*  w;             /* packed fp16 weights [n_pad][k_pad] */
+    const float* bias;          /* fp32 [n_pad] or NULL */
+    const float* rowbias;       /* fp32 [n_batches][rowbias_stride] or NULL */
+    int32_t      rows_per_batch;
+    int32_t      rowbias_stride;
+    const void*  residual;      /* fp16 [M][res_stride] or NULL */
+    int32_t      res_stride;
+    void*        out;           /* fp16 (or fp32) [M][out_stride] */
+    int32_t      out_stride;
+    int32_t      n_img, t_len;  /* images (= batch*frames), frames per batch element */
+    int32_t      hi, wi;        /* input spatial size */
+    int32_t      ho, wo;        /* output spatial size */
+    int32_t      kt, kh, kw;    /* taps */
+    int32_t      stride;        /* spatial stride (1 or 2) */
+    int32_t      pad_t, pad_h, pad_w;
+    int32_t      upsample;      /* 1: input is nearest-2x upsampled on the fly (ho=2*hi) */
+    int32_t      n;             /* logical output channels (GEGLU: 2*features) */
+    int32_t      n_pad, k_pad;  /* packed weight dims: n_pad%128==0, k_pad%64==0 */
+    float        out_scale;
+    uint32_t     flags;
+    const void*  zero_page;     /* >=256 B of device zeros (padding source for the DMA gather) */
+} uav_conv_params;
+
+int uav_conv_gemm_f16(const uav_conv_params* p, void* stream);
+
+/* ---- K3: GroupNorm statistics + apply (+SiLU) ---------------------------------------
+ * Replaces nn.GroupNorm on 5-D tensors (statistics over C/G x T x H x W: resnet.py:267,278,
+ * 366,377,467,478,495; unet_video.py:567) and on per-frame 4-D tensors (attention.py:374;
+ * unet_blocks.py:740) followed by SiLU (resnet.py:268,284).
+ *   x: fp16 rows [n_inst*rows_per_inst][c] read from up to two channel-concatenated sources.
+ *   stats pass : partial per-channel (sum, sumsq) -> scale/shift tables [n_inst][c] (fp32):
+ *                scale = gamma*rstd, shift = beta - mean*rstd*gamma.
+ *   apply pass : y = act(x*scale + shift), fp16, written contiguously [rows][c1+c2].
+ */
+int64_t uav_groupnorm_workspace_bytes(int32_t n_inst, int32_t c);
+int uav_groupnorm_scale_shift(const void* x1, const void* x2, int32_t c1, int32_t c2,
+                              int32_t c_real, /* real channels (<= c1+c2); padding gets scale=shift=0 */
+                              int32_t n_inst, int64_t rows_per_inst, int32_t groups, float eps,
+                              const float* gamma, const float* beta,
+                              float* scale_out, float* shift_out,
+                              void* workspace, int64_t workspace_bytes, void* stream);
+int uav_groupnorm_apply(const void* x1, const void* x2, int32_t c1, int32_t c2,
+                        int32_t n_inst, int64_t rows_per_inst,
+                        const float* scale, const float* shift, int32_t silu,
+                        void* y, void* stream);
+
+/* ---- LayerNorm over the channel axis (nn.LayerNorm(dim), eps 1e-5: attention.py:457-494) */
+int uav_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta,
+                      int64_t rows, int32_t c, float eps, void* stream);
+
+/* ---- K5/K6/K8: flash attention on MFMA ------------------------------------------------
+ * Replaces CrossAttention._attention (attention.py:209-238: baddbmm + softmax + bmm) for
+ * spatial self-attention and text cross-attention, and the VAE AttentionBlock core
+ * (diffusers_attention.py:341-369).  softmax(scale * Q K^T) V, fp32 softmax, no mask.
+ *   q: [bq][lq] rows, element (b,i,h,d) at q[(b*lq+i)*q_stride + h*head_dim + d]
+ *   k,v: [bk][lk] rows likewise; query batch b reads kv batch b / q_per_kv.
+ *   head_dim in {64,128,512}.
+ */
+int uav_attention_f16(const void* q, int64_t q_stride, const void* k, int64_t k_stride,
+                      const void* v, int64_t v_stride, void* out, int64_t o_stride,
+                      int32_t bq, int32_t lq, int32_t lk, int32_t q_per_kv,
+                      int32_t heads, int32_t head_dim, float scale,
+                      const void* zero_page /* >=16 B of device zeros */, void* stream);
+
+/* ---- K7: per-pixel temporal attention --------------------------------------------------
+ * Replaces TemporalAttention._attention (attention.py:699-733): q*scale -> RoPE on the first
+ * rot_dim dims of each head (interleaved pairs) -> QK^T + bias[h][i][j] -> -max -> softmax -> V,
+ * for the T tokens of each (batch, pixel), reading the channels-last tensor in place
+ * (token (b,t,p) at row (b*t_len+t)*hw + p), no (b f) d c <-> (b d) f c transposes.
+ *   qkv: fp16 rows of 3*c (q | k | v), out: fp16 rows of c.  t_len <= 8 (the pipeline's window).
+ *   rope_cos/sin: fp32 [t_len][rot_dim/2]; bias: fp32 [heads][t_len][t_len].
+ */
+int uav_temporal_attention_f16(const void* qkv, void* out, int32_t n_batch, int32_t t_len,
+                               int64_t hw, int32_t c, int32_t heads, float scale,
+                               const float* rope_cos, const float* rope_sin, int32_t rot_dim,
+                               const float* bias, void* stream);
+
+/* ---- small dense layers (time / class embedding path: unet_video.py:472-491,
+ *      resnet.py:272-273).  y[m][n] = post( sum_k pre(x[m][k]) * w[n][k] + b[n] ), m <= 16.
+ *      x,y fp32; w fp16 [n][k] (nn.Linear layout); pre/post: 0 none, 1 SiLU. */
+int uav_linear_small(const float* x, const void* w, const float* b, float* y,
+                     int32_t m, int32_t k, int32_t n, int32_t pre_act, int32_t post_act,
+                     void* stream);
+/* Timesteps(num_channels, flip_sin_to_cos, downscale_freq_shift) sinusoid (diffusers 0.16
+ * embeddings.get_timestep_embedding; call site unet_video.py:173,472): out fp32 [m][dim]. */
+int uav_timestep_embedding(const float* t, int32_t m, int32_t dim, int32_t flip_sin_to_cos,
+                           float freq_shift, float* out, void* stream);
+
+/* ---- layout edges -------------------------------------------------------------------
+ * (B,C,T,H,W) fp16/fp32 planes -> channels-last rows padded to c_pad channels, concatenating
+ * up to two sources on C (unet_video.py:440), and back. */
+int uav_pack_nhwc(const void* src1, int32_t c1, const void* src2, int32_t c2, int32_t src_is_f32,
+                  void* dst, int32_t c_pad, int32_t n_batch, int32_t t_len, int64_t hw,
+                  float scale, void* stream);
+int uav_unpack_ncthw(const void* src, int32_t src_stride, int32_t src_is_f32, void* dst,
+                     int32_t dst_is_f32, int32_t c, int32_t n_batch, int32_t t_len, int64_t hw,
+                     float clamp_lo, float clamp_hi, void* stream);
+
+/* ---- K9: fused classifier-free guidance + DDIM step_v0 / step_vt ---------------------
+ * Replaces pipeline_upscale_a_video.py:643-645 + scheduling_ddim.py:383-433 (step_v0) and
+ * :436-520 (step_vt, eta = 0).  eps: model output rows [2*n][..] (uncond | text) or [n].
+ * All tensors fp16, n elements.  Coefficients are host scalars (no device->host sync).
+ *   v0 : g = e_u + guidance*(e_c - e_u) ; x0 = a*sample + b*g   (+clamp)   -> writes g, x0
+ *   vt : prev = c0*x0 + c1*(d0*g + d1*sample)
+ * prediction types: 0 epsilon, 1 sample, 2 v_prediction (coefficients prepared by the host). */
+int uav_cfg_ddim_v0(const void* eps_uncond, const void* eps_text, const void* sample,
+                    void* guided_out, void* x0_out, int64_t n, float guidance,
+                    float coef_sample, float coef_eps, int32_t clip, float clip_range,
+                    void* stream);
+int uav_ddim_vt(const void* x0, const void* guided, const void* sample, void* prev_out,
+                int64_t n, float coef_x0, float coef_dir, float eps_from_model,
+                float eps_from_sample, float eps_from_x0, void* stream);
+/* y = a*x + b*z  (add_noise: scheduling_ddim.py:524-545; window blend pipeline:630-634) */
+int uav_axpby_f16(const void* x, const void* z, void* y, int64_t n, float a, float b,
+                  void* stream);
+
+/* ---- K10: flow-guided propagation step -----------------------------------------------
+ * Replaces one recurrence step of Propagation.forward (propagation_module.py:234-254) with
+ * fbConsistencyCheck (:140-149) and flow_warp (:104-135): planar fp16 (c,h,w) features.
+ *   mask = |f + warp_bilinear(check, f)|^2 < a1*(|f|^2 + |warp(check)|^2) + a2
+ *   out  = mask ? fuse*warp_{nearest|bilinear}(prev, f) + (1-fuse)*cur : cur
+ * Grid arithmetic is replayed in fp16 exactly as the reference does (SURVEY.md §7 hard part 4). */
+int uav_propagate_step_f16(const void* feat_prev, const void* feat_cur, const void* flow_prop,
+                           const void* flow_check, void* out, int32_t c, int32_t h, int32_t w,
+                           int32_t nearest,
+                           int32_t coord_f16, /* 1: replay fp16 grid arithmetic; 0: fp32 */
+                           float fuse_scale, float alpha1, float alpha2, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UAV_HIP_H */

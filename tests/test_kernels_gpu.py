@@ -1,0 +1,336 @@
+"""Per-kernel parity tests (GPU): every HIP kernel of libuav_hip.so, called through the C ABI,
+against a plain PyTorch fp32 reference of the same op on identical fp16-representable inputs.
+
+Tolerances (stated per test): fp16 storage of outputs carries 2^-11 relative rounding, MFMA
+accumulates in fp32 -> rel-L2 <= 2e-3 for fp16 outputs, <= 1e-4 for fp32 outputs.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a = a.float(); b = b.float()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def to_rows(x):
+    """(N,C,H,W) -> channels-last rows [N*H*W][C] fp16."""
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous().half()
+
+
+def from_rows(y, n, h, w):
+    return y.reshape(n, h, w, -1).permute(0, 3, 1, 2).float()
+
+
+def h16(*shape, dev, scale=1.0, gen=None):
+    return (torch.randn(*shape, generator=gen, device="cpu") * scale).half().float().to(dev)
+
+
+@pytest.fixture(scope="module")
+def ops(dev):
+    from uav import ops as _ops, _lib
+    lib = _lib.load()
+    assert lib.uav_device_check(0, None) == 0, "libuav_hip.so must run on gfx950"
+    return _ops
+
+
+# ------------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # name, cin, cout, (kt,kh,kw), stride, upsample, n_img, t_len, h, w
+    ("3x3_c64", 64, 128, (1, 3, 3), 1, False, 4, 2, 24, 20),
+    ("3x3_c256_n256_tail", 256, 256, (1, 3, 3), 1, False, 2, 2, 17, 19),
+    ("3x3_stride2", 128, 128, (1, 3, 3), 2, False, 2, 1, 16, 24),
+    ("3x3_upsample", 64, 64, (1, 3, 3), 1, True, 2, 2, 9, 11),
+    ("1x1", 192, 128, (1, 1, 1), 1, False, 2, 1, 13, 7),
+    ("t3", 64, 64, (3, 1, 1), 1, False, 8, 4, 6, 10),
+    ("t5", 128, 128, (5, 1, 1), 1, False, 6, 3, 8, 8),
+    ("3x3x3", 64, 64, (3, 3, 3), 1, False, 6, 3, 10, 12),
+    ("small_cin7", 7, 128, (1, 3, 3), 1, False, 4, 2, 20, 16),
+    ("small_cin3_3x3x3", 3, 64, (3, 3, 3), 1, False, 3, 3, 12, 12),
+    ("out4", 128, 4, (1, 3, 3), 1, False, 2, 2, 16, 16),
+    ("out3", 128, 3, (1, 3, 3), 1, False, 2, 1, 16, 16),
+]
+
+
+def ref_conv(x5, w, b, kt_khw, stride, upsample):
+    """x5: (B,C,T,H,W) fp32; w: (O,I,kt,kh,kw)."""
+    kt, kh, kw = kt_khw
+    if upsample:
+        x5 = F.interpolate(x5, scale_factor=[1.0, 2.0, 2.0], mode="nearest")
+    return F.conv3d(x5, w, b, stride=(1, stride, stride), padding=(kt // 2, kh // 2, kw // 2))
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_gemm(ops, dev, case):
+    name, cin, cout, k3, stride, ups, n_img, t_len, h, w = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    bsz = n_img // t_len
+    x5 = h16(bsz, cin, t_len, h, w, dev=dev, gen=g)
+    fan = cin * k3[0] * k3[1] * k3[2]
+    wt = h16(cout, cin, *k3, dev=dev, scale=fan ** -0.5, gen=g)
+    bias = torch.randn(cout, generator=g).to(dev)
+    ref = ref_conv(x5, wt, bias, k3, stride, ups)                      # (B,O,T,Ho,Wo)
+    ho, wo = ref.shape[-2:]
+    rows = x5.permute(0, 2, 3, 4, 1).reshape(-1, cin)
+    if cin % 64:
+        rows = F.pad(rows, (0, 8 - cin))
+    rows = rows.contiguous().half()
+    cw = ops.pack_conv(wt, bias, device=dev)
+    out_f32 = cout < 8
+    y = ops.conv_gemm(rows, cw, n_img=n_img, t_len=t_len, hi=h, wi=w, stride=stride, upsample=ups, out_f32=out_f32)
+    y5 = y[:, :cout].float().reshape(bsz, t_len, ho, wo, cout).permute(0, 4, 1, 2, 3)
+    err = rel_l2(y5, ref)
+    assert err < (1e-4 if out_f32 else 2e-3), f"{name}: rel-L2 {err}"
+    if cw.n > cout:                                                     # padded store column is exactly zero+0 bias
+        assert y[:, cout:].abs().max().item() == 0.0
+
+
+def test_conv_epilogue_fusions(ops, dev):
+    """bias + per-batch row bias (temb) + residual + 1/output_scale_factor, two concatenated sources."""
+    g = torch.Generator().manual_seed(7)
+    bsz, t_len, h, w, c1, c2, cout = 2, 3, 10, 14, 128, 64, 128
+    xa = h16(bsz, c1, t_len, h, w, dev=dev, gen=g); xb = h16(bsz, c2, t_len, h, w, dev=dev, gen=g)
+    wt = h16(cout, c1 + c2, 1, 3, 3, dev=dev, scale=(9 * (c1 + c2)) ** -0.5, gen=g)
+    bias = torch.randn(cout, generator=g).to(dev)
+    temb = torch.randn(bsz, cout, generator=g).to(dev)
+    res5 = h16(bsz, cout, t_len, h, w, dev=dev, gen=g)
+    scale = 1.0 / 1.7
+    ref = (ref_conv(torch.cat([xa, xb], 1), wt, bias, (1, 3, 3), 1, False) + temb[:, :, None, None, None] + res5) * scale
+    ra = xa.permute(0, 2, 3, 4, 1).reshape(-1, c1).contiguous().half()
+    rb = xb.permute(0, 2, 3, 4, 1).reshape(-1, c2).contiguous().half()
+    rr = res5.permute(0, 2, 3, 4, 1).reshape(-1, cout).contiguous().half()
+    cw = ops.pack_conv(wt, bias, device=dev)
+    y = ops.conv_gemm(ra, cw, a2=rb, n_img=bsz * t_len, t_len=t_len, hi=h, wi=w, rowbias=temb.contiguous(),
+                      rows_per_batch=t_len * h * w, residual=rr, out_scale=scale)
+    y5 = y.float().reshape(bsz, t_len, h, w, cout).permute(0, 4, 1, 2, 3)
+    assert rel_l2(y5, ref) < 2e-3
+
+
+def test_linear_geglu_and_plain(ops, dev):
+    g = torch.Generator().manual_seed(11)
+    m, k, f = 1000, 128, 256
+    x = h16(m, k, dev=dev, gen=g)
+    w = h16(2 * f, k, dev=dev, scale=k ** -0.5, gen=g)
+    b = torch.randn(2 * f, generator=g).to(dev)
+    proj = x @ w.t() + b
+    hid, gate = proj.chunk(2, dim=-1)
+    ref = hid * F.gelu(gate)
+    cw = ops.pack_conv(w, b, geglu=True, device=dev)
+    y = ops.linear(x.half(), cw)
+    assert y.shape == (m, f)
+    assert rel_l2(y, ref) < 2e-3
+    cw2 = ops.pack_conv(w, b, device=dev)
+    res = h16(m, 2 * f, dev=dev, gen=g)
+    y2 = ops.linear(x.half(), cw2, residual=res.half())
+    assert rel_l2(y2, proj + res) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c1,c2,groups,n_inst,rows,silu", [
+    (256, 0, 32, 2, 3 * 10 * 12, True),       # 5-D flavour: instance = T*H*W rows
+    (128, 64, 32, 2, 500, True),              # concat, groups of 6 channels straddle the seam
+    (512, 0, 32, 6, 77, False),               # per-frame flavour, no activation
+    (1024, 1024, 32, 1, 300, True),
+    (64, 0, 32, 3, 1000, True),
+])
+def test_groupnorm(ops, dev, c1, c2, groups, n_inst, rows, silu):
+    g = torch.Generator().manual_seed(c1 + c2)
+    c = c1 + c2
+    x = h16(n_inst * rows, c, dev=dev, gen=g) * 1.5 + 0.3
+    x = x.half().float()
+    gamma = (1 + 0.1 * torch.randn(c, generator=g)).to(dev); beta = (0.1 * torch.randn(c, generator=g)).to(dev)
+    xr = x.reshape(n_inst, rows, c).permute(0, 2, 1)                    # (N, C, L)
+    ref = F.group_norm(xr, groups, gamma, beta, eps=1e-6)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.permute(0, 2, 1).reshape(-1, c)
+    x1 = x[:, :c1].contiguous().half()
+    x2 = x[:, c1:].contiguous().half() if c2 else None
+    y = ops.groupnorm(x1, gamma, beta, n_inst=n_inst, rows_per_inst=rows, groups=groups, eps=1e-6, silu=silu, x2=x2)
+    assert rel_l2(y, ref) < 1.5e-3
+
+
+def test_groupnorm_padded_channels(ops, dev):
+    """3 real channels padded to 8 (video-VAE condition branch: GroupNorm(3 groups, 3 channels))."""
+    g = torch.Generator().manual_seed(3)
+    rows = 640
+    x = torch.zeros(rows, 8, device=dev)
+    x[:, :3] = h16(rows, 3, dev=dev, gen=g)
+    gamma = torch.tensor([1.1, 0.9, 1.3], device=dev); beta = torch.tensor([0.1, -0.2, 0.0], device=dev)
+    ref = F.silu(F.group_norm(x[:, :3].t()[None], 3, gamma, beta, eps=1e-6))[0].t()
+    y = ops.groupnorm(x.half(), gamma, beta, n_inst=1, rows_per_inst=rows, groups=3, eps=1e-6, silu=True, c_real=3)
+    assert rel_l2(y[:, :3], ref) < 1.5e-3
+    assert y[:, 3:].abs().max().item() == 0.0
+
+
+@pytest.mark.parametrize("c", [128, 512, 1024])
+def test_layernorm(ops, dev, c):
+    g = torch.Generator().manual_seed(c)
+    x = h16(777, c, dev=dev, gen=g) * 2 + 0.5
+    x = x.half().float()
+    gamma = (1 + 0.1 * torch.randn(c, generator=g)).to(dev); beta = (0.1 * torch.randn(c, generator=g)).to(dev)
+    ref = F.layer_norm(x, (c,), gamma, beta, 1e-5)
+    y = ops.layernorm(x.half(), gamma, beta, 1e-5)
+    assert rel_l2(y, ref) < 1.5e-3
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,heads,bq,lq,lk,qpk", [
+    (64, 8, 4, 300, 77, 2),        # text cross-attention, 2 frames per text
+    (128, 8, 2, 200, 200, 1),      # spatial self-attention, ragged L
+    (64, 2, 2, 130, 33, 1),
+    (128, 2, 1, 1600, 1600, 1),
+    (512, 1, 2, 160, 160, 1),      # VAE mid-block attention, single head
+    (512, 1, 1, 100, 1000, 1),
+])
+def test_attention(ops, dev, d, heads, bq, lq, lk, qpk):
+    g = torch.Generator().manual_seed(d + lq)
+    c = heads * d
+    q = h16(bq, lq, c, dev=dev, gen=g)
+    k = h16(bq // qpk, lk, c, dev=dev, gen=g)
+    v = h16(bq // qpk, lk, c, dev=dev, gen=g)
+    qh = q.reshape(bq, lq, heads, d).permute(0, 2, 1, 3)
+    kh = k.repeat_interleave(qpk, 0).reshape(bq, lk, heads, d).permute(0, 2, 1, 3)
+    vh = v.repeat_interleave(qpk, 0).reshape(bq, lk, heads, d).permute(0, 2, 1, 3)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, dim=-1)
+    ref = (p @ vh).permute(0, 2, 1, 3).reshape(bq * lq, c)
+    out = ops.attention(q.half().reshape(-1, c), k.half().reshape(-1, c), v.half().reshape(-1, c), bq=bq, lq=lq, lk=lk,
+                        heads=heads, head_dim=d, q_per_kv=qpk)
+    assert rel_l2(out, ref) < 3e-3
+
+
+def test_attention_fused_qkv_strides(ops, dev):
+    """q/k/v as column slices of one fused [rows][3C] projection (row stride 3C)."""
+    g = torch.Generator().manual_seed(5)
+    heads, d, b, l = 2, 128, 2, 96
+    c = heads * d
+    qkv = h16(b * l, 3 * c, dev=dev, gen=g).half()
+    q, k, v = qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:]
+    qh, kh, vh = [t.float().reshape(b, l, heads, d).permute(0, 2, 1, 3) for t in (q, k, v)]
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, -1) @ vh).permute(0, 2, 1, 3).reshape(b * l, c)
+    out = ops.attention(q, k, v, bq=b, lq=l, lk=l, heads=heads, head_dim=d)
+    assert rel_l2(out, ref) < 3e-3
+
+
+def rope_tables(t_len, rot_dim, dev):
+    freqs = 1.0 / (10000 ** (torch.arange(0, rot_dim, 2).float() / rot_dim))
+    ang = torch.arange(t_len).float()[:, None] * freqs[None]
+    return ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev), freqs
+
+
+def ref_rope(x, freqs):
+    """x: (..., T, d); rotate first 2*len(freqs) dims, interleaved pairs."""
+    t = x.shape[-2]
+    rd = freqs.numel() * 2
+    ang = (torch.arange(t, device=x.device).float()[:, None] * freqs.to(x.device)[None]).repeat_interleave(2, -1)
+    xr, xp = x[..., :rd], x[..., rd:]
+    x1, x2 = xr[..., 0::2], xr[..., 1::2]
+    rot = torch.stack((-x2, x1), dim=-1).reshape(xr.shape)
+    return torch.cat([xr * ang.cos() + rot * ang.sin(), xp], dim=-1)
+
+
+@pytest.mark.parametrize("c,heads,t_len,hw,nb", [(512, 8, 8, 50, 2), (1024, 8, 5, 33, 1), (128, 2, 8, 40, 2), (256, 2, 3, 20, 1)])
+def test_temporal_attention(ops, dev, c, heads, t_len, hw, nb):
+    g = torch.Generator().manual_seed(c + t_len)
+    d = c // heads
+    qkv = h16(nb * t_len * hw, 3 * c, dev=dev, gen=g)
+    bias = (0.5 * torch.randn(heads, t_len, t_len, generator=g)).to(dev).contiguous()
+    cos, sin, freqs = rope_tables(t_len, 32, dev)
+    scale = d ** -0.5
+    x = qkv.reshape(nb, t_len, hw, 3, heads, d).permute(3, 0, 2, 4, 1, 5)       # (3, b, p, h, t, d)
+    q, k, v = x[0] * scale, x[1], x[2]
+    q = ref_rope(q, freqs); k = ref_rope(k, freqs)
+    s = q @ k.transpose(-1, -2) + bias[None, None]
+    s = s - s.amax(-1, keepdim=True)
+    o = torch.softmax(s, -1) @ v                                                   # (b, p, h, t, d)
+    ref = o.permute(0, 3, 1, 2, 4).reshape(nb * t_len * hw, c)
+    out = ops.temporal_attention(qkv.half(), n_batch=nb, t_len=t_len, hw=hw, c=c, heads=heads, scale=scale,
+                                 rope_cos=cos, rope_sin=sin, rot_dim=32, bias=bias)
+    assert rel_l2(out, ref) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------
+def test_linear_small_and_timestep_embedding(ops, dev):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 256, generator=g).to(dev)
+    w = h16(1024, 256, dev=dev, scale=1 / 16, gen=g); b = torch.randn(1024, generator=g).to(dev)
+    y = ops.linear_small(x, w.half(), b, post_silu=True)
+    assert rel_l2(y, F.silu(x @ w.t() + b)) < 1e-5
+    y2 = ops.linear_small(y, h16(512, 1024, dev=dev, scale=1 / 32, gen=g).half(), None, pre_silu=True)
+    assert y2.shape == (2, 512) and torch.isfinite(y2).all()
+    t = torch.tensor([958.0, 1.0, 34.0], device=dev)
+    emb = ops.timestep_embedding(t, 256, True, 0.0)
+    half = 128
+    expo = -math.log(10000) * torch.arange(half, dtype=torch.float32, device=dev) / half
+    arg = t[:, None] * torch.exp(expo)[None]
+    ref = torch.cat([arg.cos(), arg.sin()], -1)          # flip_sin_to_cos=True -> [cos, sin]
+    assert (emb - ref).abs().max().item() < 2e-4
+
+
+def test_pack_unpack(ops, dev):
+    g = torch.Generator().manual_seed(2)
+    a = torch.randn(2, 4, 3, 6, 10, generator=g).to(dev).half()
+    b = torch.randn(2, 3, 3, 6, 10, generator=g).to(dev).half()
+    rows = ops.pack_nhwc(a, b, c_pad=8)
+    ref = torch.cat([a, b], 1).permute(0, 2, 3, 4, 1).reshape(-1, 7)
+    assert torch.equal(rows[:, :7], ref) and rows[:, 7].abs().max().item() == 0
+    back = ops.unpack_ncthw(rows, c=4, n_batch=2, t_len=3, h=6, w=10)
+    assert torch.equal(back, a)
+    rows32 = ops.pack_nhwc(a.float(), None, c_pad=8, scale=2.0)
+    assert torch.equal(rows32[:, :4], (a.float() * 2).half().permute(0, 2, 3, 4, 1).reshape(-1, 4))
+    cl = ops.unpack_ncthw(rows32.float().contiguous(), c=4, n_batch=2, t_len=3, h=6, w=10, out_dtype=torch.float32,
+                          clamp=(-1.0, 1.0))
+    assert cl.abs().max().item() <= 1.0
+
+
+def test_cfg_ddim(ops, dev):
+    g = torch.Generator().manual_seed(4)
+    n = 4 * 8 * 33 * 17 + 3
+    eu, ec, x = [torch.randn(n, generator=g).to(dev).half() for _ in range(3)]
+    a, bcoef, gs = 0.83, -0.55, 6.0
+    gd, x0 = ops.cfg_ddim_v0(eu, ec, x, guidance=gs, coef_sample=a, coef_eps=bcoef)
+    gref = eu.float() + gs * (ec.float() - eu.float())
+    assert rel_l2(gd, gref) < 1e-3
+    assert rel_l2(x0, a * x.float() + bcoef * gd.float()) < 1e-3
+    prev = ops.ddim_vt(x0, gd, x, coef_x0=0.9, coef_dir=0.4, eps_from_model=a, eps_from_sample=0.5)
+    ref = 0.9 * x0.float() + 0.4 * (a * gd.float() + 0.5 * x.float())
+    assert rel_l2(prev, ref) < 1e-3
+    y = ops.axpby(eu, ec, 0.5, 0.5)
+    assert rel_l2(y, 0.5 * eu.float() + 0.5 * ec.float()) < 1e-3
+
+
+def ref_flow_warp(x, flow, mode):
+    """flow_warp of the reference (propagation_module.py:104-135) in fp32."""
+    n, c, h, w = x.shape
+    gy, gx = torch.meshgrid(torch.arange(h, device=x.device).float(), torch.arange(w, device=x.device).float(), indexing="ij")
+    vx = gx + flow[:, 0]; vy = gy + flow[:, 1]
+    grid = torch.stack((2.0 * vx / max(w - 1, 1) - 1.0, 2.0 * vy / max(h - 1, 1) - 1.0), dim=3)
+    return F.grid_sample(x, grid, mode=mode, padding_mode="zeros", align_corners=True)
+
+
+@pytest.mark.parametrize("nearest", [True, False])
+def test_propagate_step_fp32_coords(ops, dev, nearest):
+    g = torch.Generator().manual_seed(9)
+    c, h, w = 4, 40, 56
+    prev = torch.randn(1, c, h, w, generator=g).to(dev).half()
+    cur = torch.randn(1, c, h, w, generator=g).to(dev).half()
+    # flows with a sub-pixel offset of .3/.7 so nearest never sits on a .5 tie in fp32
+    fp = (torch.randint(-3, 4, (1, 2, h, w), generator=g).float() + 0.3).to(dev).half()
+    fc = (-fp.float() + 0.05 * torch.randn(1, 2, h, w, generator=g).to(dev)).half()
+    fpf, fcf = fp.float(), fc.float()
+    bw = ref_flow_warp(fcf, fpf, "bilinear")
+    diff = fpf + bw
+    lsq = lambda t: (t * t).sum(1, keepdim=True)
+    valid = (lsq(diff) < 0.01 * (lsq(fpf) + lsq(bw)) + 0.5).float()
+    warped = ref_flow_warp(prev.float(), fpf, "nearest" if nearest else "bilinear")
+    fused = warped * 0.5 + cur.float() * 0.5
+    ref = valid * fused + (1 - valid) * cur.float()
+    out = ops.propagate_step(prev[0], cur[0], fp[0], fc[0], nearest=nearest, coord_f16=False, fuse_scale=0.5,
+                             alpha1=0.01, alpha2=0.5)
+    bad = ((out.float() - ref[0]).abs() > 2e-2).float().mean().item()
+    assert bad < 2e-3, f"{bad} of pixels differ"          # threshold-boundary pixels may flip the mask

@@ -1,0 +1,234 @@
+// K5/K6/K8 — flash attention on MFMA for gfx950: softmax(scale * Q K^T) V, fp16 in/out,
+// fp32 scores / softmax / accumulation, no mask.  Replaces CrossAttention._attention
+// (attention.py:209-238) for spatial self-attention (L=1600, d=128) and text cross-attention
+// (Lk=77, d=64/128), and the VAE AttentionBlock core (diffusers_attention.py:341-369;
+// single head d=512, L = H*W up to 102400) without materialising the L x L scores.
+//
+// Workgroup = 4 waves = 128 query rows of one (batch, head); each wave owns 32 queries.
+// Both MFMAs are issued so that a LANE owns a QUERY:
+//   S^T[key][q]  = K[key][:] . Q[q][:]     (A = K fragment from LDS, B = Q fragment in VGPRs)
+//   O^T[d][q]   += V^T[d][key] * P^T[key][q] (A = V^T fragment from LDS, B = P in VGPRs)
+// so running max / sum / rescale are per-lane scalars and P feeds the second MFMA straight
+// from the accumulator registers of the first: the k-index permutation the 32x32 C-layout
+// imposes on P (keys {0-3,8-11 | 4-7,12-15} per half-wave) is mirrored when reading V^T,
+// no cross-lane traffic (cdna guide T12 without the permlane).
+// K tiles (32 keys) arrive by global_load_lds DMA, double buffered, XOR-swizzled on the source
+// side; V tiles are register-staged and transposed 4x8 on the way into a padded V^T image
+// (72-B rows: conflict-free ds_read_b64).
+// Roofline: MFMA-bound for L >= ~1k (4*L*d FLOP per query row); the text cross-attention
+// (Lk=77) is HBM-bound on reading Q / writing O.
+#include "uav_common.h"
+
+namespace {
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct AttnArgs {
+    const char* q; long long q_stride;
+    const char* k; long long k_stride;
+    const char* v; long long v_stride;
+    char* o; long long o_stride;
+    int bq, lq, lk, q_per_kv, heads;
+    float scale_log2;
+    const char* zero_page;
+};
+
+constexpr int KV = 32;          // keys per tile
+constexpr int VT_STRIDE = 72;   // bytes per V^T row (32 keys * 2 B + 8 B pad)
+
+template <int D> struct AttnCfg {
+    static constexpr int KS_BYTES = KV * D * 2;            // one K stage
+    static constexpr int VT_BYTES = D * VT_STRIDE;
+    static constexpr int SMEM = 2 * KS_BYTES + VT_BYTES;
+    static constexpr int SLOTS = D / 8;                    // 16-B slots per K row
+    static constexpr int KPIECES = KV * SLOTS / 256;       // DMA pieces per thread per tile
+    static constexpr int VUNITS = (D + 255) / 256;         // (4 keys x 8 d) units per thread
+};
+
+template <int D> UAV_DEVINL int kswz(int key) { return D == 64 ? ((key >> 1) & 7) : (key & 15); }
+
+template <int D>
+__global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_kernel(AttnArgs p) {
+    using C = AttnCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                       // [2][KV][D] halves, swizzled
+    char* Vt = smem + 2 * C::KS_BYTES;     // [D][36] halves
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int bk = b / p.q_per_kv;
+    const char* kbase = p.k + ((long long)bk * p.lk * p.k_stride + (long long)h * D) * 2;
+    const char* vbase = p.v + ((long long)bk * p.lk * p.v_stride + (long long)h * D) * 2;
+
+    // ---- Q fragments (B operand): Q[q][16s + 8hi .. +8] ------------------------------------
+    const int qrow = q0 + l32;
+    const int qr = qrow < p.lq ? qrow : p.lq - 1;
+    const char* qptr = p.q + (((long long)b * p.lq + qr) * p.q_stride + (long long)h * D) * 2;
+    half8_t qf[D / 16];
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) qf[s] = *(const half8_t*)(qptr + (16 * s + 8 * hi) * 2);
+
+    float16_t oacc[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const int nt = (p.lk + KV - 1) / KV;
+
+    // ---- staging roles ----------------------------------------------------------------------
+    auto issue_k = [&](int stage, int t) {
+        char* dst = Ks + stage * C::KS_BYTES;
+#pragma unroll
+        for (int ps = 0; ps < C::KPIECES; ++ps) {
+            const int pi = ps * 256 + tid;
+            const int row = pi / C::SLOTS, sp = pi % C::SLOTS;
+            const int sl = sp ^ kswz<D>(row);
+            const int key = t * KV + row;
+            const char* g = key < p.lk ? kbase + ((long long)key * p.k_stride + sl * 8) * 2 : p.zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + (ps * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+    half8_t vst[C::VUNITS][4];
+    auto load_v = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < C::VUNITS; ++u) {
+            const int unit = u * 256 + tid;
+            if (unit < D) {
+                const int kg = unit & 7, dv = unit >> 3;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int key = t * KV + kg * 4 + i;
+                    half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+                    vst[u][i] = key < p.lk ? *(const half8_t*)(vbase + ((long long)key * p.v_stride + dv * 8) * 2) : z;
+                }
+            }
+        }
+    };
+    auto store_v = [&]() {
+#pragma unroll
+        for (int u = 0; u < C::VUNITS; ++u) {
+            const int unit = u * 256 + tid;
+            if (unit < D) {
+                const int kg = unit & 7, dv = unit >> 3;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    half4_t w = {vst[u][0][e], vst[u][1][e], vst[u][2][e], vst[u][3][e]};
+                    *(half4_t*)(Vt + (dv * 8 + e) * VT_STRIDE + kg * 8) = w;
+                }
+            }
+        }
+    };
+
+    issue_k(0, 0);
+    load_v(0);
+    for (int t = 0; t < nt; ++t) {
+        store_v();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) { issue_k((t + 1) & 1, t + 1); load_v(t + 1); }
+
+        // ---- S^T = K Q^T ---------------------------------------------------------------------
+        const char* kst = Ks + (t & 1) * C::KS_BYTES + l32 * (2 * D);
+        const int ksw = kswz<D>(l32);
+        float16_t sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < D / 16; ++s) {
+            half8_t kf = *(const half8_t*)(kst + (((2 * s + hi) ^ ksw) << 4));
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc, 0, 0, 0);
+        }
+        // ---- online softmax: lane = query, registers = 16 keys --------------------------------
+        const int key0 = t * KV + 4 * hi;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 8 * (r >> 2);
+            float s = sacc[r] * p.scale_log2;
+            s = key < p.lk ? s : -INFINITY;
+            sacc[r] = s; mx = fmaxf(mx, s);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float ps = 0.f;
+        half8_t pf[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = exp2f(sacc[r] - m_new);
+            ps += e;
+            pf[r >> 3][r & 7] = (half_t)e;
+        }
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        // ---- O^T += V^T P^T -------------------------------------------------------------------
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i) {
+            const char* vrow = Vt + (i * 32 + l32) * VT_STRIDE + hi * 8;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                half4_t a = *(const half4_t*)(vrow + s2 * 32);
+                half4_t c = *(const half4_t*)(vrow + s2 * 32 + 16);
+                half8_t vf = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+                oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s2], oacc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < p.lq) {
+        char* optr = p.o + (((long long)b * p.lq + qrow) * p.o_stride + (long long)h * D) * 2;
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4_t o = {(half_t)(oacc[i][4 * g] * inv), (half_t)(oacc[i][4 * g + 1] * inv),
+                             (half_t)(oacc[i][4 * g + 2] * inv), (half_t)(oacc[i][4 * g + 3] * inv)};
+                *(half4_t*)(optr + (i * 32 + 8 * g + 4 * hi) * 2) = o;
+            }
+    }
+}
+
+template <int D>
+int launch_attn(const AttnArgs& a, hipStream_t s) {
+    using C = AttnCfg<D>;
+    static bool attr_set = false;
+    if (!attr_set && C::SMEM > 65536) {
+        hipFuncSetAttribute((const void*)attn_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        attr_set = true;
+    }
+    dim3 grid((a.lq + 127) / 128, a.heads, a.bq);
+    hipLaunchKernelGGL(attn_kernel<D>, grid, dim3(256), C::SMEM, s, a);
+    return uav_launch_status();
+}
+
+}  // namespace
+
+extern "C" int uav_attention_f16(const void* q, int64_t q_stride, const void* k, int64_t k_stride, const void* v,
+                                 int64_t v_stride, void* out, int64_t o_stride, int32_t bq, int32_t lq, int32_t lk,
+                                 int32_t q_per_kv, int32_t heads, int32_t head_dim, float scale, const void* zero_page,
+                                 void* stream) {
+    if (!q || !k || !v || !out || !zero_page) return UAV_EINVAL;
+    if (bq <= 0 || lq <= 0 || lk <= 0 || heads <= 0 || q_per_kv <= 0 || (bq % q_per_kv)) return UAV_ESHAPE;
+    if ((q_stride % 8) || (k_stride % 8) || (v_stride % 8) || (o_stride % 4)) return UAV_EALIGN;
+    if (heads > 65535 || bq > 65535) return UAV_ESHAPE;
+    AttnArgs a{(const char*)q, q_stride, (const char*)k, k_stride, (const char*)v, v_stride, (char*)out, o_stride,
+               bq, lq, lk, q_per_kv, heads, scale * 1.44269504088896341f, (const char*)zero_page};
+    hipStream_t s = (hipStream_t)stream;
+    switch (head_dim) {
+        case 64: return launch_attn<64>(a, s);
+        case 128: return launch_attn<128>(a, s);
+        case 512: return launch_attn<512>(a, s);
+        default: return UAV_ESHAPE;
+    }
+}

@@ -1,0 +1,301 @@
+// K1/K2 — implicit-GEMM convolution / linear for gfx950 (MI355X), fp16 in, fp32 accumulate.
+//
+// One kernel serves every dense contraction of the UNetVideoModel / AutoencoderKLVideo hot
+// path (reference ops replaced: see include/uav_hip.h):
+//   per-frame 3x3 / 1x1 convs (stride 1|2, nearest-2x upsample folded into the gather),
+//   temporal (k,1,1) and 3x3x3 convs (frames are the image index, zero pad at clip ends),
+//   nn.Linear (1x1 "conv" over token rows).
+//
+// GEMM view:  D^T[n][m] = sum_k W[n][k] * X[m][k],  m = output pixel, n = output channel,
+// k = tap*cin + c.  The MFMA is issued "swapped" (A operand = weights, B operand = pixels) so
+// that each lane ends up owning ONE pixel m and 4 consecutive channels n per register quad:
+// the epilogue (bias, time-embedding row bias, residual, scale, GEGLU) is per-lane and the
+// output leaves as 8-byte (fp16) / 16-byte (fp32) vector stores into the channels-last row.
+//
+// Tile: 128(m) x 128(n) x 64(k) per 256-thread workgroup (4 waves, each 64x64 = 2x2 MFMA
+// 32x32x16 tiles, 64 fp32 accumulators/lane).  Two LDS stages of 32 KiB, filled by
+// global_load_lds DMA (16 B / lane, 1 KiB / wave-instruction): no staging VGPRs, no ds_write
+// pass.  The DMA writes LDS lane-linearly, so the bank-conflict swizzle is applied on the
+// per-lane SOURCE address (guide rule 21): physical 16-B slot s of LDS row r holds logical
+// k-slot s ^ ((r>>1)&7); ds_read_b128 fragment reads are then conflict-free for the
+// {0-3,12-15,20-27}/{4-11,16-19,28-31} lane groups of that instruction.
+// Zero padding (spatial / temporal borders, M tail) is a DMA from a zero page.
+//
+// Roofline: MFMA-bound (arithmetic intensity 4.5*C FLOP/B for 3x3).  Algorithmic FLOP per
+// launch = 2*M*N*K_logical.
+#include "uav_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int A_BYTES = BM * BK * 2;          // 16 KiB
+constexpr int B_BYTES = BN * BK * 2;          // 16 KiB
+constexpr int STAGE_BYTES = A_BYTES + B_BYTES;
+
+struct ConvArgs {
+    const char* a1; const char* a2; int c1, c2;
+    const char* w; const float* bias; const float* rowbias; int rows_per_batch, rowbias_stride;
+    const char* residual; int res_stride;
+    char* out; int out_stride;
+    int n_img, t_len, hi, wi, ho, wo, kt, kh, kw, stride, pad_t, pad_h, pad_w, upsample;
+    int n, n_pad, k_pad; float out_scale; unsigned flags;
+    const char* zero_page;
+    long long M;
+};
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+UAV_DEVINL void dma16(const char* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+// Source pixel (linear index into the [n_img*hi*wi] rows) read by output pixel (img,yo,xo) at
+// tap (dt,dy,dx); -1 when the tap falls into the zero padding.
+UAV_DEVINL int src_pixel(const ConvArgs& p, int img, int tloc, int yo, int xo, int dt, int dy, int dx) {
+    int tt = tloc + dt - p.pad_t;
+    int yi, xi;
+    bool ok = (tt >= 0) & (tt < p.t_len);
+    if (p.upsample) {
+        int yv = yo + dy - p.pad_h, xv = xo + dx - p.pad_w;
+        ok = ok & (yv >= 0) & (yv < p.ho) & (xv >= 0) & (xv < p.wo);
+        yi = yv >> 1; xi = xv >> 1;
+    } else {
+        yi = yo * p.stride + dy - p.pad_h; xi = xo * p.stride + dx - p.pad_w;
+        ok = ok & (yi >= 0) & (yi < p.hi) & (xi >= 0) & (xi < p.wi);
+    }
+    int pix = ((img + dt - p.pad_t) * p.hi + yi) * p.wi + xi;
+    return ok ? pix : -1;
+}
+
+template <int SMALL>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi32 = lane >> 5;          // which half of the wave (k-slot parity)
+    const int l32 = lane & 31;
+
+    const unsigned n_tiles = p.n_pad / BN;
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned mt = bid / n_tiles, nt = bid - mt * n_tiles;
+    const long long m0 = (long long)mt * BM;
+    const int n0 = nt * BN;
+
+    // ---- DMA role of this thread: rows r = pass*32 + (tid>>3), physical slot tid&7 ----------
+    const int slot_log = (tid & 7) ^ ((tid >> 4) & 7);   // logical k-slot fetched into phys slot
+    const int rbase = tid >> 3;                          // 0..31
+    int img[4], tloc[4], yx[4];
+    bool mval[4];
+    const int hw_o = p.ho * p.wo;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        long long m = m0 + ps * 32 + rbase;
+        mval[ps] = m < p.M;
+        int mm = mval[ps] ? (int)m : 0;
+        int im = mm / hw_o; int rem = mm - im * hw_o;
+        int yo = rem / p.wo; int xo = rem - yo * p.wo;
+        img[ps] = im; tloc[ps] = im % p.t_len; yx[ps] = (yo << 16) | xo;
+    }
+    const int cin = p.c1 + p.c2;
+    const int khw = p.kh * p.kw;
+    const int ntaps = p.kt * khw;
+    const int nk = p.k_pad / BK;
+    const char* wrow = p.w + ((long long)(n0 + rbase) * p.k_pad + slot_log * 8) * 2;
+
+    int pix[4] = {-1, -1, -1, -1};
+    int nxt_tap = 0, nxt_c = 0;          // (tap, channel offset) of the NEXT k-step to issue
+
+    auto issue = [&](int stage, int ks) {
+        char* sA = smem + stage * STAGE_BYTES;
+        char* sB = sA + A_BYTES;
+        if (SMALL) {
+            // cin_p == 8: every 16-B slot is one tap of one pixel.
+            int tap = ks * 8 + slot_log;
+            bool tok = tap < ntaps;
+            int dt = tap / khw; int rem = tap - dt * khw; int dy = rem / p.kw; int dx = rem - dy * p.kw;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                int px = (tok && mval[ps]) ? src_pixel(p, img[ps], tloc[ps], yx[ps] >> 16, yx[ps] & 0xffff, dt, dy, dx) : -1;
+                const char* g = px >= 0 ? p.a1 + (long long)px * 16 : p.zero_page;
+                dma16(g, sA + (ps * 256 + wave * 64) * 16);
+            }
+        } else {
+            if (nxt_c == 0) {            // tap changed (uniform branch): refresh source pixels
+                int dt = nxt_tap / khw; int rem = nxt_tap - dt * khw; int dy = rem / p.kw; int dx = rem - dy * p.kw;
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps)
+                    pix[ps] = mval[ps] ? src_pixel(p, img[ps], tloc[ps], yx[ps] >> 16, yx[ps] & 0xffff, dt, dy, dx) : -1;
+            }
+            const bool first = nxt_c < p.c1;
+            const char* src = first ? p.a1 : p.a2;
+            const int cs = first ? p.c1 : p.c2;
+            const int coff = (first ? nxt_c : nxt_c - p.c1) + slot_log * 8;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps) {
+                const char* g = pix[ps] >= 0 ? src + ((long long)pix[ps] * cs + coff) * 2 : p.zero_page;
+                dma16(g, sA + (ps * 256 + wave * 64) * 16);
+            }
+            nxt_c += BK;
+            if (nxt_c >= cin) { nxt_c = 0; ++nxt_tap; }
+        }
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps)
+            dma16(wrow + ((long long)ps * 32 * p.k_pad + (long long)ks * BK) * 2, sB + (ps * 256 + wave * 64) * 16);
+    };
+
+    // ---- accumulators: acc[ni][mi], wave tile = rows n [wn*64,+64) x cols m [wm*64,+64) -----
+    const int wn = wave & 1, wm = wave >> 1;
+    float16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read offsets (bytes inside a stage): row*128 + ((slot ^ ((row>>1)&7))*16)
+    int offW[2], offX[2], swz[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int rw = wn * 64 + i * 32 + l32;
+        int rx = wm * 64 + i * 32 + l32;
+        offW[i] = A_BYTES + rw * 128; offX[i] = rx * 128;
+        swz[i] = 0;
+    }
+    const int swW0 = ((wn * 64 + l32) >> 1) & 7, swW1 = ((wn * 64 + 32 + l32) >> 1) & 7;
+    const int swX0 = ((wm * 64 + l32) >> 1) & 7, swX1 = ((wm * 64 + 32 + l32) >> 1) & 7;
+    (void)swz;
+
+    issue(0, 0);
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ks + 1 < nk) issue(cur ^ 1, ks + 1);
+        const char* st = smem + cur * STAGE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            const int slot = kk * 2 + hi32;
+            half8_t w0 = *(const half8_t*)(st + offW[0] + ((slot ^ swW0) << 4));
+            half8_t w1 = *(const half8_t*)(st + offW[1] + ((slot ^ swW1) << 4));
+            half8_t x0 = *(const half8_t*)(st + offX[0] + ((slot ^ swX0) << 4));
+            half8_t x1 = *(const half8_t*)(st + offX[1] + ((slot ^ swX1) << 4));
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, x0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w0, x1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1, x1, acc[1][1], 0, 0, 0);
+        }
+        cur ^= 1;
+    }
+
+    // ---- epilogue: lane owns pixel m, channels n = nb + 8*g + 4*hi32 + j -------------------
+    const bool geglu = p.flags & UAV_CONV_GEGLU;
+    const bool of32 = p.flags & UAV_CONV_OUT_F32;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const long long m = m0 + wm * 64 + mi * 32 + l32;
+        if (m >= p.M) continue;
+        const float* rb = p.rowbias ? p.rowbias + (long long)((int)m / p.rows_per_batch) * p.rowbias_stride : nullptr;
+        if (geglu) {
+            const int fbase = (n0 + wn * 64) >> 1;       // output feature base of this wave
+            const int nb = n0 + wn * 64;                 // packed row base (value rows; gate rows +32)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int jn = 8 * g + 4 * hi32;
+                const int f = fbase + jn;
+                if (f >= (p.n >> 1)) continue;
+                half4_t o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float hv = acc[0][mi][4 * g + j], gv = acc[1][mi][4 * g + j];
+                    if (p.bias) { hv += p.bias[nb + jn + j]; gv += p.bias[nb + 32 + jn + j]; }
+                    o[j] = (half_t)(hv * uav_gelu_erf(gv) * p.out_scale);
+                }
+                *(half4_t*)(p.out + ((long long)m * p.out_stride + f) * 2) = o;
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * hi32;
+                    if (n >= p.n) continue;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
+                    if (p.bias) {
+                        float4_t b = *(const float4_t*)(p.bias + n);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += b[j];
+                    }
+                    if (rb) {
+                        float4_t b = *(const float4_t*)(rb + n);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += b[j];
+                    }
+                    if (p.residual) {
+                        half4_t r = *(const half4_t*)(p.residual + ((long long)m * p.res_stride + n) * 2);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= p.out_scale;
+                    if (of32) {
+                        float4_t o = {v[0], v[1], v[2], v[3]};
+                        *(float4_t*)(p.out + ((long long)m * p.out_stride + n) * 4) = o;
+                    } else {
+                        half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        *(half4_t*)(p.out + ((long long)m * p.out_stride + n) * 2) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
+    if (!q || !q->a1 || !q->w || !q->out || !q->zero_page) return UAV_EINVAL;
+    const bool small = (q->c1 == 8 && q->c2 == 0);
+    if (!small && ((q->c1 % 64) || (q->c2 % 64) || q->c1 <= 0 || q->c2 < 0)) return UAV_ESHAPE;
+    if (q->c2 > 0 && !q->a2) return UAV_EINVAL;
+    if ((q->n_pad % BN) || (q->k_pad % BK) || q->n <= 0 || q->n > q->n_pad) return UAV_ESHAPE;
+    const int ntaps = q->kt * q->kh * q->kw;
+    const int cin = q->c1 + q->c2;
+    if (ntaps <= 0 || ntaps > 27 * 4) return UAV_ESHAPE;
+    if ((long long)ntaps * cin > q->k_pad) return UAV_ESHAPE;
+    if (!small && (long long)ntaps * cin != q->k_pad) return UAV_ESHAPE;   // cin%64==0 => exact
+    if (q->n % 4) return UAV_ESHAPE;
+    if (q->out_stride % 4 || (q->residual && (q->res_stride % 4))) return UAV_EALIGN;
+    if (q->rowbias && (q->rows_per_batch <= 0 || (q->rowbias_stride % 4))) return UAV_ESHAPE;
+    if ((q->flags & UAV_CONV_GEGLU) && ((q->flags & UAV_CONV_OUT_F32) || q->residual || q->rowbias || (q->n % 64)))
+        return UAV_ESHAPE;
+    if (q->upsample && (q->stride != 1 || q->ho != 2 * q->hi || q->wo != 2 * q->wi)) return UAV_ESHAPE;
+    if (q->t_len <= 0 || q->n_img % q->t_len) return UAV_ESHAPE;
+    if (q->ho >= 65536 || q->wo >= 65536) return UAV_ESHAPE;
+    ConvArgs a;
+    a.a1 = (const char*)q->a1; a.a2 = (const char*)q->a2; a.c1 = q->c1; a.c2 = q->c2;
+    a.w = (const char*)q->w; a.bias = q->bias; a.rowbias = q->rowbias;
+    a.rows_per_batch = q->rows_per_batch; a.rowbias_stride = q->rowbias_stride;
+    a.residual = (const char*)q->residual; a.res_stride = q->res_stride;
+    a.out = (char*)q->out; a.out_stride = q->out_stride;
+    a.n_img = q->n_img; a.t_len = q->t_len; a.hi = q->hi; a.wi = q->wi; a.ho = q->ho; a.wo = q->wo;
+    a.kt = q->kt; a.kh = q->kh; a.kw = q->kw; a.stride = q->stride;
+    a.pad_t = q->pad_t; a.pad_h = q->pad_h; a.pad_w = q->pad_w; a.upsample = q->upsample;
+    a.n = q->n; a.n_pad = q->n_pad; a.k_pad = q->k_pad; a.out_scale = q->out_scale; a.flags = q->flags;
+    a.zero_page = (const char*)q->zero_page;
+    a.M = (long long)q->n_img * q->ho * q->wo;
+    if (a.M <= 0 || a.M >= (1ll << 31)) return UAV_ESHAPE;
+    const long long mtiles = (a.M + BM - 1) / BM;
+    const long long grid = mtiles * (q->n_pad / BN);
+    if (grid >= (1ll << 31)) return UAV_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (small)
+        hipLaunchKernelGGL(conv_gemm_kernel<1>, dim3((unsigned)grid), dim3(256), 2 * STAGE_BYTES, s, a);
+    else
+        hipLaunchKernelGGL(conv_gemm_kernel<0>, dim3((unsigned)grid), dim3(256), 2 * STAGE_BYTES, s, a);
+    return uav_launch_status();
+}

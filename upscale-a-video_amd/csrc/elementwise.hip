@@ -1,0 +1,337 @@
+// HBM-bound / tiny kernels of the hot path for gfx950: layout edges, time-embedding MLP,
+// fused CFG + DDIM step, flow-guided propagation step.  Each entry point cites the reference
+// lines it replaces in include/uav_hip.h.
+#include "uav_common.h"
+#include <string.h>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// y[m][n] = post( sum_k pre(x[m][k]) * w[n][k] + b[n] ),  m <= 16.  One wave per output column.
+template <int MMAX>
+__global__ __launch_bounds__(256) void linear_small_kernel(const float* __restrict__ x, const half_t* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ y, int m,
+                                                           int k, int n, int pre, int post) {
+    const int lane = threadIdx.x & 63;
+    const int col = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (col >= n) return;
+    float acc[MMAX];
+#pragma unroll
+    for (int i = 0; i < MMAX; ++i) acc[i] = 0.f;
+    for (int k0 = lane * 8; k0 < k; k0 += 64 * 8) {
+        half8_t wv = *(const half8_t*)(w + (long long)col * k + k0);
+#pragma unroll
+        for (int i = 0; i < MMAX; ++i) {
+            if (i < m) {
+                const float4_t xa = *(const float4_t*)(x + (long long)i * k + k0);
+                const float4_t xb = *(const float4_t*)(x + (long long)i * k + k0 + 4);
+                float xs[8] = {xa[0], xa[1], xa[2], xa[3], xb[0], xb[1], xb[2], xb[3]};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float xv = pre ? uav_silu(xs[e]) : xs[e];
+                    acc[i] += xv * (float)wv[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MMAX; ++i) {
+        if (i < m) {
+            float s = wave_sum(acc[i]);
+            if (lane == 0) {
+                s += b ? b[col] : 0.f;
+                y[(long long)i * n + col] = post ? uav_silu(s) : s;
+            }
+        }
+    }
+}
+
+__global__ void timestep_embedding_kernel(const float* __restrict__ t, int m, int dim, int flip, float shift,
+                                          float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int half = dim / 2;
+    if (i >= m * half) return;
+    const int r = i / half, j = i % half;
+    const float expo = -logf(10000.0f) * (float)j / ((float)half - shift);
+    const float arg = t[r] * expf(expo);
+    const float sn = sinf(arg), cs = cosf(arg);
+    // diffusers get_timestep_embedding: cat[sin, cos]; flip_sin_to_cos swaps the halves
+    out[(long long)r * dim + (flip ? half : 0) + j] = sn;
+    out[(long long)r * dim + (flip ? 0 : half) + j] = cs;
+}
+
+// ---------------------------------------------------------------------------------------------
+template <typename SrcT>
+__global__ __launch_bounds__(256) void pack_nhwc_kernel(const SrcT* __restrict__ s1, int c1, const SrcT* __restrict__ s2,
+                                                        int c2, half_t* __restrict__ dst, int c_pad, int n_batch,
+                                                        int t_len, long long hw, float scale) {
+    const long long rows = (long long)n_batch * t_len * hw;
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const long long p = r % hw; const long long bt = r / hw;
+    const int t = (int)(bt % t_len), b = (int)(bt / t_len);
+    for (int cv = 0; cv < c_pad; cv += 8) {
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = cv + e;
+            float v = 0.f;
+            if (c < c1) v = (float)s1[(((long long)b * c1 + c) * t_len + t) * hw + p];
+            else if (c < c1 + c2) v = (float)s2[(((long long)b * c2 + (c - c1)) * t_len + t) * hw + p];
+            o[e] = (half_t)(v * scale);
+        }
+        *(half8_t*)(dst + r * c_pad + cv) = o;
+    }
+}
+
+template <typename SrcT, typename DstT>
+__global__ __launch_bounds__(256) void unpack_ncthw_kernel(const SrcT* __restrict__ src, int src_stride,
+                                                           DstT* __restrict__ dst, int c, int n_batch, int t_len,
+                                                           long long hw, float lo, float hi) {
+    const long long rows = (long long)n_batch * t_len * hw;
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const long long p = r % hw; const long long bt = r / hw;
+    const int t = (int)(bt % t_len), b = (int)(bt / t_len);
+    for (int ch = 0; ch < c; ++ch) {
+        float v = (float)src[r * src_stride + ch];
+        v = fminf(fmaxf(v, lo), hi);
+        dst[(((long long)b * c + ch) * t_len + t) * hw + p] = (DstT)v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cfg_ddim_v0_kernel(const half_t* __restrict__ eu, const half_t* __restrict__ ec,
+                                                          const half_t* __restrict__ x, half_t* __restrict__ g_out,
+                                                          half_t* __restrict__ x0_out, long long n, float guidance,
+                                                          float ca, float cb, int clip, float range) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i >= n) return;
+    if (i + 8 <= n) {
+        half8_t u = *(const half8_t*)(eu + i), xv = *(const half8_t*)(x + i), c = u, g, x0;
+        if (ec) c = *(const half8_t*)(ec + i);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float gu = (float)u[e];
+            const float gg = ec ? gu + guidance * ((float)c[e] - gu) : gu;
+            g[e] = (half_t)gg;
+            float v = ca * (float)xv[e] + cb * (float)g[e];
+            if (clip) v = fminf(fmaxf(v, -range), range);
+            x0[e] = (half_t)v;
+        }
+        *(half8_t*)(g_out + i) = g; *(half8_t*)(x0_out + i) = x0;
+    } else {
+        for (long long j = i; j < n; ++j) {
+            const float gu = (float)eu[j];
+            const float gg = ec ? gu + guidance * ((float)ec[j] - gu) : gu;
+            const half_t gh = (half_t)gg;
+            float v = ca * (float)x[j] + cb * (float)gh;
+            if (clip) v = fminf(fmaxf(v, -range), range);
+            g_out[j] = gh; x0_out[j] = (half_t)v;
+        }
+    }
+}
+
+// prev = cx0*x0 + cdir*(em*g + es*sample + e0*x0)
+__global__ __launch_bounds__(256) void ddim_vt_kernel(const half_t* __restrict__ x0, const half_t* __restrict__ g,
+                                                      const half_t* __restrict__ x, half_t* __restrict__ prev,
+                                                      long long n, float cx0, float cdir, float em, float es, float e0) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float a = (float)x0[i];
+    const float eps = em * (float)g[i] + es * (float)x[i] + e0 * a;
+    prev[i] = (half_t)(cx0 * a + cdir * eps);
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const half_t* __restrict__ x, const half_t* __restrict__ z,
+                                                    half_t* __restrict__ y, long long n, float a, float b) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    y[i] = (half_t)(a * (float)x[i] + b * (float)z[i]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Propagation step.  R = rounding policy: fp16 replay of the reference's GPU arithmetic
+// (flow_warp builds the grid in the latent dtype, propagation_module.py:123-132; ATen's
+// grid_sampler_2d evaluates index/weights in scalar_t) or plain fp32 (matches the fp32 oracle).
+struct RoundF16 { static UAV_DEVINL float r(float v) { return (float)(half_t)v; } };
+struct RoundF32 { static UAV_DEVINL float r(float v) { return v; } };
+
+template <typename R>
+UAV_DEVINL void warp_coords(int x, int y, float fx, float fy, int w, int h, float& ix, float& iy) {
+    const float vx = R::r((float)x + fx), vy = R::r((float)y + fy);
+    const float dw = (float)(w - 1 > 1 ? w - 1 : 1), dh = (float)(h - 1 > 1 ? h - 1 : 1);
+    const float gx = R::r(R::r(R::r(2.0f * vx) / dw) - 1.0f);
+    const float gy = R::r(R::r(R::r(2.0f * vy) / dh) - 1.0f);
+    // grid_sampler_unnormalize(align_corners=True): float arithmetic, one rounding to scalar_t
+    ix = R::r(((gx + 1.f) / 2.f) * (float)(w - 1));
+    iy = R::r(((gy + 1.f) / 2.f) * (float)(h - 1));
+}
+
+template <typename R>
+UAV_DEVINL float sample_bilinear(const half_t* __restrict__ plane, int w, int h, float ix, float iy) {
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+    const float nw = R::r(R::r((float)x1 - ix) * R::r((float)y1 - iy));
+    const float ne = R::r(R::r(ix - (float)x0) * R::r((float)y1 - iy));
+    const float sw = R::r(R::r((float)x1 - ix) * R::r(iy - (float)y0));
+    const float se = R::r(R::r(ix - (float)x0) * R::r(iy - (float)y0));
+    float acc = 0.f;
+    if (x0 >= 0 && x0 < w && y0 >= 0 && y0 < h) acc = R::r(acc + R::r((float)plane[(long long)y0 * w + x0] * nw));
+    if (x1 >= 0 && x1 < w && y0 >= 0 && y0 < h) acc = R::r(acc + R::r((float)plane[(long long)y0 * w + x1] * ne));
+    if (x0 >= 0 && x0 < w && y1 >= 0 && y1 < h) acc = R::r(acc + R::r((float)plane[(long long)y1 * w + x0] * sw));
+    if (x1 >= 0 && x1 < w && y1 >= 0 && y1 < h) acc = R::r(acc + R::r((float)plane[(long long)y1 * w + x1] * se));
+    return acc;
+}
+
+template <typename R>
+__global__ __launch_bounds__(256) void propagate_step_kernel(const half_t* __restrict__ prev, const half_t* __restrict__ cur,
+                                                             const half_t* __restrict__ fprop, const half_t* __restrict__ fchk,
+                                                             half_t* __restrict__ out, int c, int h, int w, int nearest,
+                                                             float fuse, float a1, float a2) {
+    const long long hw = (long long)h * w;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= hw) return;
+    const int y = (int)(i / w), x = (int)(i % w);
+    const float fx = (float)fprop[i], fy = (float)fprop[hw + i];
+    float ix, iy;
+    warp_coords<R>(x, y, fx, fy, w, h, ix, iy);
+    // forward-backward consistency (fbConsistencyCheck)
+    const float bx = sample_bilinear<R>(fchk, w, h, ix, iy);
+    const float by = sample_bilinear<R>(fchk + hw, w, h, ix, iy);
+    const float dx = R::r(fx + bx), dy = R::r(fy + by);
+    const float ldiff = R::r(R::r(dx * dx) + R::r(dy * dy));
+    const float lf = R::r(R::r(fx * fx) + R::r(fy * fy));
+    const float lb = R::r(R::r(bx * bx) + R::r(by * by));
+    const float mag = R::r(lf + lb);
+    const float thr = R::r(R::r(a1 * mag) + a2);
+    const bool valid = ldiff < thr;
+    int xn = 0, yn = 0; bool inb = false;
+    if (nearest) {
+        xn = (int)nearbyintf(ix); yn = (int)nearbyintf(iy);
+        inb = xn >= 0 && xn < w && yn >= 0 && yn < h;
+    }
+    for (int ch = 0; ch < c; ++ch) {
+        const float cv = (float)cur[ch * hw + i];
+        float o = cv;
+        if (valid) {
+            float wv;
+            if (nearest) wv = inb ? (float)prev[ch * hw + (long long)yn * w + xn] : 0.f;
+            else wv = sample_bilinear<R>(prev + ch * hw, w, h, ix, iy);
+            o = R::r(R::r(wv * fuse) + R::r(cv * (1.0f - fuse)));
+        }
+        out[ch * hw + i] = (half_t)o;
+    }
+}
+
+inline unsigned nblk(long long n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+extern "C" int uav_version(void) { return UAV_ABI_VERSION; }
+
+extern "C" int uav_device_check(int dev, char* name_out) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return UAV_EINVAL;
+    if (name_out) { strncpy(name_out, prop.gcnArchName, 63); name_out[63] = 0; }
+    return strstr(prop.gcnArchName, "gfx950") ? 0 : UAV_EINVAL;
+}
+
+extern "C" int uav_linear_small(const float* x, const void* w, const float* b, float* y, int32_t m, int32_t k, int32_t n,
+                                int32_t pre_act, int32_t post_act, void* stream) {
+    if (!x || !w || !y) return UAV_EINVAL;
+    if (m <= 0 || m > 16 || k <= 0 || (k % 8) || n <= 0) return UAV_ESHAPE;
+    hipStream_t s = (hipStream_t)stream;
+    if (m <= 2)
+        hipLaunchKernelGGL(linear_small_kernel<2>, dim3((n + 3) / 4), dim3(256), 0, s, x, (const half_t*)w, b, y, m, k, n, pre_act, post_act);
+    else
+        hipLaunchKernelGGL(linear_small_kernel<16>, dim3((n + 3) / 4), dim3(256), 0, s, x, (const half_t*)w, b, y, m, k, n, pre_act, post_act);
+    return uav_launch_status();
+}
+
+extern "C" int uav_timestep_embedding(const float* t, int32_t m, int32_t dim, int32_t flip_sin_to_cos, float freq_shift,
+                                      float* out, void* stream) {
+    if (!t || !out) return UAV_EINVAL;
+    if (m <= 0 || dim <= 0 || (dim % 2)) return UAV_ESHAPE;
+    const int total = m * (dim / 2);
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, t, m, dim,
+                       flip_sin_to_cos, freq_shift, out);
+    return uav_launch_status();
+}
+
+extern "C" int uav_pack_nhwc(const void* src1, int32_t c1, const void* src2, int32_t c2, int32_t src_is_f32, void* dst,
+                             int32_t c_pad, int32_t n_batch, int32_t t_len, int64_t hw, float scale, void* stream) {
+    if (!src1 || !dst) return UAV_EINVAL;
+    if (c1 <= 0 || c2 < 0 || (c2 > 0 && !src2) || c_pad < c1 + c2 || (c_pad % 8) || n_batch <= 0 || t_len <= 0 || hw <= 0)
+        return UAV_ESHAPE;
+    const long long rows = (long long)n_batch * t_len * hw;
+    hipStream_t s = (hipStream_t)stream;
+    if (src_is_f32)
+        hipLaunchKernelGGL(pack_nhwc_kernel<float>, dim3(nblk(rows, 256)), dim3(256), 0, s, (const float*)src1, c1,
+                           (const float*)src2, c2, (half_t*)dst, c_pad, n_batch, t_len, (long long)hw, scale);
+    else
+        hipLaunchKernelGGL(pack_nhwc_kernel<half_t>, dim3(nblk(rows, 256)), dim3(256), 0, s, (const half_t*)src1, c1,
+                           (const half_t*)src2, c2, (half_t*)dst, c_pad, n_batch, t_len, (long long)hw, scale);
+    return uav_launch_status();
+}
+
+extern "C" int uav_unpack_ncthw(const void* src, int32_t src_stride, int32_t src_is_f32, void* dst, int32_t dst_is_f32,
+                                int32_t c, int32_t n_batch, int32_t t_len, int64_t hw, float clamp_lo, float clamp_hi,
+                                void* stream) {
+    if (!src || !dst) return UAV_EINVAL;
+    if (c <= 0 || src_stride < c || n_batch <= 0 || t_len <= 0 || hw <= 0) return UAV_ESHAPE;
+    const long long rows = (long long)n_batch * t_len * hw;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g(nblk(rows, 256)), b(256);
+#define UNPACK(ST, DT) hipLaunchKernelGGL((unpack_ncthw_kernel<ST, DT>), g, b, 0, s, (const ST*)src, src_stride, (DT*)dst, c, \
+                                          n_batch, t_len, (long long)hw, clamp_lo, clamp_hi)
+    if (src_is_f32) { if (dst_is_f32) UNPACK(float, float); else UNPACK(float, half_t); }
+    else            { if (dst_is_f32) UNPACK(half_t, float); else UNPACK(half_t, half_t); }
+#undef UNPACK
+    return uav_launch_status();
+}
+
+extern "C" int uav_cfg_ddim_v0(const void* eps_uncond, const void* eps_text, const void* sample, void* guided_out,
+                               void* x0_out, int64_t n, float guidance, float coef_sample, float coef_eps, int32_t clip,
+                               float clip_range, void* stream) {
+    if (!eps_uncond || !sample || !guided_out || !x0_out || n <= 0) return UAV_EINVAL;
+    hipLaunchKernelGGL(cfg_ddim_v0_kernel, dim3(nblk(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream,
+                       (const half_t*)eps_uncond, (const half_t*)eps_text, (const half_t*)sample, (half_t*)guided_out,
+                       (half_t*)x0_out, (long long)n, guidance, coef_sample, coef_eps, clip, clip_range);
+    return uav_launch_status();
+}
+
+extern "C" int uav_ddim_vt(const void* x0, const void* guided, const void* sample, void* prev_out, int64_t n,
+                           float coef_x0, float coef_dir, float eps_from_model, float eps_from_sample, float eps_from_x0,
+                           void* stream) {
+    if (!x0 || !guided || !sample || !prev_out || n <= 0) return UAV_EINVAL;
+    hipLaunchKernelGGL(ddim_vt_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x0,
+                       (const half_t*)guided, (const half_t*)sample, (half_t*)prev_out, (long long)n, coef_x0, coef_dir,
+                       eps_from_model, eps_from_sample, eps_from_x0);
+    return uav_launch_status();
+}
+
+extern "C" int uav_axpby_f16(const void* x, const void* z, void* y, int64_t n, float a, float b, void* stream) {
+    if (!x || !z || !y || n <= 0) return UAV_EINVAL;
+    hipLaunchKernelGGL(axpby_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
+                       (const half_t*)z, (half_t*)y, (long long)n, a, b);
+    return uav_launch_status();
+}
+
+extern "C" int uav_propagate_step_f16(const void* feat_prev, const void* feat_cur, const void* flow_prop,
+                                      const void* flow_check, void* out, int32_t c, int32_t h, int32_t w, int32_t nearest,
+                                      int32_t coord_f16, float fuse_scale, float alpha1, float alpha2, void* stream) {
+    if (!feat_prev || !feat_cur || !flow_prop || !flow_check || !out) return UAV_EINVAL;
+    if (c <= 0 || h <= 0 || w <= 0) return UAV_ESHAPE;
+    const long long hw = (long long)h * w;
+    hipStream_t s = (hipStream_t)stream;
+    if (coord_f16)
+        hipLaunchKernelGGL(propagate_step_kernel<RoundF16>, dim3(nblk(hw, 256)), dim3(256), 0, s, (const half_t*)feat_prev,
+                           (const half_t*)feat_cur, (const half_t*)flow_prop, (const half_t*)flow_check, (half_t*)out, c, h,
+                           w, nearest, fuse_scale, alpha1, alpha2);
+    else
+        hipLaunchKernelGGL(propagate_step_kernel<RoundF32>, dim3(nblk(hw, 256)), dim3(256), 0, s, (const half_t*)feat_prev,
+                           (const half_t*)feat_cur, (const half_t*)flow_prop, (const half_t*)flow_check, (half_t*)out, c, h,
+                           w, nearest, fuse_scale, alpha1, alpha2);
+    return uav_launch_status();
+}

@@ -1,0 +1,252 @@
+// K3 — GroupNorm statistics / apply(+SiLU) and LayerNorm for channels-last fp16 rows (gfx950).
+//
+// GroupNorm in the reference is applied to 5-D (b,c,t,h,w) tensors — statistics over
+// (C/G, T, H, W) per batch element (resnet.py:267,278; unet_video.py:567; vae_video.py:401) —
+// or per frame on (b t) c h w (attention.py:374; unet_blocks.py:740).  Both are the same
+// kernel here: an "instance" is a run of `rows_per_inst` consecutive channels-last rows
+// (T*H*W rows, or H*W rows for the per-frame flavour).
+//
+// Pass 1 (HBM-bound, reads x once = 2 B/element): per-(instance, chunk) per-channel fp32
+// (sum, sumsq) partials.  Pass 2 (tiny): fp64 reduction over chunks and the channels of each
+// group -> per-(instance, channel) fp32 scale = gamma*rstd, shift = beta - mean*rstd*gamma.
+// Pass 3 (HBM-bound, 2 B read + 2 B written per element): y = act(x*scale + shift).
+// The input may be two channel-concatenated tensors (skip connections, unet_blocks.py:563):
+// groups may straddle the seam (1536 channels / 32 groups = 48), which per-channel partials
+// handle for free.  Deterministic: no atomics.
+#include "uav_common.h"
+
+namespace {
+
+constexpr int GN_MAX_CHUNKS = 512;
+
+struct GnSrc {
+    const char* x1; const char* x2; int c1, c2;
+};
+
+UAV_DEVINL const char* gn_vec_ptr(const GnSrc& s, long long row, int v) {
+    // v = vector index (8 channels) inside the concatenated row
+    const int v1 = s.c1 >> 3;
+    return v < v1 ? s.x1 + (row * s.c1 + (long long)v * 8) * 2
+                  : s.x2 + (row * s.c2 + (long long)(v - v1) * 8) * 2;
+}
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(GnSrc s, long long rows_per_inst, int chunks,
+                                                         float* __restrict__ ws) {
+    __shared__ float red[256 * 16];
+    const int c = s.c1 + s.c2, cvec = c >> 3;
+    const int rpp = 256 / cvec;                       // rows per pass (>=1, cvec <= 256)
+    const int tid = threadIdx.x;
+    const int v = tid % cvec, ro = tid / cvec;
+    const bool active = ro < rpp;
+    const int inst = blockIdx.y, chunk = blockIdx.x;
+    const long long rows_per_chunk = (rows_per_inst + chunks - 1) / chunks;
+    const long long r0 = (long long)chunk * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk; if (r1 > rows_per_inst) r1 = rows_per_inst;
+    float sm[8], sq[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sm[j] = 0.f; sq[j] = 0.f; }
+    if (active) {
+        for (long long r = r0 + ro; r < r1; r += rpp) {
+            half8_t x = *(const half8_t*)gn_vec_ptr(s, inst * rows_per_inst + r, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { float f = (float)x[j]; sm[j] += f; sq[j] += f * f; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = sm[j]; red[tid * 16 + 8 + j] = sq[j]; }
+    __syncthreads();
+    if (tid < cvec) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float a = 0.f;
+            for (int q = 0; q < rpp; ++q) a += red[(q * cvec + tid) * 16 + j];
+            // layout: ws[inst][chunk][0:c] = sums, [c:2c] = sumsq
+            float* dst = ws + ((long long)(inst * chunks + chunk) * 2 * c);
+            dst[(j < 8 ? 0 : c) + tid * 8 + (j & 7)] = a;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ ws, int chunks, int c, int c_real,
+                                                          int groups, long long rows_per_inst, float eps,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ scale, float* __restrict__ shift) {
+    extern __shared__ __attribute__((aligned(16))) char sm_raw[];
+    double* csum = (double*)sm_raw;           // [c]
+    double* csq = csum + c;                   // [c]
+    float* gmean = (float*)(csq + c);         // [groups]
+    float* grstd = gmean + groups;
+    const int inst = blockIdx.x, tid = threadIdx.x;
+    for (int ch = tid; ch < c; ch += 256) {
+        double a = 0.0, b = 0.0;
+        const float* base = ws + (long long)inst * chunks * 2 * c;
+        for (int k = 0; k < chunks; ++k) { a += base[(long long)k * 2 * c + ch]; b += base[(long long)k * 2 * c + c + ch]; }
+        csum[ch] = a; csq[ch] = b;
+    }
+    __syncthreads();
+    const int cpg = c_real / groups;
+    for (int g = tid; g < groups; g += 256) {
+        double a = 0.0, b = 0.0;
+        for (int j = 0; j < cpg; ++j) { a += csum[g * cpg + j]; b += csq[g * cpg + j]; }
+        const double n = (double)rows_per_inst * cpg;
+        const double mean = a / n;
+        double var = b / n - mean * mean; if (var < 0.0) var = 0.0;
+        gmean[g] = (float)mean; grstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int ch = tid; ch < c; ch += 256) {
+        float sc = 0.f, sh = 0.f;
+        if (ch < c_real) {
+            const int g = ch / cpg;
+            const float ga = gamma ? gamma[ch] : 1.f, be = beta ? beta[ch] : 0.f;
+            sc = ga * grstd[g]; sh = be - gmean[g] * grstd[g] * ga;
+        }
+        scale[(long long)inst * c + ch] = sc; shift[(long long)inst * c + ch] = sh;
+    }
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc s, long long rows_per_inst, int chunks,
+                                                       const float* __restrict__ scale, const float* __restrict__ shift,
+                                                       int silu, char* __restrict__ y) {
+    const int c = s.c1 + s.c2, cvec = c >> 3;
+    const int rpp = 256 / cvec;
+    const int tid = threadIdx.x;
+    const int v = tid % cvec, ro = tid / cvec;
+    if (ro >= rpp) return;
+    const int inst = blockIdx.y, chunk = blockIdx.x;
+    const long long rows_per_chunk = (rows_per_inst + chunks - 1) / chunks;
+    const long long r0 = (long long)chunk * rows_per_chunk;
+    long long r1 = r0 + rows_per_chunk; if (r1 > rows_per_inst) r1 = rows_per_inst;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { sc[j] = scale[(long long)inst * c + v * 8 + j]; sh[j] = shift[(long long)inst * c + v * 8 + j]; }
+    for (long long r = r0 + ro; r < r1; r += rpp) {
+        const long long row = inst * rows_per_inst + r;
+        half8_t x = *(const half8_t*)gn_vec_ptr(s, row, v);
+        half8_t o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = (float)x[j] * sc[j] + sh[j];
+            if (silu) f = uav_silu(f);
+            o[j] = (half_t)f;
+        }
+        *(half8_t*)(y + (row * c + (long long)v * 8) * 2) = o;
+    }
+}
+
+// LayerNorm: one wave per row, row held in registers (c <= 2048), two-pass mean/variance.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const char* __restrict__ x, char* __restrict__ y,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        long long rows, int c, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int cvec = c >> 3;
+    const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nwaves = (long long)gridDim.x * 4;
+    for (long long row = wave_id; row < rows; row += nwaves) {
+        half8_t xv[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = lane + i * 64;
+            if (v < cvec) {
+                xv[i] = *(const half8_t*)(x + (row * c + (long long)v * 8) * 2);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += (float)xv[i][j];
+            }
+        }
+        const float mean = wave_sum(s) / (float)c;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = lane + i * 64;
+            if (v < cvec) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float d = (float)xv[i][j] - mean; q += d * d; }
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = lane + i * 64;
+            if (v < cvec) {
+                half8_t o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ch = v * 8 + j;
+                    o[j] = (half_t)(((float)xv[i][j] - mean) * rstd * gamma[ch] + beta[ch]);
+                }
+                *(half8_t*)(y + (row * c + (long long)v * 8) * 2) = o;
+            }
+        }
+    }
+}
+
+int gn_chunks(int n_inst, long long rows_per_inst, int c) {
+    const int rpp = 256 / (c >> 3);
+    long long by_rows = (rows_per_inst + (long long)rpp * 8 - 1) / ((long long)rpp * 8);   // >= 8 passes per block
+    long long want = 2048 / (n_inst > 0 ? n_inst : 1); if (want < 1) want = 1;
+    long long ch = by_rows < want ? by_rows : want;
+    if (ch > GN_MAX_CHUNKS) ch = GN_MAX_CHUNKS;
+    if (ch < 1) ch = 1;
+    return (int)ch;
+}
+
+}  // namespace
+
+extern "C" int64_t uav_groupnorm_workspace_bytes(int32_t n_inst, int32_t c) {
+    return (int64_t)n_inst * GN_MAX_CHUNKS * c * 2 * 4;
+}
+
+extern "C" int uav_groupnorm_scale_shift(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t c_real,
+                                         int32_t n_inst, int64_t rows_per_inst, int32_t groups, float eps,
+                                         const float* gamma, const float* beta, float* scale_out, float* shift_out,
+                                         void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!x1 || !scale_out || !shift_out || !workspace) return UAV_EINVAL;
+    const int c = c1 + c2;
+    if (c1 <= 0 || c2 < 0 || (c1 % 8) || (c2 % 8) || c > 2048 || (c2 > 0 && !x2)) return UAV_ESHAPE;
+    if (c_real <= 0 || c_real > c || groups <= 0 || (c_real % groups) || n_inst <= 0 || rows_per_inst <= 0) return UAV_ESHAPE;
+    if (n_inst > 65535) return UAV_ESHAPE;
+    const int chunks = gn_chunks(n_inst, rows_per_inst, c);
+    if (workspace_bytes < (int64_t)n_inst * chunks * c * 2 * 4) return UAV_EINVAL;
+    GnSrc s{(const char*)x1, (const char*)x2, c1, c2};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, n_inst), dim3(256), 0, st, s, (long long)rows_per_inst, chunks,
+                       (float*)workspace);
+    const size_t sm = (size_t)c * 16 + (size_t)groups * 8;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_inst), dim3(256), sm, st, (const float*)workspace, chunks, c, c_real,
+                       groups, (long long)rows_per_inst, eps, gamma, beta, scale_out, shift_out);
+    return uav_launch_status();
+}
+
+extern "C" int uav_groupnorm_apply(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t n_inst,
+                                   int64_t rows_per_inst, const float* scale, const float* shift, int32_t silu, void* y,
+                                   void* stream) {
+    if (!x1 || !scale || !shift || !y) return UAV_EINVAL;
+    const int c = c1 + c2;
+    if (c1 <= 0 || c2 < 0 || (c1 % 8) || (c2 % 8) || c > 2048 || (c2 > 0 && !x2)) return UAV_ESHAPE;
+    if (n_inst <= 0 || n_inst > 65535 || rows_per_inst <= 0) return UAV_ESHAPE;
+    const int rpp = 256 / (c >> 3);
+    long long chunks = (rows_per_inst + (long long)rpp * 4 - 1) / ((long long)rpp * 4);
+    long long want = 8192 / n_inst; if (want < 1) want = 1;
+    if (chunks > want) chunks = want;
+    if (chunks < 1) chunks = 1;
+    GnSrc s{(const char*)x1, (const char*)x2, c1, c2};
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)chunks, n_inst), dim3(256), 0, (hipStream_t)stream, s,
+                       (long long)rows_per_inst, (int)chunks, scale, shift, silu, (char*)y);
+    return uav_launch_status();
+}
+
+extern "C" int uav_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t c,
+                                 float eps, void* stream) {
+    if (!x || !y || !gamma || !beta) return UAV_EINVAL;
+    if (c <= 0 || (c % 8) || c > 2048 || rows <= 0) return UAV_ESHAPE;
+    long long blocks = (rows + 3) / 4; if (blocks > 4096) blocks = 4096;
+    const int nv = ((c >> 3) + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+#define LN_LAUNCH(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, st, (const char*)x, \
+                                         (char*)y, gamma, beta, (long long)rows, c, eps)
+    if (nv == 1) LN_LAUNCH(1); else if (nv == 2) LN_LAUNCH(2); else if (nv == 3) LN_LAUNCH(3); else LN_LAUNCH(4);
+#undef LN_LAUNCH
+    return uav_launch_status();
+}

@@ -1,0 +1,151 @@
+// K7 — per-pixel temporal attention for gfx950.  Replaces TemporalAttention._attention
+// (attention.py:699-733) + RelativePositionBias (attention.py:735-772) + RotaryEmbedding(32)
+// (rotary-embedding-torch 0.2.3; call site attention.py:709-711):
+//   q*scale -> RoPE(first rot_dim dims of each head, interleaved pairs) ; k -> RoPE
+//   s_ij = q_i . k_j + bias[h][i][j] ; s -= max_j ; p = softmax_j ; out_i = sum_j p_ij v_j
+// over the T (<= 8) tokens of one (batch, pixel), all heads.
+//
+// The reference materialises (b f) d c -> (b d) f c transposes around this op
+// (attention.py:555,560).  Here the channels-last tensor is read in place: token (b,t,p) is row
+// (b*T + t)*hw + p of the fused qkv projection [rows][3C].  One wave handles one pixel and a
+// 512-channel group: lane = 8 consecutive channels (16-B loads, 1 KiB per wave-instruction,
+// fully coalesced); the d/8 lanes of a head all-reduce the partial dot products.
+// HBM-bound by construction (~4 FLOP/B): algorithmic bytes = 8*C per token (read q,k,v,
+// write out, fp16).
+#include "uav_common.h"
+
+namespace {
+
+constexpr int TMAX = 8;
+
+struct TAttnArgs {
+    const char* qkv; char* out;
+    int n_batch, t_len; long long hw; int c, heads, d;
+    float scale; const float* rope_cos; const float* rope_sin; int rot_dim; const float* bias;
+    int groups;   // ceil(c / 512)
+};
+
+__global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long nwork = (long long)p.n_batch * p.hw * p.groups;
+    if (wid >= nwork) return;
+    const int grp = (int)(wid % p.groups);
+    const long long bp = wid / p.groups;
+    const long long pix = bp % p.hw;
+    const int b = (int)(bp / p.hw);
+    const int c0 = grp * 512 + lane * 8;
+    if (c0 >= p.c) return;
+    const int lph = p.d >> 3;                 // lanes per head (power of two, <= 64)
+    const int head = c0 / p.d;
+    const int sub = (c0 % p.d) >> 3;          // this lane's 8-dim slice inside the head
+    const bool rot = sub * 8 < p.rot_dim;
+    const int T = p.t_len;
+    const long long row_stride = 3ll * p.c * 2;       // bytes per qkv row
+    const char* base = p.qkv + ((long long)b * T * p.hw + pix) * row_stride + (long long)c0 * 2;
+    const long long fstride = p.hw * row_stride;      // bytes between frames of this pixel
+
+    // ---- K (rotated) in fp32, V as fp16 -----------------------------------------------------
+    float kf[TMAX][8];
+    half8_t vh[TMAX];
+#pragma unroll
+    for (int j = 0; j < TMAX; ++j) {
+        if (j < T) {
+            half8_t kx = *(const half8_t*)(base + j * fstride + (long long)p.c * 2);
+            vh[j] = *(const half8_t*)(base + j * fstride + (long long)p.c * 4);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kf[j][e] = (float)kx[e];
+            if (rot) {
+                const float4_t cs = *(const float4_t*)(p.rope_cos + j * (p.rot_dim >> 1) + sub * 4);
+                const float4_t sn = *(const float4_t*)(p.rope_sin + j * (p.rot_dim >> 1) + sub * 4);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float a = kf[j][2 * q], bb = kf[j][2 * q + 1];
+                    kf[j][2 * q] = a * cs[q] - bb * sn[q];
+                    kf[j][2 * q + 1] = bb * cs[q] + a * sn[q];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kf[j][e] = 0.f;
+            vh[j] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+
+    char* obase = p.out + (((long long)b * T * p.hw + pix) * p.c + c0) * 2;
+    const long long ofstride = p.hw * (long long)p.c * 2;
+#pragma unroll
+    for (int i = 0; i < TMAX; ++i) {
+        if (i >= T) break;
+        half8_t qx = *(const half8_t*)(base + i * fstride);
+        float qf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[e] = (float)qx[e] * p.scale;
+        if (rot) {
+            const float4_t cs = *(const float4_t*)(p.rope_cos + i * (p.rot_dim >> 1) + sub * 4);
+            const float4_t sn = *(const float4_t*)(p.rope_sin + i * (p.rot_dim >> 1) + sub * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float a = qf[2 * q], bb = qf[2 * q + 1];
+                qf[2 * q] = a * cs[q] - bb * sn[q];
+                qf[2 * q + 1] = bb * cs[q] + a * sn[q];
+            }
+        }
+        float s[TMAX];
+#pragma unroll
+        for (int j = 0; j < TMAX; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) a += qf[e] * kf[j][e];
+            // all-reduce over the lph lanes of this head
+            for (int o = 1; o < lph; o <<= 1) a += __shfl_xor(a, o, 64);
+            s[j] = a;
+        }
+        const float* brow = p.bias + ((long long)head * T + i) * T;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < TMAX; ++j) {
+            if (j < T) { s[j] += brow[j]; mx = fmaxf(mx, s[j]); }
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < TMAX; ++j) {
+            s[j] = j < T ? __expf(s[j] - mx) : 0.f;
+            den += s[j];
+        }
+        const float inv = 1.0f / den;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TMAX; ++j) {
+            const float pj = s[j] * inv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += pj * (float)vh[j][e];
+        }
+        half8_t oh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) oh[e] = (half_t)o[e];
+        *(half8_t*)(obase + i * ofstride) = oh;
+    }
+}
+
+}  // namespace
+
+extern "C" int uav_temporal_attention_f16(const void* qkv, void* out, int32_t n_batch, int32_t t_len, int64_t hw,
+                                          int32_t c, int32_t heads, float scale, const float* rope_cos,
+                                          const float* rope_sin, int32_t rot_dim, const float* bias, void* stream) {
+    if (!qkv || !out || !bias) return UAV_EINVAL;
+    if (n_batch <= 0 || t_len <= 0 || t_len > TMAX || hw <= 0 || c <= 0 || heads <= 0 || (c % heads)) return UAV_ESHAPE;
+    const int d = c / heads;
+    if ((d % 8) || (d & (d - 1)) || d > 512 || (512 % d)) return UAV_ESHAPE;   // head inside one 512-channel group
+    if (rot_dim < 0 || (rot_dim % 8) || rot_dim > d) return UAV_ESHAPE;
+    if (rot_dim > 0 && (!rope_cos || !rope_sin)) return UAV_EINVAL;
+    TAttnArgs a{(const char*)qkv, (char*)out, n_batch, t_len, (long long)hw, c, heads, d, scale,
+                rope_cos, rope_sin, rot_dim, bias, (c + 511) / 512};
+    const long long nwork = (long long)n_batch * hw * a.groups;
+    const long long blocks = (nwork + 3) / 4;
+    if (blocks >= (1ll << 31)) return UAV_ESHAPE;
+    hipLaunchKernelGGL(temporal_attn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    return uav_launch_status();
+}

@@ -1,0 +1,95 @@
+"""ctypes binding of libuav_hip.so (C ABI declared in include/uav_hip.h).
+
+The product path has no CPU / PyTorch fallback: if the HIP library cannot be loaded, every op
+raises.  `load()` builds the library in-tree on first use when hipcc is available.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_LIB = None
+
+c_p = C.c_void_p
+i32 = C.c_int32
+i64 = C.c_int64
+f32 = C.c_float
+u32 = C.c_uint32
+
+
+class ConvParams(C.Structure):
+    """Mirror of `uav_conv_params` (include/uav_hip.h)."""
+    _fields_ = [
+        ("a1", c_p), ("a2", c_p), ("c1", i32), ("c2", i32),
+        ("w", c_p), ("bias", c_p), ("rowbias", c_p),
+        ("rows_per_batch", i32), ("rowbias_stride", i32),
+        ("residual", c_p), ("res_stride", i32),
+        ("out", c_p), ("out_stride", i32),
+        ("n_img", i32), ("t_len", i32), ("hi", i32), ("wi", i32), ("ho", i32), ("wo", i32),
+        ("kt", i32), ("kh", i32), ("kw", i32), ("stride", i32),
+        ("pad_t", i32), ("pad_h", i32), ("pad_w", i32), ("upsample", i32),
+        ("n", i32), ("n_pad", i32), ("k_pad", i32),
+        ("out_scale", f32), ("flags", u32), ("zero_page", c_p),
+    ]
+
+
+CONV_GEGLU = 1
+CONV_OUT_F32 = 2
+
+# name -> (restype, argtypes); the complete export list of include/uav_hip.h
+SIGNATURES = {
+    "uav_version": (C.c_int, []),
+    "uav_device_check": (C.c_int, [C.c_int, C.c_char_p]),
+    "uav_conv_gemm_f16": (C.c_int, [C.POINTER(ConvParams), c_p]),
+    "uav_groupnorm_workspace_bytes": (i64, [i32, i32]),
+    "uav_groupnorm_scale_shift": (C.c_int, [c_p, c_p, i32, i32, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
+    "uav_groupnorm_apply": (C.c_int, [c_p, c_p, i32, i32, i32, i64, c_p, c_p, i32, c_p, c_p]),
+    "uav_layernorm_f16": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, f32, c_p]),
+    "uav_attention_f16": (C.c_int, [c_p, i64, c_p, i64, c_p, i64, c_p, i64, i32, i32, i32, i32, i32, i32, f32, c_p, c_p]),
+    "uav_temporal_attention_f16": (C.c_int, [c_p, c_p, i32, i32, i64, i32, i32, f32, c_p, c_p, i32, c_p, c_p]),
+    "uav_linear_small": (C.c_int, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, c_p]),
+    "uav_timestep_embedding": (C.c_int, [c_p, i32, i32, i32, f32, c_p, c_p]),
+    "uav_pack_nhwc": (C.c_int, [c_p, i32, c_p, i32, i32, c_p, i32, i32, i32, i64, f32, c_p]),
+    "uav_unpack_ncthw": (C.c_int, [c_p, i32, i32, c_p, i32, i32, i32, i32, i64, f32, f32, c_p]),
+    "uav_cfg_ddim_v0": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, f32, f32, f32, i32, f32, c_p]),
+    "uav_ddim_vt": (C.c_int, [c_p, c_p, c_p, c_p, i64, f32, f32, f32, f32, f32, c_p]),
+    "uav_axpby_f16": (C.c_int, [c_p, c_p, c_p, i64, f32, f32, c_p]),
+    "uav_propagate_step_f16": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, f32, f32, f32, c_p]),
+}
+
+
+class UavError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """Load (building if necessary) libuav_hip.so and attach prototypes.  Raises on failure."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB
+    if build_if_missing and not _build.is_fresh():
+        if os.path.exists(_build.HIPCC):
+            _build.build()
+        elif not os.path.exists(path):
+            raise UavError("libuav_hip.so is missing and hipcc is unavailable — the HIP extension is required "
+                           "(there is no CPU fallback)")
+    if not os.path.exists(path):
+        raise UavError(f"{path} not found — run `python __graft_entry__.py` / uav.build.build() first")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if an exported symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "UAV_EINVAL", -2: "UAV_EALIGN", -3: "UAV_ESHAPE"}.get(rc, f"hipError {rc}")
+        raise UavError(f"{what} failed: {kind}")

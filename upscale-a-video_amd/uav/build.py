@@ -1,0 +1,73 @@
+"""Build libuav_hip.so (gfx950) in-tree with hipcc.
+
+The library is built next to this file so that it travels with the source snapshot to the GPU
+box (the .so is git-ignored, not gpurun-ignored).  hipcc cross-compiles without a GPU.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(HERE), "csrc")
+LIB = os.path.join(HERE, "libuav_hip.so")
+STAMP = os.path.join(HERE, ".libuav_hip.stamp")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-value"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _digest():
+    h = hashlib.sha256()
+    files = sources() + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".h")]
+    files.append(os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "uav_hip.h"))
+    for f in files:
+        with open(f, "rb") as fh:
+            h.update(f.encode()); h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def is_fresh():
+    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
+        return False
+    with open(STAMP) as fh:
+        return fh.read().strip() == _digest()
+
+
+def build(force=False, verbose=True):
+    """Compile every csrc/*.hip for gfx950 and link libuav_hip.so.  Returns the library path."""
+    if not force and is_fresh():
+        return LIB
+    if not os.path.exists(HIPCC):
+        raise RuntimeError(f"hipcc not found at {HIPCC}; cannot build libuav_hip.so")
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def cc(src):
+        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(cc, sources()))
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    with open(STAMP, "w") as fh:
+        fh.write(_digest())
+    if verbose:
+        print(f"[uav] built {LIB} from {len(objs)} objects", file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

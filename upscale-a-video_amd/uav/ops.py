@@ -1,0 +1,352 @@
+"""Tensor-level wrappers over the C ABI (include/uav_hip.h).
+
+PyTorch is used for device memory and streams only: every function takes CUDA(=HIP) tensors,
+passes `data_ptr()`s and the current stream to libuav_hip.so and returns torch tensors that own
+the output buffers.  Activations are channels-last fp16 matrices [rows][C], rows ordered
+(batch, frame, y, x).  There is no eager/CPU fallback.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+HALF = torch.float16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _req(t, dtype=None, name="tensor"):
+    if not t.is_cuda:
+        raise _lib.UavError(f"{name} must live on the GPU (libuav_hip.so has no CPU path)")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.UavError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.UavError(f"{name} must be contiguous")
+    return t
+
+
+_ZERO = {}
+
+
+def zero_page(device):
+    key = str(device)
+    if key not in _ZERO:
+        _ZERO[key] = torch.zeros(256, dtype=torch.uint8, device=device)
+    return _ZERO[key]
+
+
+# ------------------------------------------------------------------------------------------------
+@dataclass
+class ConvW:
+    """Packed weights of one conv / linear layer: fp16 [n_pad][k_pad], k = tap*cin_p + c."""
+    w: torch.Tensor
+    bias: Optional[torch.Tensor]
+    n: int            # logical output channels (GEGLU: 2*features)
+    n_pad: int
+    k_pad: int
+    cin: int          # logical input channels
+    cin_p: int        # padded input channels seen by the kernel (cin, or 8 in small mode)
+    kt: int
+    kh: int
+    kw: int
+    geglu: bool = False
+
+    @property
+    def n_out(self):
+        return self.n // 2 if self.geglu else self.n
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def pack_conv(weight, bias=None, geglu=False, device=None, n_store_align=4):
+    """Pack an nn.Conv2d (O,I,kh,kw) / nn.Conv3d (O,I,kt,kh,kw) / nn.Linear (O,I) weight.
+
+    k index = ((dt*kh + dy)*kw + dx)*cin_p + c.  Inputs with cin % 64 != 0 use the "small" mode:
+    channels padded to 8 (requires cin <= 8).  GEGLU: rows re-ordered in blocks of
+    [32 value rows | 32 gate rows] (diffusers GEGLU chunk order: value first, gate second).
+    """
+    w = weight.detach()
+    if w.dim() == 2:
+        w = w[:, :, None, None, None]
+    elif w.dim() == 4:
+        w = w[:, :, None]
+    assert w.dim() == 5
+    o, i, kt, kh, kw = w.shape
+    b = None if bias is None else bias.detach().float()
+    if i % 64 == 0:
+        cin_p = i
+    elif i <= 8:
+        cin_p = 8
+    else:
+        raise _lib.UavError(f"conv input channels {i} unsupported (need multiple of 64 or <= 8)")
+    w = w.permute(0, 2, 3, 4, 1).float()                      # o, kt, kh, kw, c
+    if cin_p != i:
+        w = torch.nn.functional.pad(w, (0, cin_p - i))
+    w = w.reshape(o, kt * kh * kw * cin_p)
+    n = o
+    if geglu:
+        assert o % 64 == 0
+        f = o // 2
+        val = w[:f].reshape(f // 32, 32, -1)
+        gate = w[f:].reshape(f // 32, 32, -1)
+        w = torch.cat([val, gate], dim=1).reshape(o, -1)
+        if b is not None:
+            b = torch.cat([b[:f].reshape(f // 32, 32), b[f:].reshape(f // 32, 32)], dim=1).reshape(o)
+    if n % n_store_align:                                      # e.g. VAE conv_out: 3 -> 4 (zero row)
+        extra = n_store_align - n % n_store_align
+        w = torch.nn.functional.pad(w, (0, 0, 0, extra))
+        if b is not None:
+            b = torch.nn.functional.pad(b, (0, extra))
+        n += extra
+    k = w.shape[1]
+    n_pad, k_pad = _round_up(n, 128), _round_up(k, 64)
+    wp = torch.zeros(n_pad, k_pad, dtype=HALF)
+    wp[:n, :k] = w.to(HALF)
+    bp = None
+    if b is not None:
+        bp = torch.zeros(n_pad, dtype=torch.float32)
+        bp[:n] = b
+    dev = device if device is not None else weight.device
+    return ConvW(wp.to(dev), None if bp is None else bp.to(dev), n, n_pad, k_pad, i, cin_p, kt, kh, kw, geglu)
+
+
+def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None,
+              rowbias=None, rows_per_batch=0, residual=None, out_scale=1.0, out_f32=False, out=None):
+    """out[M][n_out] = scale*(conv(a1|a2, W) + bias + rowbias[m//rows_per_batch] + residual)."""
+    lib = _lib.load()
+    _req(a1, HALF, "a1")
+    c1 = a1.shape[-1]
+    c2 = 0
+    if a2 is not None:
+        _req(a2, HALF, "a2")
+        c2 = a2.shape[-1]
+    if c1 + c2 != wt.cin_p:
+        raise _lib.UavError(f"conv input channels {c1}+{c2} != packed {wt.cin_p}")
+    if pad is None:
+        pad = (wt.kt // 2, wt.kh // 2, wt.kw // 2)
+    pt, ph, pw = pad
+    if upsample:
+        ho, wo = 2 * hi, 2 * wi
+    else:
+        ho = (hi + 2 * ph - wt.kh) // stride + 1
+        wo = (wi + 2 * pw - wt.kw) // stride + 1
+    if a1.numel() != n_img * hi * wi * c1:
+        raise _lib.UavError(f"a1 has {a1.numel()} elements, expected {n_img}*{hi}*{wi}*{c1}")
+    m = n_img * ho * wo
+    n_out = wt.n_out
+    if out is None:
+        out = torch.empty((m, n_out), dtype=torch.float32 if out_f32 else HALF, device=a1.device)
+    flags = (_lib.CONV_GEGLU if wt.geglu else 0) | (_lib.CONV_OUT_F32 if out_f32 else 0)
+    p = _lib.ConvParams()
+    p.a1 = _p(a1); p.a2 = _p(a2); p.c1 = c1; p.c2 = c2
+    p.w = _p(wt.w); p.bias = _p(wt.bias)
+    p.rowbias = _p(rowbias); p.rows_per_batch = rows_per_batch
+    p.rowbias_stride = 0 if rowbias is None else rowbias.shape[-1]
+    if rowbias is not None:
+        _req(rowbias, torch.float32, "rowbias")
+    p.residual = _p(residual); p.res_stride = 0 if residual is None else residual.shape[-1]
+    if residual is not None:
+        _req(residual, HALF, "residual")
+        if residual.numel() != m * residual.shape[-1]:
+            raise _lib.UavError("residual rows != output rows")
+    p.out = _p(out); p.out_stride = out.shape[-1]
+    p.n_img = n_img; p.t_len = t_len; p.hi = hi; p.wi = wi; p.ho = ho; p.wo = wo
+    p.kt = wt.kt; p.kh = wt.kh; p.kw = wt.kw; p.stride = stride
+    p.pad_t = pt; p.pad_h = ph; p.pad_w = pw; p.upsample = 1 if upsample else 0
+    p.n = wt.n; p.n_pad = wt.n_pad; p.k_pad = wt.k_pad
+    p.out_scale = out_scale; p.flags = flags; p.zero_page = _p(zero_page(a1.device))
+    _lib.check(lib.uav_conv_gemm_f16(C.byref(p), _stream()), "uav_conv_gemm_f16")
+    return out
+
+
+def _factor_rows(m):
+    """m = n_img * hi with hi < 65536 (the kernel packs pixel coordinates in 16 bits)."""
+    if m < 65536:
+        return 1, m
+    for hi in range(min(m, 65535), 0, -1):
+        if m % hi == 0:
+            return m // hi, hi
+    raise _lib.UavError("unreachable")
+
+
+def linear(x, wt: ConvW, *, residual=None, out_scale=1.0, rowbias=None, rows_per_batch=0, out_f32=False):
+    """nn.Linear over token rows x[M][K] (a 1x1 'conv': every row is one pixel)."""
+    n_img, hi = _factor_rows(x.shape[0])
+    return conv_gemm(x, wt, n_img=n_img, t_len=1, hi=hi, wi=1, residual=residual, out_scale=out_scale,
+                     rowbias=rowbias, rows_per_batch=rows_per_batch, out_f32=out_f32)
+
+
+# ------------------------------------------------------------------------------------------------
+def groupnorm_scale_shift(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps, x2=None, c_real=None):
+    lib = _lib.load()
+    _req(x1, HALF, "x1")
+    c1 = x1.shape[-1]
+    c2 = 0 if x2 is None else _req(x2, HALF, "x2").shape[-1]
+    c = c1 + c2
+    if c_real is None:
+        c_real = c
+    scale = torch.empty((n_inst, c), dtype=torch.float32, device=x1.device)
+    shift = torch.empty_like(scale)
+    ws_bytes = lib.uav_groupnorm_workspace_bytes(n_inst, c)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x1.device)
+    rc = lib.uav_groupnorm_scale_shift(_p(x1), _p(x2), c1, c2, c_real, n_inst, rows_per_inst, groups, eps,
+                                       _p(gamma), _p(beta), _p(scale), _p(shift), _p(ws), ws_bytes, _stream())
+    _lib.check(rc, "uav_groupnorm_scale_shift")
+    return scale, shift
+
+
+def groupnorm_apply(x1, scale, shift, *, n_inst, rows_per_inst, silu, x2=None):
+    lib = _lib.load()
+    c1 = x1.shape[-1]
+    c2 = 0 if x2 is None else x2.shape[-1]
+    y = torch.empty((n_inst * rows_per_inst, c1 + c2), dtype=HALF, device=x1.device)
+    rc = lib.uav_groupnorm_apply(_p(x1), _p(x2), c1, c2, n_inst, rows_per_inst, _p(scale), _p(shift),
+                                 1 if silu else 0, _p(y), _stream())
+    _lib.check(rc, "uav_groupnorm_apply")
+    return y
+
+
+def groupnorm(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps, silu, x2=None, c_real=None):
+    """GroupNorm(+SiLU) over `n_inst` instances of `rows_per_inst` channels-last rows."""
+    sc, sh = groupnorm_scale_shift(x1, gamma, beta, n_inst=n_inst, rows_per_inst=rows_per_inst, groups=groups,
+                                   eps=eps, x2=x2, c_real=c_real)
+    return groupnorm_apply(x1, sc, sh, n_inst=n_inst, rows_per_inst=rows_per_inst, silu=silu, x2=x2)
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    lib = _lib.load()
+    _req(x, HALF, "x")
+    y = torch.empty_like(x)
+    rows, c = x.numel() // x.shape[-1], x.shape[-1]
+    _lib.check(lib.uav_layernorm_f16(_p(x), _p(y), _p(gamma), _p(beta), rows, c, eps, _stream()), "uav_layernorm_f16")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+def attention(q, k, v, *, bq, lq, lk, heads, head_dim, q_per_kv=1, scale=None,
+              q_stride=None, k_stride=None, v_stride=None):
+    """softmax(scale*QK^T)V.  q/k/v are fp16 views whose row strides (in elements) may exceed
+    heads*head_dim (slices of a fused projection)."""
+    lib = _lib.load()
+    c = heads * head_dim
+    q_stride = q_stride or q.stride(-2)
+    k_stride = k_stride or k.stride(-2)
+    v_stride = v_stride or v.stride(-2)
+    out = torch.empty((bq * lq, c), dtype=HALF, device=q.device)
+    if scale is None:
+        scale = head_dim ** -0.5
+    rc = lib.uav_attention_f16(_p(q), q_stride, _p(k), k_stride, _p(v), v_stride, _p(out), c, bq, lq, lk, q_per_kv,
+                               heads, head_dim, scale, _p(zero_page(q.device)), _stream())
+    _lib.check(rc, "uav_attention_f16")
+    return out
+
+
+def temporal_attention(qkv, *, n_batch, t_len, hw, c, heads, scale, rope_cos, rope_sin, rot_dim, bias):
+    lib = _lib.load()
+    _req(qkv, HALF, "qkv")
+    out = torch.empty((n_batch * t_len * hw, c), dtype=HALF, device=qkv.device)
+    rc = lib.uav_temporal_attention_f16(_p(qkv), _p(out), n_batch, t_len, hw, c, heads, scale, _p(rope_cos),
+                                        _p(rope_sin), rot_dim, _p(bias), _stream())
+    _lib.check(rc, "uav_temporal_attention_f16")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+def linear_small(x, w, b, *, pre_silu=False, post_silu=False):
+    """fp32 x[m<=16][k] @ fp16 w[n][k]^T + b."""
+    lib = _lib.load()
+    _req(x, torch.float32, "x"); _req(w, HALF, "w")
+    m, k = x.shape
+    n = w.shape[0]
+    y = torch.empty((m, n), dtype=torch.float32, device=x.device)
+    rc = lib.uav_linear_small(_p(x), _p(w), _p(b), _p(y), m, k, n, int(pre_silu), int(post_silu), _stream())
+    _lib.check(rc, "uav_linear_small")
+    return y
+
+
+def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0):
+    lib = _lib.load()
+    _req(t, torch.float32, "t")
+    out = torch.empty((t.numel(), dim), dtype=torch.float32, device=t.device)
+    rc = lib.uav_timestep_embedding(_p(t), t.numel(), dim, int(flip_sin_to_cos), freq_shift, _p(out), _stream())
+    _lib.check(rc, "uav_timestep_embedding")
+    return out
+
+
+def pack_nhwc(src1, src2=None, c_pad=8, scale=1.0):
+    """(B,C,T,H,W) [+ second tensor concatenated on C] -> channels-last fp16 rows [B*T*H*W][c_pad]."""
+    lib = _lib.load()
+    _req(src1, None, "src1")
+    b, c1, t, h, w = src1.shape
+    c2 = 0
+    if src2 is not None:
+        _req(src2, src1.dtype, "src2")
+        c2 = src2.shape[1]
+    is_f32 = src1.dtype == torch.float32
+    if not is_f32 and src1.dtype != HALF:
+        raise _lib.UavError("pack_nhwc: fp16 or fp32 input expected")
+    dst = torch.empty((b * t * h * w, c_pad), dtype=HALF, device=src1.device)
+    rc = lib.uav_pack_nhwc(_p(src1), c1, _p(src2), c2, int(is_f32), _p(dst), c_pad, b, t, h * w, scale, _stream())
+    _lib.check(rc, "uav_pack_nhwc")
+    return dst
+
+
+def unpack_ncthw(src, *, c, n_batch, t_len, h, w, out_dtype=HALF, clamp=None):
+    lib = _lib.load()
+    _req(src, None, "src")
+    lo, hi = (-3.0e38, 3.0e38) if clamp is None else clamp
+    dst = torch.empty((n_batch, c, t_len, h, w), dtype=out_dtype, device=src.device)
+    rc = lib.uav_unpack_ncthw(_p(src), src.shape[-1], int(src.dtype == torch.float32), _p(dst),
+                              int(out_dtype == torch.float32), c, n_batch, t_len, h * w, lo, hi, _stream())
+    _lib.check(rc, "uav_unpack_ncthw")
+    return dst
+
+
+def cfg_ddim_v0(eps_uncond, eps_text, sample, *, guidance, coef_sample, coef_eps, clip=False, clip_range=1.0):
+    lib = _lib.load()
+    _req(eps_uncond, HALF, "eps"); _req(sample, HALF, "sample")
+    g = torch.empty_like(sample); x0 = torch.empty_like(sample)
+    rc = lib.uav_cfg_ddim_v0(_p(eps_uncond), _p(eps_text), _p(sample), _p(g), _p(x0), sample.numel(), guidance,
+                             coef_sample, coef_eps, int(clip), clip_range, _stream())
+    _lib.check(rc, "uav_cfg_ddim_v0")
+    return g, x0
+
+
+def ddim_vt(x0, guided, sample, *, coef_x0, coef_dir, eps_from_model, eps_from_sample, eps_from_x0=0.0):
+    lib = _lib.load()
+    prev = torch.empty_like(sample)
+    rc = lib.uav_ddim_vt(_p(_req(x0, HALF)), _p(_req(guided, HALF)), _p(_req(sample, HALF)), _p(prev), sample.numel(),
+                         coef_x0, coef_dir, eps_from_model, eps_from_sample, eps_from_x0, _stream())
+    _lib.check(rc, "uav_ddim_vt")
+    return prev
+
+
+def axpby(x, z, a, b):
+    lib = _lib.load()
+    y = torch.empty_like(x)
+    _lib.check(lib.uav_axpby_f16(_p(_req(x, HALF)), _p(_req(z, HALF)), _p(y), x.numel(), a, b, _stream()), "uav_axpby_f16")
+    return y
+
+
+def propagate_step(feat_prev, feat_cur, flow_prop, flow_check, *, nearest, coord_f16, fuse_scale, alpha1, alpha2):
+    """One recurrence step on planar fp16 (c,h,w) features with (2,h,w) flows."""
+    lib = _lib.load()
+    c, h, w = feat_cur.shape[-3:]
+    out = torch.empty_like(feat_cur)
+    rc = lib.uav_propagate_step_f16(_p(_req(feat_prev, HALF)), _p(_req(feat_cur, HALF)), _p(_req(flow_prop, HALF)),
+                                    _p(_req(flow_check, HALF)), _p(out), c, h, w, int(nearest), int(coord_f16),
+                                    fuse_scale, alpha1, alpha2, _stream())
+    _lib.check(rc, "uav_propagate_step_f16")
+    return out
