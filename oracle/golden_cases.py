@@ -1,0 +1,91 @@
+"""TEST INFRASTRUCTURE ONLY.  Reduced-width configs and seeded inputs shared by
+oracle/make_golden.py (reference side, build container) and tests/ (engine side, GPU box).
+
+The configs keep the reference's full topology (4 down / mid / 4 up blocks, temporal modules
+everywhere, cross-only + self attention, 32 GroupNorm groups) at 1/4 width, so every code path
+of the north-star model is exercised while the CPU reference runs in seconds.
+`attention_head_dim` is the head COUNT in this model: 2 heads -> head dims 64 /
+64 / 128, the head dims of the full model.
+"""
+import torch
+
+import synth
+
+UNET_TINY = {
+    "act_fn": "silu", "attention_head_dim": 2, "block_out_channels": [64, 128, 128, 256],
+    "center_input_sample": False, "cross_attention_dim": 64,
+    "down_block_types": ["DownBlock3D", "CrossAttnDownBlock3D", "CrossAttnDownBlock3D", "CrossAttnDownBlock3D"],
+    "downsample_padding": 1, "dual_cross_attention": False, "flip_sin_to_cos": True, "freq_shift": 0,
+    "in_channels": 7, "layers_per_block": 2, "mid_block_scale_factor": 1, "norm_eps": 1e-05,
+    "norm_num_groups": 32, "num_class_embeds": 1000, "only_cross_attention": [True, True, True, False],
+    "out_channels": 4, "sample_size": 128,
+    "up_block_types": ["CrossAttnUpBlock3D", "CrossAttnUpBlock3D", "CrossAttnUpBlock3D", "UpBlock3D"],
+    "use_linear_projection": True, "down_temporal_idx": [0, 1, 2, 3], "mid_temporal": True,
+    "up_temporal_idx": [0, 1, 2, 3], "temporal_module_config": {"attention_block_types": ["", ""]},
+}
+
+VAE3D_TINY = {
+    "act_fn": "silu", "block_out_channels": [64, 64, 128],
+    "down_block_types": ["DownEncoderBlock3D"] * 3, "in_channels": 3, "latent_channels": 4,
+    "layers_per_block": 2, "norm_num_groups": 32, "out_channels": 3, "sample_size": 256,
+    "up_block_types": ["UpDecoderBlock3D"] * 3, "scaling_factor": 0.08333,
+}
+
+VAEVIDEO_TINY = dict(VAE3D_TINY, up_block_types=["UpDecoderBlock3D_plus"] * 3, condition_img=True,
+                     condition_channels=64, use_temporal_block=True)
+
+# upstream SD-x4-upscaler scheduler_config.json values (absent from the reference tree)
+SCHED = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+             clip_sample=False, set_alpha_to_one=False, steps_offset=1, prediction_type="v_prediction")
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def unet_inputs(bsz, t, h, w, cross_dim, seed=100):
+    g = _g(seed + t * 7 + h)
+    sample = torch.randn(1, 4, t, h, w, generator=g).half().float().repeat(bsz, 1, 1, 1, 1)
+    low = torch.randn(1, 3, t, h, w, generator=g).half().float().repeat(bsz, 1, 1, 1, 1)
+    ehs = torch.randn(bsz, 77, cross_dim, generator=g).half().float()
+    return sample, low, ehs, 925, torch.tensor([120], dtype=torch.long)
+
+
+def vae_inputs(bsz, t, h, w, seed=200):
+    g = _g(seed + t + h)
+    z = (torch.randn(bsz, 4, t, h, w, generator=g) * 2.0).half().float()
+    img = synth.synth_clip(bsz, t, h, w, seed=seed)
+    return z, img
+
+
+def prop_inputs(t, h, w, seed=300):
+    """x0 latents + bidirectional flows of a (2,1) px/frame translation with noise and an
+    occluded band; sub-pixel parts of .3 keep nearest-neighbour rounding away from .5 ties."""
+    g = _g(seed)
+    x = torch.randn(1, 4, t, h, w, generator=g).half().float()
+    ff = torch.zeros(1, 2, t - 1, h, w); fb = torch.zeros(1, 2, t - 1, h, w)
+    ff[:, 0] = 2.3; ff[:, 1] = 1.3; fb[:, 0] = -2.3; fb[:, 1] = -1.3
+    ff = ff + 0.02 * torch.randn(ff.shape, generator=g); fb = fb + 0.02 * torch.randn(fb.shape, generator=g)
+    fb[:, :, :, h // 3: h // 2] += 3.0                      # inconsistent region -> mask = 0
+    return x, ff.half().float(), fb.half().float()
+
+
+PIPE_CASES = {
+    # plumbing case of BASELINE config 1 shape family, scaled to run on CPU in seconds
+    "pipe_t8_vae3d": dict(vae="vae3d", t=8, h=16, w=16, steps=3, guidance=6.0, noise_level=120,
+                          prompt="best quality, extremely detailed", negative="blur, worst quality",
+                          propagation_steps=()),
+    # sliding-window branch (T > 8: windows [0,8) and [2,10)) + propagation + video VAE
+    "pipe_t10_vaevideo_prop": dict(vae="vaevideo", t=10, h=16, w=24, steps=3, guidance=6.0, noise_level=120,
+                                   prompt="best quality, extremely detailed", negative="blur, worst quality",
+                                   propagation_steps=(1,)),
+}
+
+
+def pipeline_inputs(case, seed=400):
+    image = synth.synth_clip(1, case["t"], case["h"], case["w"], seed=seed)
+    flows = None
+    if case["propagation_steps"]:
+        _, ff, fb = prop_inputs(case["t"], case["h"], case["w"], seed=seed + 1)
+        flows = [ff, fb]
+    return image, flows

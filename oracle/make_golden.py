@@ -1,0 +1,188 @@
+"""TEST INFRASTRUCTURE ONLY.  Run in the build container (needs /root/reference):
+
+    python oracle/make_golden.py
+
+1. imports the reference's own modules unmodified (oracle/ref_stubs.py),
+2. instantiates reduced-width configs with seeded synthetic weights (oracle/synth.py),
+3. runs the reference on CPU fp32 and the restatement oracle/uav_oracle.py on the same inputs,
+   records their agreement in tests/golden/PINNING.json (this is what pins the oracle),
+4. writes the reference outputs as small fixtures under tests/golden/ (fp16/fp32 .pt files).
+
+The GPU box has no /root/reference: tests there regenerate the inputs from the same seeds, run the
+HIP engine and compare against these fixtures and against the oracle.
+"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+import ref_stubs  # noqa: E402
+import synth  # noqa: E402
+import uav_oracle as O  # noqa: E402
+from golden_cases import (UNET_TINY, VAE3D_TINY, VAEVIDEO_TINY, SCHED, unet_inputs, vae_inputs, prop_inputs,  # noqa: E402
+                          pipeline_inputs, PIPE_CASES)
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def maxabs(a, b):
+    return (a.float() - b.float()).abs().max().item()
+
+
+def rel_l2(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
+
+
+class _Tok:
+    """Stand-in tokenizer: ids carry the index of the prompt string."""
+    model_max_length = 77
+
+    def __init__(self):
+        self.prompts = []
+
+    def __call__(self, prompt, padding=None, max_length=None, truncation=None, return_tensors=None):
+        prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+        ids = []
+        for p in prompts:
+            if p not in self.prompts:
+                self.prompts.append(p)
+            ids.append(torch.full((77,), self.prompts.index(p), dtype=torch.long))
+        import types
+        return types.SimpleNamespace(input_ids=torch.stack(ids), attention_mask=None)
+
+    def batch_decode(self, ids):
+        return [""]
+
+
+class _TextEnc(torch.nn.Module):
+    def __init__(self, tok, dim):
+        super().__init__()
+        self.tok, self.dim = tok, dim
+        self.dummy = torch.nn.Parameter(torch.zeros(1))
+        import types
+        self.config = types.SimpleNamespace()
+
+    @property
+    def dtype(self):
+        return torch.float32
+
+    def forward(self, ids, attention_mask=None):
+        return (torch.cat([synth.synth_prompt_embeds(self.tok.prompts[int(r[0])], self.dim) for r in ids]),)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    ns = ref_stubs.import_reference()
+    pin = {"reference_root": ref_stubs.REFERENCE_ROOT, "torch": torch.__version__, "cases": {}}
+
+    # ---------------- UNet ----------------------------------------------------------------------
+    unet = ns.unet_video.UNetVideoModel.from_config(dict(UNET_TINY)).eval()
+    usd = synth.synth_state_dict(unet.state_dict(), seed=1234)
+    unet.load_state_dict(usd, strict=True)
+    for name, (bsz, t, h, w) in {"unet_t4_16": (2, 4, 16, 16), "unet_t8_32": (2, 8, 32, 32)}.items():
+        sample, low, ehs, ts, cl = unet_inputs(bsz, t, h, w, UNET_TINY["cross_attention_dim"])
+        with torch.no_grad():
+            t0 = time.time()
+            ref = unet(sample, torch.tensor(ts), low, encoder_hidden_states=ehs, class_labels=cl).sample
+            t_ref = time.time() - t0
+            mine = O.unet_forward(usd, UNET_TINY, sample, ts, low, ehs, cl)
+        pin["cases"][name] = {"maxabs_oracle_vs_reference": maxabs(mine, ref), "rel_l2": rel_l2(mine, ref),
+                              "ref_absmean": ref.abs().mean().item(), "ref_seconds": t_ref}
+        torch.save(ref.half(), os.path.join(GOLD, name + ".pt"))
+        print(name, pin["cases"][name], flush=True)
+
+    # ---------------- VAE (both configs) --------------------------------------------------------
+    vaes = {}
+    for name, cfg in (("vae3d", VAE3D_TINY), ("vaevideo", VAEVIDEO_TINY)):
+        vae = ns.vae.AutoencoderKLVideo.from_config(dict(cfg)).eval()
+        vsd = synth.synth_state_dict(vae.state_dict(), seed=4321)
+        vae.load_state_dict(vsd, strict=True)
+        vaes[name] = (vae, vsd, cfg)
+        z, img = vae_inputs(1, 3, 16, 16)
+        with torch.no_grad():
+            ref = vae.decode(z, img, 1.0).sample
+            mine = O.vae_decode(vsd, cfg, z, img, 1.0)
+        key = name + "_t3_16"
+        pin["cases"][key] = {"maxabs_oracle_vs_reference": maxabs(mine, ref), "rel_l2": rel_l2(mine, ref),
+                             "ref_absmean": ref.abs().mean().item()}
+        torch.save(ref.half(), os.path.join(GOLD, key + ".pt"))
+        print(key, pin["cases"][key], flush=True)
+
+    # ---------------- scheduler -----------------------------------------------------------------
+    sch = ns.scheduling_ddim.DDIMScheduler(**SCHED)
+    sch.set_timesteps(30)
+    mine = O.DDIM(**SCHED)
+    ts30 = mine.set_timesteps(30)
+    assert ts30 == [int(v) for v in sch.timesteps.tolist()], (ts30, sch.timesteps.tolist())
+    g = torch.Generator().manual_seed(5)
+    eps, x = torch.randn(1, 4, 3, 8, 8, generator=g), torch.randn(1, 4, 3, 8, 8, generator=g)
+    worst = 0.0
+    for t in (ts30[0], ts30[7], ts30[-1]):
+        x0r = sch.step_v0(eps, t, x).pred_original_sample
+        prr = sch.step_vt(x0r, eps, t, x).prev_sample
+        worst = max(worst, maxabs(mine.step_v0(eps, t, x), x0r), maxabs(mine.step_vt(x0r, eps, t, x), prr))
+    pin["cases"]["ddim"] = {"timesteps30": ts30, "maxabs_oracle_vs_reference": worst}
+    json.dump({"timesteps30": ts30, "alphas_cumprod_at": {str(t): float(mine.alphas_cumprod[t]) for t in ts30}},
+              open(os.path.join(GOLD, "ddim.json"), "w"))
+    print("ddim", worst, ts30[:3], ts30[-2:], flush=True)
+
+    # ---------------- propagation ---------------------------------------------------------------
+    prop = ns.propagation.Propagation(4, learnable=False)
+    x, ff, fb = prop_inputs(8, 24, 32)
+    for interp in ("nearest", "bilinear"):
+        with torch.no_grad():
+            ref = prop(x, ff, fb, interpolation=interp, mode="fuse", fuse_scale=0.5, alpha1=0.001, alpha2=0.05)
+            mine_p = O.propagation(x, ff, fb, interp, 0.5, 0.001, 0.05)
+        key = "propagation_" + interp
+        pin["cases"][key] = {"maxabs_oracle_vs_reference": maxabs(mine_p, ref),
+                             "changed_fraction": (ref != x).float().mean().item()}
+        torch.save(ref.half(), os.path.join(GOLD, key + ".pt"))
+        print(key, pin["cases"][key], flush=True)
+
+    # ---------------- pipeline end-to-end (tiny) ------------------------------------------------
+    tok = _Tok()
+    for name, case in PIPE_CASES.items():
+        vae, vsd, vcfg = vaes[case["vae"]]
+        pipe = ns.pipeline.VideoUpscalePipeline(
+            text_encoder=_TextEnc(tok, UNET_TINY["cross_attention_dim"]), tokenizer=tok,
+            low_res_scheduler=ref_stubs.DDPMScheduler(beta_schedule="scaled_linear", beta_start=0.0001, beta_end=0.02),
+            scheduler=ns.scheduling_ddim.DDIMScheduler(**SCHED), vae=vae, unet=unet,
+            propagator=prop if case["propagation_steps"] else None)
+        image, flows = pipeline_inputs(case)
+        gen = torch.Generator().manual_seed(10)
+        t0 = time.time()
+        out = pipe(case["prompt"], image=image, flows_bi=flows, generator=gen, num_inference_steps=case["steps"],
+                   guidance_scale=case["guidance"], noise_level=case["noise_level"], negative_prompt=case["negative"],
+                   propagation_steps=list(case["propagation_steps"]), return_dict=False)
+        t_ref = time.time() - t0
+        ref_img, ref_lat = out
+        gen = torch.Generator().manual_seed(10)
+        lr_noise = torch.randn(image.shape, generator=gen)
+        lat0 = torch.randn((1, 4) + tuple(image.shape[2:]), generator=gen)
+        pe = torch.cat([synth.synth_prompt_embeds(case["negative"], UNET_TINY["cross_attention_dim"]),
+                        synth.synth_prompt_embeds(case["prompt"], UNET_TINY["cross_attention_dim"])])
+        with torch.no_grad():
+            img, lat = O.pipeline_call(usd, UNET_TINY, vsd, vcfg, image, pe, num_inference_steps=case["steps"],
+                                       guidance_scale=case["guidance"], noise_level=case["noise_level"],
+                                       lr_noise=lr_noise, latents=lat0, flows_bi=flows,
+                                       propagation_steps=case["propagation_steps"], scheduler_kwargs=SCHED)
+        pin["cases"][name] = {"latents_maxabs_oracle_vs_reference": maxabs(lat, ref_lat),
+                              "latents_rel_l2": rel_l2(lat, ref_lat),
+                              "image_maxabs_oracle_vs_reference": maxabs(img, ref_img),
+                              "image_saturated_fraction": (ref_img.abs() >= 1).float().mean().item(),
+                              "ref_seconds": t_ref}
+        torch.save({"latents": ref_lat.half(), "images": ref_img.half()}, os.path.join(GOLD, name + ".pt"))
+        print(name, pin["cases"][name], flush=True)
+
+    json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
+    print("wrote", GOLD)
+
+
+if __name__ == "__main__":
+    main()
