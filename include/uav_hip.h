@@ -172,19 +172,23 @@ int uav_cfg_ddim_v0(const void* eps_uncond, const void* eps_text, const void* sa
                     void* stream);
 int uav_ddim_vt(const void* x0, const void* guided, const void* sample, void* prev_out,
                 int64_t n, float coef_x0, float coef_dir, float eps_from_model,
-                float eps_from_sample, float eps_from_x0, void* stream);
+                float eps_from_sample, float eps_from_x0, int32_t clip, float clip_range,
+                void* stream);
 /* y = a*x + b*z  (add_noise: scheduling_ddim.py:524-545; window blend pipeline:630-634) */
 int uav_axpby_f16(const void* x, const void* z, void* y, int64_t n, float a, float b,
                   void* stream);
 
 /* ---- K10: flow-guided propagation step -----------------------------------------------
  * Replaces one recurrence step of Propagation.forward (propagation_module.py:234-254) with
- * fbConsistencyCheck (:140-149) and flow_warp (:104-135): planar fp16 (c,h,w) features.
+ * fbConsistencyCheck (:140-149) and flow_warp (:104-135): planar fp16 features, one frame of a
+ * (C,T,H,W) tensor addressed in place through the channel strides.
  *   mask = |f + warp_bilinear(check, f)|^2 < a1*(|f|^2 + |warp(check)|^2) + a2
  *   out  = mask ? fuse*warp_{nearest|bilinear}(prev, f) + (1-fuse)*cur : cur
  * Grid arithmetic is replayed in fp16 exactly as the reference does (SURVEY.md §7 hard part 4). */
 int uav_propagate_step_f16(const void* feat_prev, const void* feat_cur, const void* flow_prop,
                            const void* flow_check, void* out, int32_t c, int32_t h, int32_t w,
+                           int64_t feat_chan_stride, /* elements between channel planes of prev/cur/out */
+                           int64_t flow_chan_stride, /* elements between the x and y flow planes */
                            int32_t nearest,
                            int32_t coord_f16, /* 1: replay fp16 grid arithmetic; 0: fp32 */
                            float fuse_scale, float alpha1, float alpha2, void* stream);

@@ -30,7 +30,7 @@ def synth_tensor(name, shape, seed=1234):
     is_norm = any(s in name for s in ("norm", "group_norm")) and len(shape) == 1
     if leaf == "freqs":                      # RotaryEmbedding(dim): analytic, 1/10000^(2i/dim)
         dim = shape[0] * 2
-        return 1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim))
+        return (1.0 / (10000 ** (torch.arange(0, dim, 2).float() / dim))).half().float()   # as in a .half() UNet
     if leaf == "num_batches_tracked":
         return torch.zeros(shape, dtype=torch.long)
     if leaf == "running_var":

@@ -330,7 +330,8 @@ def test_propagate_step_fp32_coords(ops, dev, nearest):
     warped = ref_flow_warp(prev.float(), fpf, "nearest" if nearest else "bilinear")
     fused = warped * 0.5 + cur.float() * 0.5
     ref = valid * fused + (1 - valid) * cur.float()
-    out = ops.propagate_step(prev[0], cur[0], fp[0], fc[0], nearest=nearest, coord_f16=False, fuse_scale=0.5,
-                             alpha1=0.01, alpha2=0.5)
+    out = torch.empty_like(cur[0])
+    ops.propagate_step(prev[0], cur[0], fp[0], fc[0], out, c=c, h=h, w=w, feat_chan_stride=h * w, flow_chan_stride=h * w,
+                       nearest=nearest, coord_f16=False, fuse_scale=0.5, alpha1=0.01, alpha2=0.5)
     bad = ((out.float() - ref[0]).abs() > 2e-2).float().mean().item()
     assert bad < 2e-3, f"{bad} of pixels differ"          # threshold-boundary pixels may flip the mask

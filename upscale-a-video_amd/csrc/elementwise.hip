@@ -135,10 +135,12 @@ __global__ __launch_bounds__(256) void cfg_ddim_v0_kernel(const half_t* __restri
 // prev = cx0*x0 + cdir*(em*g + es*sample + e0*x0)
 __global__ __launch_bounds__(256) void ddim_vt_kernel(const half_t* __restrict__ x0, const half_t* __restrict__ g,
                                                       const half_t* __restrict__ x, half_t* __restrict__ prev,
-                                                      long long n, float cx0, float cdir, float em, float es, float e0) {
+                                                      long long n, float cx0, float cdir, float em, float es, float e0,
+                                                      int clip, float range) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float a = (float)x0[i];
+    float a = (float)x0[i];
+    if (clip) a = fminf(fmaxf(a, -range), range);
     const float eps = em * (float)g[i] + es * (float)x[i] + e0 * a;
     prev[i] = (half_t)(cx0 * a + cdir * eps);
 }
@@ -187,18 +189,19 @@ UAV_DEVINL float sample_bilinear(const half_t* __restrict__ plane, int w, int h,
 template <typename R>
 __global__ __launch_bounds__(256) void propagate_step_kernel(const half_t* __restrict__ prev, const half_t* __restrict__ cur,
                                                              const half_t* __restrict__ fprop, const half_t* __restrict__ fchk,
-                                                             half_t* __restrict__ out, int c, int h, int w, int nearest,
-                                                             float fuse, float a1, float a2) {
+                                                             half_t* __restrict__ out, int c, int h, int w, long long fcs,
+                                                             long long wcs, int nearest, float fuse, float a1, float a2) {
+    // fcs / wcs: channel strides (elements) of the feature planes / flow planes
     const long long hw = (long long)h * w;
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= hw) return;
     const int y = (int)(i / w), x = (int)(i % w);
-    const float fx = (float)fprop[i], fy = (float)fprop[hw + i];
+    const float fx = (float)fprop[i], fy = (float)fprop[wcs + i];
     float ix, iy;
     warp_coords<R>(x, y, fx, fy, w, h, ix, iy);
     // forward-backward consistency (fbConsistencyCheck)
     const float bx = sample_bilinear<R>(fchk, w, h, ix, iy);
-    const float by = sample_bilinear<R>(fchk + hw, w, h, ix, iy);
+    const float by = sample_bilinear<R>(fchk + wcs, w, h, ix, iy);
     const float dx = R::r(fx + bx), dy = R::r(fy + by);
     const float ldiff = R::r(R::r(dx * dx) + R::r(dy * dy));
     const float lf = R::r(R::r(fx * fx) + R::r(fy * fy));
@@ -212,15 +215,15 @@ __global__ __launch_bounds__(256) void propagate_step_kernel(const half_t* __res
         inb = xn >= 0 && xn < w && yn >= 0 && yn < h;
     }
     for (int ch = 0; ch < c; ++ch) {
-        const float cv = (float)cur[ch * hw + i];
+        const float cv = (float)cur[ch * fcs + i];
         float o = cv;
         if (valid) {
             float wv;
-            if (nearest) wv = inb ? (float)prev[ch * hw + (long long)yn * w + xn] : 0.f;
-            else wv = sample_bilinear<R>(prev + ch * hw, w, h, ix, iy);
+            if (nearest) wv = inb ? (float)prev[ch * fcs + (long long)yn * w + xn] : 0.f;
+            else wv = sample_bilinear<R>(prev + ch * fcs, w, h, ix, iy);
             o = R::r(R::r(wv * fuse) + R::r(cv * (1.0f - fuse)));
         }
-        out[ch * hw + i] = (half_t)o;
+        out[ch * fcs + i] = (half_t)o;
     }
 }
 
@@ -303,11 +306,11 @@ extern "C" int uav_cfg_ddim_v0(const void* eps_uncond, const void* eps_text, con
 
 extern "C" int uav_ddim_vt(const void* x0, const void* guided, const void* sample, void* prev_out, int64_t n,
                            float coef_x0, float coef_dir, float eps_from_model, float eps_from_sample, float eps_from_x0,
-                           void* stream) {
+                           int32_t clip, float clip_range, void* stream) {
     if (!x0 || !guided || !sample || !prev_out || n <= 0) return UAV_EINVAL;
     hipLaunchKernelGGL(ddim_vt_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x0,
                        (const half_t*)guided, (const half_t*)sample, (half_t*)prev_out, (long long)n, coef_x0, coef_dir,
-                       eps_from_model, eps_from_sample, eps_from_x0);
+                       eps_from_model, eps_from_sample, eps_from_x0, clip, clip_range);
     return uav_launch_status();
 }
 
@@ -319,19 +322,21 @@ extern "C" int uav_axpby_f16(const void* x, const void* z, void* y, int64_t n, f
 }
 
 extern "C" int uav_propagate_step_f16(const void* feat_prev, const void* feat_cur, const void* flow_prop,
-                                      const void* flow_check, void* out, int32_t c, int32_t h, int32_t w, int32_t nearest,
+                                      const void* flow_check, void* out, int32_t c, int32_t h, int32_t w,
+                                      int64_t feat_chan_stride, int64_t flow_chan_stride, int32_t nearest,
                                       int32_t coord_f16, float fuse_scale, float alpha1, float alpha2, void* stream) {
     if (!feat_prev || !feat_cur || !flow_prop || !flow_check || !out) return UAV_EINVAL;
     if (c <= 0 || h <= 0 || w <= 0) return UAV_ESHAPE;
     const long long hw = (long long)h * w;
+    if (feat_chan_stride < hw || flow_chan_stride < hw) return UAV_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
     if (coord_f16)
         hipLaunchKernelGGL(propagate_step_kernel<RoundF16>, dim3(nblk(hw, 256)), dim3(256), 0, s, (const half_t*)feat_prev,
                            (const half_t*)feat_cur, (const half_t*)flow_prop, (const half_t*)flow_check, (half_t*)out, c, h,
-                           w, nearest, fuse_scale, alpha1, alpha2);
+                           w, (long long)feat_chan_stride, (long long)flow_chan_stride, nearest, fuse_scale, alpha1, alpha2);
     else
         hipLaunchKernelGGL(propagate_step_kernel<RoundF32>, dim3(nblk(hw, 256)), dim3(256), 0, s, (const half_t*)feat_prev,
                            (const half_t*)feat_cur, (const half_t*)flow_prop, (const half_t*)flow_check, (half_t*)out, c, h,
-                           w, nearest, fuse_scale, alpha1, alpha2);
+                           w, (long long)feat_chan_stride, (long long)flow_chan_stride, nearest, fuse_scale, alpha1, alpha2);
     return uav_launch_status();
 }

@@ -1,0 +1,259 @@
+"""MI355X-native transformer blocks of Upscale-A-Video (drop-in for the reference's
+`models_video/attention.py`: CrossAttention :44, Transformer3DModel :292, BasicTransformerBlock
+:414, TemporalAttention :626, RelativePositionBias :735).
+
+State-dict keys and constructor arguments follow the reference; execution is channels-last on the
+HIP kernel library:
+  * q/k/v projections are fused GEMMs (`uav_conv_gemm_f16`), to_out carries bias + residual in
+    its epilogue, the GEGLU feed-forward gates in the up-projection's epilogue;
+  * spatial self-attention / text cross-attention run in the flash kernel `uav_attention_f16`
+    (scores never reach HBM; reference attention.py:214-234 materialises them);
+  * text K/V are projected ONCE per prompt tensor (the reference recomputes them per frame and per
+    step, attention.py:364,177-178);
+  * temporal attention reads the (B,T,H,W,C) rows in place (`uav_temporal_attention_f16`): the
+    reference's (b f) d c <-> (b d) f c transposes (attention.py:555,560) do not exist here,
+    LayerNorm and the projections are per-token and need no re-ordering.
+"""
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from uav import engine as E
+from uav import ops
+
+from ._compat import BaseOutput, ConfigMixin, ModelMixin, register_to_config
+from .resnet import ResnetBlock3DCNN
+
+
+@dataclass
+class Transformer3DModelOutput(BaseOutput):
+    sample: torch.FloatTensor
+
+
+class RotaryEmbedding(nn.Module):
+    """Parameter container of rotary-embedding-torch's RotaryEmbedding(dim): `freqs` appears in the
+    reference state dict (one shared instance, unet_video.py:203)."""
+
+    def __init__(self, dim, theta=10000):
+        super().__init__()
+        self.dim = dim
+        self.freqs = nn.Parameter(1.0 / (theta ** (torch.arange(0, dim, 2)[: dim // 2].float() / dim)), requires_grad=False)
+
+
+class RelativePositionBias(nn.Module):
+    """T5-style bucketed relative position bias (reference attention.py:735-772)."""
+
+    def __init__(self, heads=8, num_buckets=32, max_distance=128):
+        super().__init__()
+        self.num_buckets, self.max_distance = num_buckets, max_distance
+        self.relative_attention_bias = nn.Embedding(num_buckets, heads)
+
+    def bucket_table(self, n):
+        """Integer bucket index [n][n] (host-side index math)."""
+        nb = self.num_buckets // 2
+        max_exact = nb // 2
+        tab = torch.zeros((n, n), dtype=torch.long)
+        for i in range(n):
+            for j in range(n):
+                rel = j - i
+                m = -rel
+                ret = nb if m < 0 else 0
+                m = abs(m)
+                if m < max_exact:
+                    ret += m
+                else:
+                    v = max_exact + int(math.log(m / max_exact) / math.log(self.max_distance / max_exact) * (nb - max_exact))
+                    ret += min(v, nb - 1)
+                tab[i, j] = ret
+        return tab
+
+
+class CrossAttention(E.EngineModule):
+    """Spatial self-attention (cross_attention_dim=None) or text cross-attention."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, dropout=0.0, bias=False,
+                 upcast_attention=False, upcast_softmax=False, added_kv_proj_dim=None, norm_num_groups=None,
+                 use_relative_position=False):
+        super().__init__()
+        if added_kv_proj_dim is not None or norm_num_groups is not None or use_relative_position:
+            raise NotImplementedError("not used by the released UNet config")
+        inner = dim_head * heads
+        self.is_cross = cross_attention_dim is not None
+        cad = cross_attention_dim if cross_attention_dim is not None else query_dim
+        self.heads, self.dim_head, self.scale = heads, dim_head, dim_head ** -0.5
+        self._use_memory_efficient_attention_xformers = False
+        self.to_q = nn.Linear(query_dim, inner, bias=bias)
+        self.to_k = nn.Linear(cad, inner, bias=bias)
+        self.to_v = nn.Linear(cad, inner, bias=bias)
+        self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(dropout)])
+
+    def run(self, x, residual, *, bq, lq, text=None, q_per_kv=1):
+        """x: normalised tokens [bq*lq][C]; text: TextKV cache entry (k, v, lk) for cross-attention."""
+        c = self.heads * self.dim_head
+        if self.is_cross:
+            q = ops.linear(x, E.packed_conv(self, "q", self.to_q))
+            k, v, lk = text
+            o = ops.attention(q, k, v, bq=bq, lq=lq, lk=lk, heads=self.heads, head_dim=self.dim_head, q_per_kv=q_per_kv,
+                              scale=self.scale, q_stride=c, k_stride=2 * c, v_stride=2 * c)
+        else:
+            qkv = ops.linear(x, E.packed_cat(self, "qkv", [self.to_q, self.to_k, self.to_v]))
+            o = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], bq=bq, lq=lq, lk=lq, heads=self.heads,
+                              head_dim=self.dim_head, scale=self.scale, q_stride=3 * c, k_stride=3 * c, v_stride=3 * c)
+        return ops.linear(o, E.packed_conv(self, "out", self.to_out[0]), residual=residual)
+
+    def project_text(self, ehs_rows):
+        """K|V of the text tokens: [B*77][2C] (fused GEMM), computed once per prompt tensor."""
+        kv = ops.linear(ehs_rows, E.packed_cat(self, "kv", [self.to_k, self.to_v]))
+        c = self.heads * self.dim_head
+        return kv[:, :c], kv[:, c:]
+
+
+class TemporalAttention(CrossAttention):
+    """Per-pixel attention over the frame axis with RoPE + relative position bias
+    (reference attention.py:626-733)."""
+
+    def __init__(self, query_dim, cross_attention_dim=None, heads=8, dim_head=64, dropout=0.0, bias=False,
+                 upcast_attention=False, upcast_softmax=False, added_kv_proj_dim=None, norm_num_groups=None,
+                 rotary_emb=None):
+        super().__init__(query_dim, cross_attention_dim, heads, dim_head, dropout, bias, upcast_attention,
+                         upcast_softmax, added_kv_proj_dim, norm_num_groups)
+        self.time_rel_pos_bias = RelativePositionBias(heads=heads, max_distance=32)
+        self.rotary_emb = rotary_emb
+
+    def _tables(self, t_len):
+        def build():
+            dev = E._dev(self.to_q.weight)
+            tab = self.time_rel_pos_bias.bucket_table(t_len).to(dev)
+            w = self.time_rel_pos_bias.relative_attention_bias.weight.detach().float()
+            bias = w[tab].permute(2, 0, 1).contiguous()                          # (heads, T, T)
+            if self.rotary_emb is not None:
+                fr = self.rotary_emb.freqs.detach().float().to(dev)
+                ang = torch.arange(t_len, device=dev, dtype=torch.float32)[:, None] * fr[None, :]
+                return bias, ang.cos().contiguous(), ang.sin().contiguous(), 2 * fr.numel()
+            return bias, None, None, 0
+        return self._cache().get(("ttab", t_len), build)
+
+    def run_temporal(self, x, residual, g: E.Geom):
+        c = self.heads * self.dim_head
+        bias, cos, sin, rot = self._tables(g.t)
+        qkv = ops.linear(x, E.packed_cat(self, "qkv", [self.to_q, self.to_k, self.to_v]))
+        o = ops.temporal_attention(qkv, n_batch=g.b, t_len=g.t, hw=g.hw, c=c, heads=self.heads, scale=self.scale,
+                                   rope_cos=cos, rope_sin=sin, rot_dim=rot, bias=bias)
+        return ops.linear(o, E.packed_conv(self, "out", self.to_out[0]), residual=residual)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+
+class FeedForward(E.EngineModule):
+    """diffusers FeedForward(dim, activation_fn='geglu') (spec: diffusers_attention.py:735-823)."""
+
+    def __init__(self, dim, dim_out=None, mult=4, dropout=0.0, activation_fn="geglu"):
+        super().__init__()
+        if activation_fn != "geglu":
+            raise NotImplementedError(activation_fn)
+        inner = int(dim * mult)
+        self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim_out or dim)])
+
+    def run(self, x, residual):
+        h = ops.linear(x, E.packed_conv(self, "up", self.net[0].proj, geglu=True))
+        return ops.linear(h, E.packed_conv(self, "down", self.net[2]), residual=residual)
+
+
+class BasicTransformerBlock(E.EngineModule):
+    def __init__(self, dim, num_attention_heads, attention_head_dim, dropout=0.0, cross_attention_dim=None,
+                 activation_fn="geglu", num_embeds_ada_norm=None, attention_bias=False, only_cross_attention=False,
+                 upcast_attention=False, use_first_frame=False, use_relative_position=False, rotary_emb=None):
+        super().__init__()
+        if num_embeds_ada_norm is not None or use_first_frame:
+            raise NotImplementedError("AdaLayerNorm / SparseCausalAttention are not used by the released config")
+        self.only_cross_attention = only_cross_attention
+        self.attn1 = CrossAttention(query_dim=dim, heads=num_attention_heads, dim_head=attention_head_dim, dropout=dropout,
+                                    bias=attention_bias, cross_attention_dim=cross_attention_dim if only_cross_attention else None)
+        self.norm1 = nn.LayerNorm(dim)
+        if cross_attention_dim is not None:
+            self.attn2 = CrossAttention(query_dim=dim, cross_attention_dim=cross_attention_dim, heads=num_attention_heads,
+                                        dim_head=attention_head_dim, dropout=dropout, bias=attention_bias)
+            self.norm2 = nn.LayerNorm(dim)
+        else:
+            self.attn2, self.norm2 = None, None
+        self.attn_temporal = TemporalAttention(query_dim=dim, heads=num_attention_heads, dim_head=attention_head_dim,
+                                               dropout=dropout, bias=attention_bias, rotary_emb=rotary_emb)
+        nn.init.zeros_(self.attn_temporal.to_out[0].weight.data)
+        self.norm_temporal = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn)
+        self.norm3 = nn.LayerNorm(dim)
+
+    def _text_kv(self, attn, ehs_rows, tag):
+        """K/V of the text tokens, cached per prompt tensor: the cache holds a reference to
+        `ehs_rows` (so its storage cannot be recycled) and is keyed on identity + version."""
+        c = self._cache()
+        hit = c.store.get(("textkv", tag))
+        if hit is not None and hit[0] is ehs_rows and hit[1] == ehs_rows._version:
+            return hit[2]
+        kv = attn.project_text(ehs_rows)
+        c.store[("textkv", tag)] = (ehs_rows, ehs_rows._version, kv)
+        return kv
+
+    def run(self, x, g: E.Geom, ehs_rows, n_text):
+        """x: tokens [B*T*HW][C] (rows ordered b,t,p); ehs_rows: [B*n_text][Cx] fp16."""
+        bq, lq = g.n_img, g.hw
+        n = E.layer_norm(self, "norm1", self.norm1, x)
+        if self.only_cross_attention:
+            k, v = self._text_kv(self.attn1, ehs_rows, "a1")
+            x = self.attn1.run(n, x, bq=bq, lq=lq, text=(k, v, n_text), q_per_kv=g.t)
+        else:
+            x = self.attn1.run(n, x, bq=bq, lq=lq)
+        if self.attn2 is not None:
+            n = E.layer_norm(self, "norm2", self.norm2, x)
+            k, v = self._text_kv(self.attn2, ehs_rows, "a2")
+            x = self.attn2.run(n, x, bq=bq, lq=lq, text=(k, v, n_text), q_per_kv=g.t)
+        n = E.layer_norm(self, "norm_temporal", self.norm_temporal, x)
+        x = self.attn_temporal.run_temporal(n, x, g)
+        n = E.layer_norm(self, "norm3", self.norm3, x)
+        return self.ff.run(n, x)
+
+
+class Transformer3DModel(ModelMixin, ConfigMixin, E.EngineModule):
+    @register_to_config
+    def __init__(self, num_attention_heads=16, attention_head_dim=88, in_channels=None, num_layers=1, dropout=0.0,
+                 norm_num_groups=32, cross_attention_dim=None, attention_bias=False, activation_fn="geglu",
+                 num_embeds_ada_norm=None, use_linear_projection=False, only_cross_attention=False,
+                 upcast_attention=False, use_first_frame=False, use_relative_position=False, rotary_emb=None):
+        super().__init__()
+        if not use_linear_projection:
+            raise NotImplementedError("the released config uses use_linear_projection=True")
+        inner = num_attention_heads * attention_head_dim
+        self.in_channels = in_channels
+        self.resblock_temporal = ResnetBlock3DCNN(in_channels=in_channels, kernel=(3, 1, 1), temb_channels=None)
+        self.norm = nn.GroupNorm(num_groups=norm_num_groups, num_channels=in_channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Linear(in_channels, inner)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(inner, num_attention_heads, attention_head_dim, dropout=dropout,
+                                  cross_attention_dim=cross_attention_dim, activation_fn=activation_fn,
+                                  attention_bias=attention_bias, only_cross_attention=only_cross_attention,
+                                  upcast_attention=upcast_attention, rotary_emb=rotary_emb)
+            for _ in range(num_layers)])
+        self.proj_out = nn.Linear(in_channels, inner)
+
+    def run(self, x, g: E.Geom, ehs_rows, n_text):
+        x = self.resblock_temporal.run(x, g, None)
+        res = x
+        n = E.group_norm(self, "norm", self.norm, x, n_inst=g.n_img, rows_per_inst=g.hw, silu=False)   # per frame
+        tok = ops.linear(n, E.packed_conv(self, "proj_in", self.proj_in))
+        for blk in self.transformer_blocks:
+            tok = blk.run(tok, g, ehs_rows, n_text)
+        return ops.linear(tok, E.packed_conv(self, "proj_out", self.proj_out), residual=res)
+
+    def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, return_dict=True):
+        rows, g = E.to_rows(hidden_states, c_pad=self.in_channels)
+        ehs = encoder_hidden_states.half().reshape(-1, encoder_hidden_states.shape[-1]).contiguous()
+        y = self.run(rows, g, ehs, encoder_hidden_states.shape[1])
+        out = E.from_rows(y, g, self.in_channels, out_dtype=hidden_states.dtype)
+        return Transformer3DModelOutput(sample=out) if return_dict else (out,)

@@ -52,9 +52,9 @@ SIGNATURES = {
     "uav_pack_nhwc": (C.c_int, [c_p, i32, c_p, i32, i32, c_p, i32, i32, i32, i64, f32, c_p]),
     "uav_unpack_ncthw": (C.c_int, [c_p, i32, i32, c_p, i32, i32, i32, i32, i64, f32, f32, c_p]),
     "uav_cfg_ddim_v0": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, f32, f32, f32, i32, f32, c_p]),
-    "uav_ddim_vt": (C.c_int, [c_p, c_p, c_p, c_p, i64, f32, f32, f32, f32, f32, c_p]),
+    "uav_ddim_vt": (C.c_int, [c_p, c_p, c_p, c_p, i64, f32, f32, f32, f32, f32, i32, f32, c_p]),
     "uav_axpby_f16": (C.c_int, [c_p, c_p, c_p, i64, f32, f32, c_p]),
-    "uav_propagate_step_f16": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, f32, f32, f32, c_p]),
+    "uav_propagate_step_f16": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i64, i64, i32, i32, f32, f32, f32, c_p]),
 }
 
 

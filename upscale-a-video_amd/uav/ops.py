@@ -123,7 +123,7 @@ def pack_conv(weight, bias=None, geglu=False, device=None, n_store_align=4):
 
 
 def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None,
-              rowbias=None, rows_per_batch=0, residual=None, out_scale=1.0, out_f32=False, out=None):
+              rowbias=None, rows_per_batch=0, residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None):
     """out[M][n_out] = scale*(conv(a1|a2, W) + bias + rowbias[m//rows_per_batch] + residual)."""
     lib = _lib.load()
     _req(a1, HALF, "a1")
@@ -142,6 +142,8 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
     else:
         ho = (hi + 2 * ph - wt.kh) // stride + 1
         wo = (wi + 2 * pw - wt.kw) // stride + 1
+    if out_hw is not None:                 # asymmetric (right/bottom) zero padding: taps past the edge read zeros
+        ho, wo = out_hw
     if a1.numel() != n_img * hi * wi * c1:
         raise _lib.UavError(f"a1 has {a1.numel()} elements, expected {n_img}*{hi}*{wi}*{c1}")
     m = n_img * ho * wo
@@ -324,11 +326,12 @@ def cfg_ddim_v0(eps_uncond, eps_text, sample, *, guidance, coef_sample, coef_eps
     return g, x0
 
 
-def ddim_vt(x0, guided, sample, *, coef_x0, coef_dir, eps_from_model, eps_from_sample, eps_from_x0=0.0):
+def ddim_vt(x0, guided, sample, *, coef_x0, coef_dir, eps_from_model, eps_from_sample, eps_from_x0=0.0, clip=False,
+            clip_range=1.0):
     lib = _lib.load()
     prev = torch.empty_like(sample)
     rc = lib.uav_ddim_vt(_p(_req(x0, HALF)), _p(_req(guided, HALF)), _p(_req(sample, HALF)), _p(prev), sample.numel(),
-                         coef_x0, coef_dir, eps_from_model, eps_from_sample, eps_from_x0, _stream())
+                         coef_x0, coef_dir, eps_from_model, eps_from_sample, eps_from_x0, int(clip), clip_range, _stream())
     _lib.check(rc, "uav_ddim_vt")
     return prev
 
@@ -340,13 +343,16 @@ def axpby(x, z, a, b):
     return y
 
 
-def propagate_step(feat_prev, feat_cur, flow_prop, flow_check, *, nearest, coord_f16, fuse_scale, alpha1, alpha2):
-    """One recurrence step on planar fp16 (c,h,w) features with (2,h,w) flows."""
+def propagate_step(feat_prev, feat_cur, flow_prop, flow_check, out, *, c, h, w, feat_chan_stride, flow_chan_stride,
+                   nearest, coord_f16, fuse_scale, alpha1, alpha2):
+    """One recurrence step of the flow-guided propagation.  The tensors are (possibly strided) views
+    of (C,T,H,W) fp16 buffers: frame planes are addressed in place through the channel strides."""
     lib = _lib.load()
-    c, h, w = feat_cur.shape[-3:]
-    out = torch.empty_like(feat_cur)
-    rc = lib.uav_propagate_step_f16(_p(_req(feat_prev, HALF)), _p(_req(feat_cur, HALF)), _p(_req(flow_prop, HALF)),
-                                    _p(_req(flow_check, HALF)), _p(out), c, h, w, int(nearest), int(coord_f16),
-                                    fuse_scale, alpha1, alpha2, _stream())
+    for t_ in (feat_prev, feat_cur, flow_prop, flow_check, out):
+        if not t_.is_cuda or t_.dtype != HALF:
+            raise _lib.UavError("propagate_step: fp16 GPU tensors expected")
+    rc = lib.uav_propagate_step_f16(_p(feat_prev), _p(feat_cur), _p(flow_prop), _p(flow_check), _p(out), c, h, w,
+                                    feat_chan_stride, flow_chan_stride, int(nearest), int(coord_f16), fuse_scale,
+                                    alpha1, alpha2, _stream())
     _lib.check(rc, "uav_propagate_step_f16")
     return out
