@@ -1,0 +1,221 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path on MI355X: BASELINE.json's metric
+"upscaled frames/sec (4x, 30 DDIM steps, 8-frame 320p clip)".
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full pass of the hot path over one synthetic 8-frame 320x320 clip:
+`VideoUpscalePipeline.__call__` with 30 DDIM steps, guidance 6, noise level 120, no propagation,
+vae_3d decode to 1280x1280 (BASELINE.json configs[1]).  Weights are random-init at the released
+architecture (691 M-param UNet + 55 M-param VAE); the LR clip is already resident in HBM when the
+timed region starts.  With N > 1 every rank (one process per GPU) upscales its own clips: clips are
+independent, there is no data-path collective -> weak scaling; the timed region is
+bracketed by barrier + synchronize on both sides and the MAX over ranks is reported.
+
+Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     dominant kernel (implicit-GEMM conv/linear): algorithmic FLOP / HIP-event time per
+               launch over the timed region vs the dense fp16 MFMA peak (2.5 PFLOP/s)
+  cpu_baseline the oracle (CPU fp32 restatement of the reference path) timed on this host's cores on
+               a bounded sample (N=1 only), extrapolated by FLOP — a reported baseline, not the target
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "upscale-a-video_amd"))
+
+METRIC = "upscaled frames/sec (4x, 30 DDIM steps, 8-frame 320p clip)"
+PEAK_TFLOPS_F16 = 2500.0        # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def build_pipeline(dev, height, width, unet_cfg=None, vae_cfg=None):
+    from uav import configs, init_weights
+    from uav.standin_text import StandInTextEncoder, StandInTokenizer
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
+    from models_video.scheduling_ddim import DDIMScheduler, DDPMScheduler
+    from models_video.unet_video import UNetVideoModel
+    unet_cfg = unet_cfg or configs.UNET_VIDEO
+    vae_cfg = vae_cfg or configs.VAE_3D
+    unet = UNetVideoModel.from_config(dict(unet_cfg)).half().to(dev).eval()
+    init_weights.random_init_(unet, seed=1234)
+    vae = AutoencoderKLVideo.from_config(dict(vae_cfg)).half().to(dev).eval()
+    init_weights.random_init_(vae, seed=4321)
+    tok = StandInTokenizer()
+    pipe = VideoUpscalePipeline(text_encoder=StandInTextEncoder(tok, unet_cfg["cross_attention_dim"]), tokenizer=tok,
+                                low_res_scheduler=DDPMScheduler(**configs.LOW_RES_DDPM),
+                                scheduler=DDIMScheduler(**configs.DDIM), vae=vae, unet=unet, propagator=None).to(dev)
+    return pipe
+
+
+def synthetic_clip(frames, height, width, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand((1, 3, frames, height + 4, width + 4), generator=g) * 2 - 1
+    x = torch.nn.functional.avg_pool3d(x, (1, 5, 5), stride=1)           # low-pass: trackable structure
+    return (x / x.abs().max()).contiguous().to(dev)
+
+
+def cpu_baseline(sample_hw=64, frames=8):
+    """Oracle (CPU fp32 restatement of the reference path) on the full-width model, bounded sample:
+    ONE UNet forward (CFG batch 2, 8 frames) + ONE 3-frame VAE decode chunk at sample_hw x sample_hw,
+    extrapolated to config 2 by the analytic FLOP model."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import synth
+    import uav_oracle as O
+    from uav import configs
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from models_video.unet_video import UNetVideoModel
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    shapes = {k: tuple(v.shape) for k, v in UNetVideoModel.from_config(dict(configs.UNET_VIDEO)).state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    usd = {}
+    for k, shp in shapes.items():
+        if k.endswith("freqs"):
+            usd[k] = synth.synth_tensor(k, shp)
+        elif len(shp) == 1 and "norm" in k and k.endswith("weight"):
+            usd[k] = torch.ones(shp)
+        else:
+            fan = 1
+            for s in shp[1:]:
+                fan *= s
+            usd[k] = torch.randn(shp, generator=g) * (fan ** -0.5 if len(shp) > 1 else 0.1)
+    vshapes = {k: tuple(v.shape) for k, v in AutoencoderKLVideo.from_config(dict(configs.VAE_3D)).state_dict().items()}
+    vsd = {}
+    for k, shp in vshapes.items():
+        fan = 1
+        for s in shp[1:]:
+            fan *= s
+        vsd[k] = torch.ones(shp) if (len(shp) == 1 and "norm" in k and k.endswith("weight")) else \
+            torch.randn(shp, generator=g) * (fan ** -0.5 if len(shp) > 1 else 0.1)
+    h = w = sample_hw
+    sample = torch.randn(2, 4, frames, h, w, generator=g); low = torch.randn(2, 3, frames, h, w, generator=g)
+    ehs = torch.randn(2, 77, 1024, generator=g)
+    with torch.no_grad():
+        t0 = time.time()
+        O.unet_forward(usd, configs.UNET_VIDEO, sample, 925, low, ehs, torch.tensor([120]))
+        t_unet = time.time() - t0
+        t0 = time.time()
+        O.vae_decode(vsd, configs.VAE_3D, torch.randn(1, 4, 3, h, w, generator=g), None, 1.0)
+        t_vae = time.time() - t0
+    # FLOP of the sample (conv/linear parts scale with pixels; attention cores with pixels^2 — small at 64x64)
+    scale = (sample_hw / 320.0) ** 2
+    tf_unet = configs.TFLOP_UNET_320 * scale
+    tf_vae_conv = (configs.TFLOP_VAE3D_320 - 171.80) * scale * 3 / 8
+    tf_vae_attn = 171.80 * scale * scale * 3 / 8
+    rate = (tf_unet + tf_vae_conv + tf_vae_attn) / (t_unet + t_vae)                 # TFLOP/s on this host
+    clip_seconds = configs.TFLOP_CLIP_C2 / rate
+    return {"value": 8.0 / clip_seconds, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"oracle (CPU fp32 restatement), full-width model: 1 UNet forward (B2xT{frames}x{h}x{w}, {t_unet:.1f}s) + "
+                      f"1 three-frame VAE decode chunk ({h}x{w}, {t_vae:.1f}s) = {rate:.3f} TFLOP/s, extrapolated by "
+                      f"FLOP to 5608.7 TFLOP/clip"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--height", type=int, default=320)
+    ap.add_argument("--width", type=int, default=320)
+    ap.add_argument("--frames", type=int, default=8)
+    ap.add_argument("--ddim-steps", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl")                       # RCCL on ROCm
+    if args.gpus != world and rank == 0 and world > 1:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from uav import _lib, ops
+    lib = _lib.load()
+    if lib.uav_device_check(local_rank, None) != 0:
+        raise SystemExit("bench.py needs an MI355X (gfx950)")
+
+    pipe = build_pipeline(dev, args.height, args.width)
+    clip = synthetic_clip(args.frames, args.height, args.width, seed=rank, dev=dev)
+    kw = dict(image=clip, flows_bi=None, num_inference_steps=args.ddim_steps, guidance_scale=6.0, noise_level=120,
+              negative_prompt="blur, worst quality", propagation_steps=[])
+    prompt = "best quality, extremely detailed"
+
+    def one_step(seed):
+        gen = torch.Generator().manual_seed(seed)
+        return pipe(prompt, generator=gen, **kw).images
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out = one_step(100 + i)
+    barrier()
+    use_events = (not args.no_kernel_events) and rank == 0
+    if use_events:
+        ops.PROFILER.start()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = one_step(10 + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.PROFILER.stop()
+    assert out.shape == (1, 3, args.frames, 4 * args.height, 4 * args.width) and bool(torch.isfinite(out).all())
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        frames_total = world * args.steps * args.frames
+        res = {
+            "metric": METRIC, "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {args.frames}-frame {args.height}x{args.width}->{4 * args.height}x{4 * args.width}, "
+                                   f"{args.ddim_steps} DDIM steps, guidance 6, noise_level 120, vae_3d, no propagation; "
+                                   "one clip per GPU per step (clip-parallel, no collective)",
+                       "clips_per_step": world, "frames_per_clip": args.frames},
+        }
+        if use_events:
+            summ = ops.PROFILER.summary()
+            total_s = sum(v["seconds"] for v in summ.values())
+            dom = max(summ.items(), key=lambda kv: kv[1]["seconds"])
+            name, d = dom
+            ach = d["flops"] / d["seconds"] / 1e12
+            res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
+                               "frac": ach / PEAK_TFLOPS_F16, "traffic": None, "launches": d["launches"],
+                               "avg_launch_us": d["seconds"] / d["launches"] * 1e6,
+                               "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+                               "kernel_time_share": d["seconds"] / total_s}
+            res["kernel_breakdown"] = {k: {"launches": v["launches"], "ms": round(v["seconds"] * 1e3, 2),
+                                           "tflops": round(v["flops"] / v["seconds"] / 1e12, 1) if v["flops"] else None,
+                                           "GBps": round(v["bytes"] / v["seconds"] / 1e9, 1)}
+                                       for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])}
+            res["kernel_time_ms_per_step"] = total_s / args.steps * 1e3
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -217,12 +217,13 @@ class VideoUpscalePipeline(ConfigMixin):
 
         prompt_embeds = self._encode_prompt(prompt, device, num_images_per_prompt, do_cfg, negative_prompt,
                                             prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds)
+        draw_dtype = prompt_embeds.dtype          # the reference draws both noises in prompt_embeds.dtype (:547,:573)
         prompt_embeds = prompt_embeds.to(torch.float16).contiguous()
 
         # 4/5. LR frames: fp32 copy for the VAE conditioning, fp16 + noise for the UNet (:542-551)
         image_dec = image.clone().to(dtype=torch.float32, device=device)
         image = image.to(dtype=torch.float16, device=device)
-        noise = randn_tensor(image.shape, generator=generator, device=device, dtype=torch.float16)
+        noise = randn_tensor(image.shape, generator=generator, device=device, dtype=draw_dtype).to(torch.float16)
         image = self.low_res_scheduler.add_noise(image, noise, torch.tensor([noise_level]))
         level = torch.tensor([noise_level if denoise_level is None else denoise_level], dtype=torch.long)
         if do_cfg:
@@ -232,7 +233,7 @@ class VideoUpscalePipeline(ConfigMixin):
         timesteps = [int(t) for t in self.scheduler.timesteps]
         t_total, height, width = image.shape[2:]
         num_channels_latents = self.vae.config.latent_channels
-        latents = self.prepare_latents_3d(1, num_channels_latents, t_total, height, width, torch.float16, device,
+        latents = self.prepare_latents_3d(1, num_channels_latents, t_total, height, width, draw_dtype, device,
                                           generator, latents).to(torch.float16).contiguous()
         if num_channels_latents + image.shape[1] != self.unet.config.in_channels:
             raise ValueError(f"Incorrect configuration settings! The config of `pipeline.unet`: {self.unet.config} expects"

@@ -35,6 +35,45 @@ def _req(t, dtype=None, name="tensor"):
     return t
 
 
+class KernelProfiler:
+    """Optional per-launch HIP-event timing (bench.py roofline leg).  Events are recorded on torch's
+    current stream, which is the stream every libuav_hip.so launch is issued on."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []          # (kernel, flops, bytes, start_event, end_event)
+
+    def start(self):
+        self.enabled, self.records = True, []
+
+    def stop(self):
+        self.enabled = False
+
+    def begin(self):
+        if not self.enabled:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def end(self, e0, kernel, flops=0.0, nbytes=0.0):
+        if e0 is None:
+            return
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((kernel, flops, nbytes, e0, e1))
+
+    def summary(self):
+        """kernel -> dict(launches, seconds, flops, bytes); call after a device synchronize."""
+        out = {}
+        for k, fl, nb, e0, e1 in self.records:
+            d = out.setdefault(k, dict(launches=0, seconds=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1; d["seconds"] += e0.elapsed_time(e1) * 1e-3; d["flops"] += fl; d["bytes"] += nb
+        return out
+
+
+PROFILER = KernelProfiler()
+
 _ZERO = {}
 
 
@@ -169,7 +208,11 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
     p.pad_t = pt; p.pad_h = ph; p.pad_w = pw; p.upsample = 1 if upsample else 0
     p.n = wt.n; p.n_pad = wt.n_pad; p.k_pad = wt.k_pad
     p.out_scale = out_scale; p.flags = flags; p.zero_page = _p(zero_page(a1.device))
+    ev = PROFILER.begin()
     _lib.check(lib.uav_conv_gemm_f16(C.byref(p), _stream()), "uav_conv_gemm_f16")
+    # algorithmic work: 2*M*N*K over the LOGICAL taps x input channels (no padding counted)
+    PROFILER.end(ev, "conv_gemm", 2.0 * m * wt.n * wt.kt * wt.kh * wt.kw * wt.cin,
+                 2.0 * (n_img * hi * wi * wt.cin + m * n_out) + 2.0 * wt.n * wt.kt * wt.kh * wt.kw * wt.cin)
     return out
 
 
@@ -203,9 +246,11 @@ def groupnorm_scale_shift(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps
     shift = torch.empty_like(scale)
     ws_bytes = lib.uav_groupnorm_workspace_bytes(n_inst, c)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x1.device)
+    ev = PROFILER.begin()
     rc = lib.uav_groupnorm_scale_shift(_p(x1), _p(x2), c1, c2, c_real, n_inst, rows_per_inst, groups, eps,
                                        _p(gamma), _p(beta), _p(scale), _p(shift), _p(ws), ws_bytes, _stream())
     _lib.check(rc, "uav_groupnorm_scale_shift")
+    PROFILER.end(ev, "groupnorm_stats", 0.0, 2.0 * n_inst * rows_per_inst * c)
     return scale, shift
 
 
@@ -214,9 +259,11 @@ def groupnorm_apply(x1, scale, shift, *, n_inst, rows_per_inst, silu, x2=None):
     c1 = x1.shape[-1]
     c2 = 0 if x2 is None else x2.shape[-1]
     y = torch.empty((n_inst * rows_per_inst, c1 + c2), dtype=HALF, device=x1.device)
+    ev = PROFILER.begin()
     rc = lib.uav_groupnorm_apply(_p(x1), _p(x2), c1, c2, n_inst, rows_per_inst, _p(scale), _p(shift),
                                  1 if silu else 0, _p(y), _stream())
     _lib.check(rc, "uav_groupnorm_apply")
+    PROFILER.end(ev, "groupnorm_apply", 0.0, 4.0 * n_inst * rows_per_inst * (c1 + c2))
     return y
 
 
@@ -232,7 +279,9 @@ def layernorm(x, gamma, beta, eps=1e-5):
     _req(x, HALF, "x")
     y = torch.empty_like(x)
     rows, c = x.numel() // x.shape[-1], x.shape[-1]
+    ev = PROFILER.begin()
     _lib.check(lib.uav_layernorm_f16(_p(x), _p(y), _p(gamma), _p(beta), rows, c, eps, _stream()), "uav_layernorm_f16")
+    PROFILER.end(ev, "layernorm", 0.0, 4.0 * rows * c)
     return y
 
 
@@ -249,9 +298,11 @@ def attention(q, k, v, *, bq, lq, lk, heads, head_dim, q_per_kv=1, scale=None,
     out = torch.empty((bq * lq, c), dtype=HALF, device=q.device)
     if scale is None:
         scale = head_dim ** -0.5
+    ev = PROFILER.begin()
     rc = lib.uav_attention_f16(_p(q), q_stride, _p(k), k_stride, _p(v), v_stride, _p(out), c, bq, lq, lk, q_per_kv,
                                heads, head_dim, scale, _p(zero_page(q.device)), _stream())
     _lib.check(rc, "uav_attention_f16")
+    PROFILER.end(ev, f"attention_d{head_dim}", 4.0 * bq * heads * lq * lk * head_dim, 2.0 * (2 * bq * lq * c + 2 * (bq // q_per_kv) * lk * c))
     return out
 
 
@@ -259,9 +310,11 @@ def temporal_attention(qkv, *, n_batch, t_len, hw, c, heads, scale, rope_cos, ro
     lib = _lib.load()
     _req(qkv, HALF, "qkv")
     out = torch.empty((n_batch * t_len * hw, c), dtype=HALF, device=qkv.device)
+    ev = PROFILER.begin()
     rc = lib.uav_temporal_attention_f16(_p(qkv), _p(out), n_batch, t_len, hw, c, heads, scale, _p(rope_cos),
                                         _p(rope_sin), rot_dim, _p(bias), _stream())
     _lib.check(rc, "uav_temporal_attention_f16")
+    PROFILER.end(ev, "temporal_attention", 4.0 * n_batch * hw * t_len * t_len * c, 8.0 * n_batch * t_len * hw * c)
     return out
 
 
