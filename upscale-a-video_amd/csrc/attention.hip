@@ -199,12 +199,183 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_kernel(AttnArgs 
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// head_dim = 512 (VAE mid-block attention, one head, L = H*W up to 102400; 57 % of the VAE FLOPs).
+// The generic kernel above would need 256 (O^T) + 128 (Q) accumulator/operand registers per lane
+// and spills.  Here a PAIR of waves shares 32 queries and splits d in halves of 256:
+//   * each wave computes the partial S^T over ITS 256 dims (16 MFMAs), the two partials are
+//     summed through a 4-KiB LDS exchange slot per wave, both waves then run the same (cheap,
+//     per-lane) online softmax;
+//   * each wave accumulates O^T for ITS 256 output dims (8 tiles x 2 k-steps = 16 MFMAs).
+// 8 waves (512 threads) = 4 pairs = 128 queries per workgroup, 2 waves per SIMD at <= 256 VGPRs,
+// LDS: K 2 x 32 KiB (DMA, double buffered) + V^T 36 KiB + exchange 32 KiB = 132 KiB.
+constexpr int K5_BYTES = KV * 512 * 2;         // 32 KiB per K stage
+constexpr int V5_BYTES = 512 * VT_STRIDE;      // 36 KiB
+constexpr int X5_BYTES = 8 * 4096;             // partial-S exchange
+constexpr int SMEM5 = 2 * K5_BYTES + V5_BYTES + X5_BYTES;
+
+__global__ __launch_bounds__(512, 2) void attn512_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vt = smem + 2 * K5_BYTES;
+    char* Ex = Vt + V5_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qg = wave >> 1, dh = wave & 1;
+    const int b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + qg * 32;
+    const int bk = b / p.q_per_kv;
+    const char* kbase = p.k + (long long)bk * p.lk * p.k_stride * 2;
+    const char* vbase = p.v + (long long)bk * p.lk * p.v_stride * 2;
+
+    const int qrow = q0 + l32;
+    const int qr = qrow < p.lq ? qrow : p.lq - 1;
+    const char* qptr = p.q + (((long long)b * p.lq + qr) * p.q_stride + dh * 256) * 2;
+    half8_t qf[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) qf[s] = *(const half8_t*)(qptr + (16 * s + 8 * hi) * 2);
+
+    float16_t oacc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    const int nt = (p.lk + KV - 1) / KV;
+
+    auto issue_k = [&](int stage, int t) {
+        char* dst = Ks + stage * K5_BYTES;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const int row = ps * 8 + wave;                 // 64 slots per row: one row per wave-instruction
+            const int sl = lane ^ (row & 15);
+            const int key = t * KV + row;
+            const char* g = key < p.lk ? kbase + ((long long)key * p.k_stride + sl * 8) * 2 : p.zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + (ps * 512 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+    half8_t vst[4];
+    const int vkg = tid & 7, vdv = tid >> 3;
+    auto load_v = [&](int t) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = t * KV + vkg * 4 + i;
+            half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+            vst[i] = key < p.lk ? *(const half8_t*)(vbase + ((long long)key * p.v_stride + vdv * 8) * 2) : z;
+        }
+    };
+    auto store_v = [&]() {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            half4_t w = {vst[0][e], vst[1][e], vst[2][e], vst[3][e]};
+            *(half4_t*)(Vt + (vdv * 8 + e) * VT_STRIDE + vkg * 8) = w;
+        }
+    };
+
+    issue_k(0, 0);
+    load_v(0);
+    char* exw = Ex + wave * 4096 + lane * 16;
+    const char* exr = Ex + (wave ^ 1) * 4096 + lane * 16;
+    for (int t = 0; t < nt; ++t) {
+        store_v();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < nt) { issue_k((t + 1) & 1, t + 1); load_v(t + 1); }
+
+        const char* kst = Ks + (t & 1) * K5_BYTES + l32 * 1024;
+        const int ksw = l32 & 15;
+        float16_t sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            half8_t kf = *(const half8_t*)(kst + (((dh * 32 + 2 * s + hi) ^ ksw) << 4));
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc, 0, 0, 0);
+        }
+        // exchange partial scores with the partner wave (other half of d)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            float4_t v = {sacc[4 * r4], sacc[4 * r4 + 1], sacc[4 * r4 + 2], sacc[4 * r4 + 3]};
+            *(float4_t*)(exw + r4 * 1024) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            float4_t v = *(const float4_t*)(exr + r4 * 1024);
+            sacc[4 * r4] += v[0]; sacc[4 * r4 + 1] += v[1]; sacc[4 * r4 + 2] += v[2]; sacc[4 * r4 + 3] += v[3];
+        }
+        const int key0 = t * KV + 4 * hi;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 8 * (r >> 2);
+            float sc = sacc[r] * p.scale_log2;
+            sc = key < p.lk ? sc : -INFINITY;
+            sacc[r] = sc; mx = fmaxf(mx, sc);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = exp2f(m_run - m_new);
+        float ps = 0.f;
+        half8_t pf[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = exp2f(sacc[r] - m_new);
+            ps += e;
+            pf[r >> 3][r & 7] = (half_t)e;
+        }
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const char* vrow = Vt + ((dh * 8 + i) * 32 + l32) * VT_STRIDE + hi * 8;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                half4_t a = *(const half4_t*)(vrow + s2 * 32);
+                half4_t c = *(const half4_t*)(vrow + s2 * 32 + 16);
+                half8_t vf = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+                oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s2], oacc[i], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < p.lq) {
+        char* optr = p.o + (((long long)b * p.lq + qrow) * p.o_stride + dh * 256) * 2;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4_t o = {(half_t)(oacc[i][4 * g] * inv), (half_t)(oacc[i][4 * g + 1] * inv),
+                             (half_t)(oacc[i][4 * g + 2] * inv), (half_t)(oacc[i][4 * g + 3] * inv)};
+                *(half4_t*)(optr + (i * 32 + 8 * g + 4 * hi) * 2) = o;
+            }
+    }
+}
+
+int launch_attn512(const AttnArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)attn512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM5);
+        attr_set = true;
+    }
+    dim3 grid((a.lq + 127) / 128, 1, a.bq);
+    hipLaunchKernelGGL(attn512_kernel, grid, dim3(512), SMEM5, s, a);
+    return uav_launch_status();
+}
+
 template <int D>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
     using C = AttnCfg<D>;
     static bool attr_set = false;
     if (!attr_set && C::SMEM > 65536) {
-        hipFuncSetAttribute((const void*)attn_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
+        (void)hipFuncSetAttribute((const void*)attn_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
         attr_set = true;
     }
     dim3 grid((a.lq + 127) / 128, a.heads, a.bq);
@@ -228,7 +399,7 @@ extern "C" int uav_attention_f16(const void* q, int64_t q_stride, const void* k,
     switch (head_dim) {
         case 64: return launch_attn<64>(a, s);
         case 128: return launch_attn<128>(a, s);
-        case 512: return launch_attn<512>(a, s);
+        case 512: return heads == 1 ? launch_attn512(a, s) : launch_attn<512>(a, s);
         default: return UAV_ESHAPE;
     }
 }

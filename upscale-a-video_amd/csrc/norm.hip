@@ -46,10 +46,19 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnSrc s, long long rows
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sm[j] = 0.f; sq[j] = 0.f; }
     if (active) {
-        for (long long r = r0 + ro; r < r1; r += rpp) {
-            half8_t x = *(const half8_t*)gn_vec_ptr(s, inst * rows_per_inst + r, v);
+        constexpr int U = 8;                                // independent 16-B loads in flight per thread
+        for (long long r = r0 + ro; r < r1; r += (long long)rpp * U) {
+            half8_t x[U];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { float f = (float)x[j]; sm[j] += f; sq[j] += f * f; }
+            for (int u = 0; u < U; ++u) {
+                const long long rr = r + (long long)u * rpp;
+                half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+                x[u] = rr < r1 ? *(const half8_t*)gn_vec_ptr(s, inst * rows_per_inst + rr, v) : z;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { float f = (float)x[u][j]; sm[j] += f; sq[j] += f * f; }
         }
     }
 #pragma unroll
@@ -67,42 +76,43 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnSrc s, long long rows
     }
 }
 
+// One workgroup per (group, instance): fp64 reduction of the per-chunk per-channel partials of the
+// group's channels, then scale/shift for those channels.  (A single block per instance walking all
+// chunks serially cost ~0.23 ms per GroupNorm — more than the statistics pass itself at 1/8 res.)
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ ws, int chunks, int c, int c_real,
                                                           int groups, long long rows_per_inst, float eps,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           float* __restrict__ scale, float* __restrict__ shift) {
-    extern __shared__ __attribute__((aligned(16))) char sm_raw[];
-    double* csum = (double*)sm_raw;           // [c]
-    double* csq = csum + c;                   // [c]
-    float* gmean = (float*)(csq + c);         // [groups]
-    float* grstd = gmean + groups;
-    const int inst = blockIdx.x, tid = threadIdx.x;
-    for (int ch = tid; ch < c; ch += 256) {
-        double a = 0.0, b = 0.0;
-        const float* base = ws + (long long)inst * chunks * 2 * c;
-        for (int k = 0; k < chunks; ++k) { a += base[(long long)k * 2 * c + ch]; b += base[(long long)k * 2 * c + c + ch]; }
-        csum[ch] = a; csq[ch] = b;
-    }
-    __syncthreads();
+    __shared__ double rs[256], rq[256];
+    const int g = blockIdx.x, inst = blockIdx.y, tid = threadIdx.x;
     const int cpg = c_real / groups;
-    for (int g = tid; g < groups; g += 256) {
-        double a = 0.0, b = 0.0;
-        for (int j = 0; j < cpg; ++j) { a += csum[g * cpg + j]; b += csq[g * cpg + j]; }
-        const double n = (double)rows_per_inst * cpg;
-        const double mean = a / n;
-        double var = b / n - mean * mean; if (var < 0.0) var = 0.0;
-        gmean[g] = (float)mean; grstd[g] = (float)(1.0 / sqrt(var + (double)eps));
+    const float* base = ws + (long long)inst * chunks * 2 * c;
+    double a = 0.0, b = 0.0;
+    const int items = chunks * cpg;
+    for (int it = tid; it < items; it += 256) {
+        const int k = it / cpg, ch = g * cpg + (it - k * cpg);
+        a += base[(long long)k * 2 * c + ch];
+        b += base[(long long)k * 2 * c + c + ch];
     }
+    rs[tid] = a; rq[tid] = b;
     __syncthreads();
-    for (int ch = tid; ch < c; ch += 256) {
-        float sc = 0.f, sh = 0.f;
-        if (ch < c_real) {
-            const int g = ch / cpg;
-            const float ga = gamma ? gamma[ch] : 1.f, be = beta ? beta[ch] : 0.f;
-            sc = ga * grstd[g]; sh = be - gmean[g] * grstd[g] * ga;
-        }
-        scale[(long long)inst * c + ch] = sc; shift[(long long)inst * c + ch] = sh;
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
+        __syncthreads();
     }
+    const double n = (double)rows_per_inst * cpg;
+    const double mean = rs[0] / n;
+    double var = rq[0] / n - mean * mean; if (var < 0.0) var = 0.0;
+    const float fm = (float)mean, fr = (float)(1.0 / sqrt(var + (double)eps));
+    for (int j = tid; j < cpg; j += 256) {
+        const int ch = g * cpg + j;
+        const float ga = gamma ? gamma[ch] : 1.f, be = beta ? beta[ch] : 0.f;
+        scale[(long long)inst * c + ch] = ga * fr;
+        shift[(long long)inst * c + ch] = be - fm * fr * ga;
+    }
+    // padding channels (c_real <= ch < c) carry scale = shift = 0
+    if (g == 0)
+        for (int ch = c_real + tid; ch < c; ch += 256) { scale[(long long)inst * c + ch] = 0.f; shift[(long long)inst * c + ch] = 0.f; }
 }
 
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc s, long long rows_per_inst, int chunks,
@@ -184,8 +194,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const char* __restrict__
 
 int gn_chunks(int n_inst, long long rows_per_inst, int c) {
     const int rpp = 256 / (c >> 3);
-    long long by_rows = (rows_per_inst + (long long)rpp * 8 - 1) / ((long long)rpp * 8);   // >= 8 passes per block
-    long long want = 2048 / (n_inst > 0 ? n_inst : 1); if (want < 1) want = 1;
+    long long by_rows = (rows_per_inst + (long long)rpp * 32 - 1) / ((long long)rpp * 32);  // >= 4 unrolled passes per block
+    long long want = 4096 / (n_inst > 0 ? n_inst : 1); if (want < 1) want = 1;
     long long ch = by_rows < want ? by_rows : want;
     if (ch > GN_MAX_CHUNKS) ch = GN_MAX_CHUNKS;
     if (ch < 1) ch = 1;
@@ -213,8 +223,7 @@ extern "C" int uav_groupnorm_scale_shift(const void* x1, const void* x2, int32_t
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, n_inst), dim3(256), 0, st, s, (long long)rows_per_inst, chunks,
                        (float*)workspace);
-    const size_t sm = (size_t)c * 16 + (size_t)groups * 8;
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(n_inst), dim3(256), sm, st, (const float*)workspace, chunks, c, c_real,
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n_inst), dim3(256), 0, st, (const float*)workspace, chunks, c, c_real,
                        groups, (long long)rows_per_inst, eps, gamma, beta, scale_out, shift_out);
     return uav_launch_status();
 }
