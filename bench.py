@@ -61,7 +61,7 @@ def synthetic_clip(frames, height, width, seed, dev):
     return (x / x.abs().max()).contiguous().to(dev)
 
 
-def cpu_baseline(sample_hw=64, frames=8):
+def cpu_baseline(sample_hw=48, frames=8, max_threads=32):
     """Oracle (CPU fp32 restatement of the reference path) on the full-width model, bounded sample:
     ONE UNet forward (CFG batch 2, 8 frames) + ONE 3-frame VAE decode chunk at sample_hw x sample_hw,
     extrapolated to config 2 by the analytic FLOP model."""
@@ -71,7 +71,7 @@ def cpu_baseline(sample_hw=64, frames=8):
     from uav import configs
     from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
     from models_video.unet_video import UNetVideoModel
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, max_threads)      # more threads than that slow ATen's CPU convs down
     torch.set_num_threads(cores)
     shapes = {k: tuple(v.shape) for k, v in UNetVideoModel.from_config(dict(configs.UNET_VIDEO)).state_dict().items()}
     g = torch.Generator().manual_seed(0)

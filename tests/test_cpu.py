@@ -1,0 +1,300 @@
+"""CPU suite (`-m "not gpu"`): the oracle against the reference-generated golden vectors, host
+logic of the drop-in package, state-dict compatibility with the reference, C-ABI export list,
+no-CPU-fallback behaviour, and the world_size-2 gloo path of the multi-GPU helpers."""
+import json
+import os
+import re
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+import golden_cases as GC  # noqa: E402
+import synth  # noqa: E402
+import uav_oracle as O  # noqa: E402
+
+
+def rel_l2(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
+
+
+# ---------------------------------------------------------------------------------------------
+# 1. the oracle reproduces the fixtures the REFERENCE's own modules produced
+def test_pinning_record():
+    pin = json.load(open(os.path.join(GOLD, "PINNING.json")))
+    for name, rec in pin["cases"].items():
+        for k, v in rec.items():
+            if "maxabs" in k:
+                assert v < 1e-4, f"{name}: oracle vs reference {k} = {v}"
+
+
+@pytest.fixture(scope="module")
+def unet_sd():
+    from models_video.unet_video import UNetVideoModel
+    m = UNetVideoModel.from_config(dict(GC.UNET_TINY))
+    return synth.synth_state_dict(m.state_dict(), seed=1234)
+
+
+def test_oracle_unet_vs_golden(unet_sd):
+    sample, low, ehs, ts, cl = GC.unet_inputs(2, 4, 16, 16, GC.UNET_TINY["cross_attention_dim"])
+    with torch.no_grad():
+        out = O.unet_forward(unet_sd, GC.UNET_TINY, sample, ts, low, ehs, cl)
+    gold = torch.load(os.path.join(GOLD, "unet_t4_16.pt"))
+    assert rel_l2(out, gold) < 1e-3          # fixture stored in fp16
+
+
+@pytest.mark.parametrize("name,cfg", [("vae3d", GC.VAE3D_TINY), ("vaevideo", GC.VAEVIDEO_TINY)])
+def test_oracle_vae_vs_golden(name, cfg):
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    vsd = synth.synth_state_dict(AutoencoderKLVideo.from_config(dict(cfg)).state_dict(), seed=4321)
+    z, img = GC.vae_inputs(1, 3, 16, 16)
+    with torch.no_grad():
+        out = O.vae_decode(vsd, cfg, z, img, 1.0)
+    assert rel_l2(out, torch.load(os.path.join(GOLD, name + "_t3_16.pt"))) < 1e-3
+
+
+def test_oracle_pipeline_vs_golden(unet_sd):
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from uav.standin_text import prompt_embedding
+    case = GC.PIPE_CASES["pipe_t8_vae3d"]
+    vsd = synth.synth_state_dict(AutoencoderKLVideo.from_config(dict(GC.VAE3D_TINY)).state_dict(), seed=4321)
+    image, flows = GC.pipeline_inputs(case)
+    gen = torch.Generator().manual_seed(10)
+    lr_noise = torch.randn(image.shape, generator=gen)
+    lat0 = torch.randn((1, 4) + tuple(image.shape[2:]), generator=gen)
+    dim = GC.UNET_TINY["cross_attention_dim"]
+    pe = torch.cat([synth.synth_prompt_embeds(case["negative"], dim), synth.synth_prompt_embeds(case["prompt"], dim)])
+    assert torch.equal(prompt_embedding(case["prompt"], dim), synth.synth_prompt_embeds(case["prompt"], dim))
+    with torch.no_grad():
+        img, lat = O.pipeline_call(unet_sd, GC.UNET_TINY, vsd, GC.VAE3D_TINY, image, pe, num_inference_steps=case["steps"],
+                                   guidance_scale=case["guidance"], noise_level=case["noise_level"], lr_noise=lr_noise,
+                                   latents=lat0, scheduler_kwargs=GC.SCHED)
+    gold = torch.load(os.path.join(GOLD, "pipe_t8_vae3d.pt"))
+    assert rel_l2(lat, gold["latents"]) < 1e-3
+    assert rel_l2(img, gold["images"]) < 2e-3
+
+
+def test_oracle_propagation_vs_golden():
+    x, ff, fb = GC.prop_inputs(8, 24, 32)
+    for interp in ("nearest", "bilinear"):
+        out = O.propagation(x, ff, fb, interp, 0.5, 0.001, 0.05)
+        gold = torch.load(os.path.join(GOLD, f"propagation_{interp}.pt")).float()
+        assert (out - gold).abs().max().item() < 2e-3
+
+
+def test_oracle_ddim_vs_golden():
+    rec = json.load(open(os.path.join(GOLD, "ddim.json")))
+    sch = O.DDIM(**GC.SCHED)
+    assert sch.set_timesteps(30) == rec["timesteps30"]
+    assert rec["timesteps30"][:2] == [958, 925] and rec["timesteps30"][-2:] == [34, 1]
+    for t, a in rec["alphas_cumprod_at"].items():
+        assert abs(float(sch.alphas_cumprod[int(t)]) - a) < 1e-7
+
+
+# ---------------------------------------------------------------------------------------------
+# 2. drop-in surface: state-dict keys/shapes identical to the reference's modules
+def _keys(model):
+    return {k: list(v.shape) for k, v in model.state_dict().items()}
+
+
+def test_state_dict_keys_match_reference():
+    from uav import configs
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from models_video.unet_video import UNetVideoModel
+    assert _keys(UNetVideoModel.from_config(dict(configs.UNET_VIDEO))) == json.load(open(os.path.join(GOLD, "unet_full_keys.json")))
+    assert _keys(AutoencoderKLVideo.from_config(dict(configs.VAE_3D))) == json.load(open(os.path.join(GOLD, "vae3d_full_keys.json")))
+    assert _keys(AutoencoderKLVideo.from_config(dict(configs.VAE_VIDEO))) == json.load(open(os.path.join(GOLD, "vaevideo_full_keys.json")))
+
+
+def test_cli_import_surface():
+    """The names inference_upscale_a_video.py imports (reference :39-45) exist in the drop-in package."""
+    from models_video.RAFT.raft_bi import RAFT_bi  # noqa: F401
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo  # noqa: F401
+    from models_video.pipeline_upscale_a_video import VideoUpscalePipeline  # noqa: F401
+    from models_video.propagation_module import Propagation  # noqa: F401
+    from models_video.scheduling_ddim import DDIMScheduler  # noqa: F401
+    from models_video.unet_video import UNetVideoModel  # noqa: F401
+    from models_video.color_correction import adaptive_instance_normalization, wavelet_reconstruction  # noqa: F401
+
+
+def test_no_cpu_fallback():
+    from uav import UavError
+    from models_video.unet_video import UNetVideoModel
+    unet = UNetVideoModel.from_config(dict(GC.UNET_TINY))
+    with pytest.raises(UavError):
+        unet(torch.zeros(2, 4, 4, 16, 16), 925, torch.zeros(2, 3, 4, 16, 16), encoder_hidden_states=torch.zeros(2, 77, 64),
+             class_labels=torch.tensor([120]))
+
+
+def test_pipeline_input_errors():
+    from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
+    pipe = VideoUpscalePipeline(max_noise_level=350)
+    img = torch.zeros(1, 3, 8, 16, 16)
+    with pytest.raises(ValueError):
+        pipe.check_inputs("a", img, 351)
+    with pytest.raises(ValueError):
+        pipe.check_inputs(None, img, 20)
+    with pytest.raises(ValueError):
+        pipe.check_inputs("a", img, 20, prompt_embeds=torch.zeros(1, 77, 8))
+    with pytest.raises(ValueError):
+        pipe.check_inputs(["a", "b"], img, 20)
+    with pytest.raises(TypeError):
+        pipe.check_inputs(None, img, 20, prompt_embeds=torch.zeros(1, 77, 8))   # the reference's len(None) crash
+
+
+# ---------------------------------------------------------------------------------------------
+# 3. C ABI
+def test_cabi_exports_every_declared_symbol():
+    from uav import _lib
+    hdr = open(os.path.join(ROOT, "include", "uav_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(uav_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/uav_hip.h but not exported"
+    assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
+    assert lib.uav_version() == 1
+
+
+# ---------------------------------------------------------------------------------------------
+# 4. host logic
+def emulate_conv_gemm(rows, cw, n_img, t_len, hi, wi, stride, pad, upsample, out_hw=None):
+    """Executable spec of uav_conv_gemm_f16's addressing (csrc/conv_gemm.hip src_pixel + k order)."""
+    pt, ph, pw = pad
+    if upsample:
+        ho, wo = 2 * hi, 2 * wi
+    else:
+        ho, wo = (hi + 2 * ph - cw.kh) // stride + 1, (wi + 2 * pw - cw.kw) // stride + 1
+    if out_hw:
+        ho, wo = out_hw
+    w = cw.w.float()[: cw.n]
+    x = rows.float().reshape(n_img, hi, wi, cw.cin_p)
+    out = torch.zeros(n_img, ho, wo, cw.n)
+    for img in range(n_img):
+        tloc = img % t_len
+        for dt in range(cw.kt):
+            tt = tloc + dt - pt
+            if not (0 <= tt < t_len):
+                continue
+            for dy in range(cw.kh):
+                for dx in range(cw.kw):
+                    tap = (dt * cw.kh + dy) * cw.kw + dx
+                    wk = w[:, tap * cw.cin_p:(tap + 1) * cw.cin_p]
+                    for yo in range(ho):
+                        for xo in range(wo):
+                            if upsample:
+                                yv, xv = yo + dy - ph, xo + dx - pw
+                                if not (0 <= yv < ho and 0 <= xv < wo):
+                                    continue
+                                yi, xi = yv >> 1, xv >> 1
+                            else:
+                                yi, xi = yo * stride + dy - ph, xo * stride + dx - pw
+                                if not (0 <= yi < hi and 0 <= xi < wi):
+                                    continue
+                            out[img, yo, xo] += wk @ x[img + dt - pt, yi, xi]
+    return out + (cw.bias[: cw.n] if cw.bias is not None else 0)
+
+
+@pytest.mark.parametrize("cin,cout,k3,stride,ups,t_len", [(64, 8, (1, 3, 3), 1, False, 1), (64, 8, (1, 3, 3), 2, False, 1),
+                                                          (64, 4, (1, 3, 3), 1, True, 1), (64, 8, (3, 1, 1), 1, False, 3),
+                                                          (7, 8, (1, 3, 3), 1, False, 1), (3, 4, (3, 3, 3), 1, False, 3)])
+def test_pack_conv_and_kernel_addressing_spec(cin, cout, k3, stride, ups, t_len):
+    from uav import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    h, w_, nb = 5, 6, 1
+    x5 = torch.randn(nb, cin, t_len, h, w_, generator=g)
+    wt = torch.randn(cout, cin, *k3, generator=g).half().float()
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv3d(F.interpolate(x5, scale_factor=[1.0, 2.0, 2.0], mode="nearest") if ups else x5, wt, bias,
+                   stride=(1, stride, stride), padding=tuple(k // 2 for k in k3))
+    cw = ops.pack_conv(wt, bias, device="cpu")
+    rows = x5.permute(0, 2, 3, 4, 1).reshape(-1, cin)
+    if cin % 64:
+        rows = F.pad(rows, (0, 8 - cin))
+    out = emulate_conv_gemm(rows, cw, nb * t_len, t_len, h, w_, stride, tuple(k // 2 for k in k3), ups)
+    ho, wo = ref.shape[-2:]
+    out5 = out[..., :cout].reshape(nb, t_len, ho, wo, cout).permute(0, 4, 1, 2, 3)
+    assert (out5 - ref).abs().max().item() < 1e-3
+    assert cw.n_pad % 128 == 0 and cw.k_pad % 64 == 0
+
+
+def test_geglu_packing_order():
+    from uav import ops
+    f, k = 64, 64
+    w = torch.arange(2 * f, dtype=torch.float32)[:, None].expand(2 * f, k).contiguous() / 1024
+    b = torch.arange(2 * f, dtype=torch.float32)
+    cw = ops.pack_conv(w, b, geglu=True, device="cpu")
+    # packed rows: [32 value | 32 gate] per block of 32 features
+    assert torch.equal(cw.bias[:32], b[:32]) and torch.equal(cw.bias[32:64], b[f:f + 32])
+    assert torch.equal(cw.bias[64:96], b[32:64]) and torch.equal(cw.bias[96:128], b[f + 32:f + 64])
+
+
+def test_window_schedule_and_scheduler_coefficients():
+    from models_video.pipeline_upscale_a_video import window_schedule
+    from models_video.scheduling_ddim import DDIMScheduler
+    for t in (3, 8, 9, 10, 14, 27, 32, 47):
+        assert window_schedule(t) == O.window_schedule(t)
+    assert window_schedule(32)[-2:] == [(24, 32), (24, 32)]          # the reference's duplicate tail window
+    g = torch.Generator().manual_seed(0)
+    eps, x = torch.randn(64, generator=g), torch.randn(64, generator=g)
+    for pred in ("v_prediction", "epsilon", "sample"):
+        kw = dict(GC.SCHED, prediction_type=pred)
+        sch = DDIMScheduler(**kw); sch.set_timesteps(30)
+        ora = O.DDIM(**kw); ora.set_timesteps(30)
+        for t in (958, 496, 1):
+            cs, ce = sch.v0_coefficients(t)
+            x0 = cs * x + ce * eps
+            assert (x0 - ora.step_v0(eps, t, x)).abs().max().item() < 1e-5
+            c0, cd, em, es, e0 = sch.vt_coefficients(t)
+            prev = c0 * x0 + cd * (em * eps + es * x + e0 * x0)
+            assert (prev - ora.step_vt(x0, eps, t, x)).abs().max().item() < 1e-5
+
+
+def test_relative_position_bucket_table():
+    from models_video.attention import RelativePositionBias
+    rpb = RelativePositionBias(heads=8, max_distance=32)
+    for n in (3, 8, 12):
+        pos = torch.arange(n)
+        ora = O.relative_position_bucket(pos[None, :] - pos[:, None], 32, 32)
+        assert torch.equal(rpb.bucket_table(n), ora)
+
+
+# ---------------------------------------------------------------------------------------------
+# 5. multi-GPU helpers on gloo, world_size 2
+def _dist_worker(rank, world, port, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, os.path.join(ROOT, "upscale-a-video_amd"))
+    from uav import dist as D
+    w, r, _ = D.init("gloo")
+    clips = list(range(7))
+    mine = D.shard(clips, r, w)
+    D.barrier()
+    elapsed = D.max_over_ranks(1.0 + r)
+    total = D.sum_over_ranks(len(mine))
+    gathered = D.gather_to_rank0(mine)
+    q.put((r, mine, elapsed, total, gathered))
+    D.finalize()
+
+
+def test_dist_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 1000
+    procs = [ctx.Process(target=_dist_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, m0, e0, t0, g0), (r1, m1, e1, t1, g1) = res
+    assert m0 == [0, 2, 4, 6] and m1 == [1, 3, 5]
+    assert e0 == e1 == 2.0 and t0 == t1 == 7.0
+    assert g0 == [[0, 2, 4, 6], [1, 3, 5]] and g1 is None

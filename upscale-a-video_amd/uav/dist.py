@@ -1,0 +1,70 @@
+"""One-process-per-GPU helpers (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm, "gloo" on CPU).
+
+The hot path shards by CLIP (and by spatial tile of a clip): units are independent, so the data path
+needs no collective — ranks only meet at the timing barrier and at the optional gather
+of results.  Everything here is backend-agnostic so the N>1 logic is covered by world_size-2 gloo tests
+on CPU.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_world():
+    return int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend=None):
+    """Initialise the default process group from torchrun's environment (no-op for world size 1)."""
+    world, rank, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (see task environment notes)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        dist.init_process_group(backend)
+    return world, rank, local
+
+
+def shard(items, rank, world):
+    """Round-robin assignment of independent work units (clips / tiles) to ranks: unit i -> rank i % world."""
+    return [it for i, it in enumerate(items) if i % world == rank]
+
+
+def barrier(device=None):
+    if dist.is_initialized():
+        dist.barrier()
+    if device is not None and torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def max_over_ranks(value, device="cpu"):
+    """MAX-reduce a python float over all ranks (the timed region's duration)."""
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value, device="cpu"):
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_to_rank0(obj):
+    """Gather one picklable object per rank on rank 0 (None elsewhere)."""
+    if not dist.is_initialized():
+        return [obj]
+    out = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
+    dist.gather_object(obj, out, dst=0)
+    return out
+
+
+def finalize():
+    if dist.is_initialized():
+        dist.destroy_process_group()
