@@ -54,6 +54,12 @@ CONV_CASES = [
     ("small_cin3_3x3x3", 3, 64, (3, 3, 3), 1, False, 3, 3, 12, 12),
     ("out4", 128, 4, (1, 3, 3), 1, False, 2, 2, 16, 16),
     ("out3", 128, 3, (1, 3, 3), 1, False, 2, 1, 16, 16),
+    # cout % 256 == 0: also run by the 256x256-tile kernel when UAV_CONV_TILE=256 (or a large grid)
+    ("big_3x3_c128_n256", 128, 256, (1, 3, 3), 1, False, 2, 2, 23, 17),
+    ("big_t3_c256_n256", 256, 256, (3, 1, 1), 1, False, 6, 3, 9, 11),
+    ("big_up_c64_n256", 64, 256, (1, 3, 3), 1, True, 2, 1, 9, 7),
+    ("big_s2_c64_n512", 64, 512, (1, 3, 3), 2, False, 2, 2, 18, 14),
+    ("big_1x1_c192_n512", 192, 512, (1, 1, 1), 1, False, 3, 1, 31, 9),
 ]
 
 
@@ -93,7 +99,7 @@ def test_conv_gemm(ops, dev, case):
 def test_conv_epilogue_fusions(ops, dev):
     """bias + per-batch row bias (temb) + residual + 1/output_scale_factor, two concatenated sources."""
     g = torch.Generator().manual_seed(7)
-    bsz, t_len, h, w, c1, c2, cout = 2, 3, 10, 14, 128, 64, 128
+    bsz, t_len, h, w, c1, c2, cout = 2, 3, 10, 14, 128, 64, 256
     xa = h16(bsz, c1, t_len, h, w, dev=dev, gen=g); xb = h16(bsz, c2, t_len, h, w, dev=dev, gen=g)
     wt = h16(cout, c1 + c2, 1, 3, 3, dev=dev, scale=(9 * (c1 + c2)) ** -0.5, gen=g)
     bias = torch.randn(cout, generator=g).to(dev)

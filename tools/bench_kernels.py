@@ -49,6 +49,8 @@ def main():
         conv_case("linear 512->4096 M=409600", 640, 1, 640, 1, 512, 4096, (1, 1, 1), iters=3)
         conv_case("linear 2048->512 M=409600", 640, 1, 640, 1, 2048, 512, (1, 1, 1))
         conv_case("3x3 128->128 @3x1280x1280", 3, 3, 1280, 1280, 128, 128, (1, 3, 3), iters=3)
+        conv_case("3x3 1024->512 @16x160x160", 16, 8, 160, 160, 1024, 512, (1, 3, 3), iters=3)
+        conv_case("t5 512->512 @16x320x320", 16, 8, 320, 320, 512, 512, (5, 1, 1), iters=3)
     if "norm" in which:
         for c, rows in [(256, 16 * 320 * 320), (512, 16 * 160 * 160), (1024, 16 * 40 * 40)]:
             x = torch.randn(rows, c, device=dev).half()

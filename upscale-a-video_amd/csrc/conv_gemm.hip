@@ -24,6 +24,7 @@
 // Roofline: MFMA-bound (arithmetic intensity 4.5*C FLOP/B for 3x3).  Algorithmic FLOP per
 // launch = 2*M*N*K_logical.
 #include "uav_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -255,6 +256,200 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Large-tile variant: 256(m) x 256(n) x 64(k) per 512-thread workgroup (8 waves; wave tile
+// 128(n) x 64(m) = 4x2 MFMA 32x32x16 tiles, 128 fp32 accumulators/lane), two 64-KiB LDS stages,
+// one workgroup per CU.  Compared with the 128x128 kernel each wave issues 2x the MFMAs per
+// global_load_lds instruction (4:1) and 0.75 ds_read_b128 per MFMA instead of 1, and there are
+// 2x the MFMAs between two barriers.  Because only 2 waves share a SIMD, latency is hidden INSIDE
+// the wave: fragments are double-buffered in registers (the reads of k-slice kk+1 are issued
+// before the MFMAs of slice kk) and the DMA of the next stage is issued in the first two slices.
+constexpr int LM = 256, LN = 256;
+constexpr int LA_BYTES = LM * BK * 2;            // 32 KiB
+constexpr int LSTAGE = 2 * LA_BYTES;             // 64 KiB (X tile + W tile)
+
+__global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi32 = lane >> 5, l32 = lane & 31;
+
+    const unsigned n_tiles = p.n_pad / LN;
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned mt = bid / n_tiles, nt = bid - mt * n_tiles;
+    const long long m0 = (long long)mt * LM;
+    const int n0 = nt * LN;
+
+    const int slot_log = (tid & 7) ^ ((tid >> 4) & 7);
+    const int rbase = tid >> 3;                          // 0..63; rows r = pass*64 + rbase
+    int img[4], tloc[4], yx[4];
+    bool mval[4];
+    const int hw_o = p.ho * p.wo;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        long long m = m0 + ps * 64 + rbase;
+        mval[ps] = m < p.M;
+        int mm = mval[ps] ? (int)m : 0;
+        int im = mm / hw_o; int rem = mm - im * hw_o;
+        int yo = rem / p.wo; int xo = rem - yo * p.wo;
+        img[ps] = im; tloc[ps] = im % p.t_len; yx[ps] = (yo << 16) | xo;
+    }
+    const int cin = p.c1 + p.c2;
+    const int khw = p.kh * p.kw;
+    const int nk = p.k_pad / BK;
+    const char* wrow = p.w + ((long long)(n0 + rbase) * p.k_pad + slot_log * 8) * 2;
+
+    int pix[4] = {-1, -1, -1, -1};
+    int nxt_tap = 0, nxt_c = 0;
+    const char* xsrc = p.a1; int xcs = p.c1; int xcoff = 0;
+
+    // DMA of one stage is split in two halves (X pieces, then W pieces) issued in different k-slices
+    auto issue_x = [&](int stage) {
+        char* sA = smem + stage * LSTAGE;
+        if (nxt_c == 0) {
+            int dt = nxt_tap / khw; int rem = nxt_tap - dt * khw; int dy = rem / p.kw; int dx = rem - dy * p.kw;
+#pragma unroll
+            for (int ps = 0; ps < 4; ++ps)
+                pix[ps] = mval[ps] ? src_pixel(p, img[ps], tloc[ps], yx[ps] >> 16, yx[ps] & 0xffff, dt, dy, dx) : -1;
+        }
+        const bool first = nxt_c < p.c1;
+        xsrc = first ? p.a1 : p.a2; xcs = first ? p.c1 : p.c2;
+        xcoff = (first ? nxt_c : nxt_c - p.c1) + slot_log * 8;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            const char* g = pix[ps] >= 0 ? xsrc + ((long long)pix[ps] * xcs + xcoff) * 2 : p.zero_page;
+            dma16(g, sA + (ps * 512 + wave * 64) * 16);
+        }
+        nxt_c += BK;
+        if (nxt_c >= cin) { nxt_c = 0; ++nxt_tap; }
+    };
+    auto issue_w = [&](int stage, int ks) {
+        char* sB = smem + stage * LSTAGE + LA_BYTES;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps)
+            dma16(wrow + ((long long)ps * 64 * p.k_pad + (long long)ks * BK) * 2, sB + (ps * 512 + wave * 64) * 16);
+    };
+
+    const int wn = wave & 1, wm = wave >> 1;
+    float16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment addresses: row*128 + ((slot ^ sw) << 4); all 32-row tiles share sw = (l32>>1)&7
+    const int sw = (l32 >> 1) & 7;
+    const int offW = LA_BYTES + (wn * 128 + l32) * 128;      // + ni*4096
+    const int offX = (wm * 64 + l32) * 128;                  // + mi*4096
+
+    half8_t fw[2][4], fx[2][2];
+#define LOAD_FRAGS(SET, KK)                                                                      \
+    {                                                                                            \
+        const int so = (((KK) * 2 + hi32) ^ sw) << 4;                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) fw[SET][i] = *(const half8_t*)(st + offW + i * 4096 + so); \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j) fx[SET][j] = *(const half8_t*)(st + offX + j * 4096 + so); \
+    }
+#define MFMA_SET(SET)                                                                            \
+    {                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                        \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[SET][i], fx[SET][j], acc[i][j], 0, 0, 0); \
+    }
+
+    issue_x(0); issue_w(0, 0);
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const char* st = smem + cur * LSTAGE;
+        const bool more = ks + 1 < nk;
+        LOAD_FRAGS(0, 0)
+        if (more) issue_x(cur ^ 1);
+        LOAD_FRAGS(1, 1)
+        MFMA_SET(0)
+        if (more) issue_w(cur ^ 1, ks + 1);
+        LOAD_FRAGS(0, 2)
+        MFMA_SET(1)
+        LOAD_FRAGS(1, 3)
+        MFMA_SET(0)
+        MFMA_SET(1)
+        cur ^= 1;
+    }
+#undef LOAD_FRAGS
+#undef MFMA_SET
+
+    // ---- epilogue (same per-lane scheme as the 128x128 kernel) ---------------------------------
+    const bool geglu = p.flags & UAV_CONV_GEGLU;
+    const bool of32 = p.flags & UAV_CONV_OUT_F32;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        const long long m = m0 + wm * 64 + mi * 32 + l32;
+        if (m >= p.M) continue;
+        const float* rb = p.rowbias ? p.rowbias + (long long)((int)m / p.rows_per_batch) * p.rowbias_stride : nullptr;
+        if (geglu) {
+#pragma unroll
+            for (int blk = 0; blk < 2; ++blk) {
+                const int nb = n0 + wn * 128 + blk * 64;             // packed rows: [32 value | 32 gate]
+                const int fbase = nb >> 1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int jn = 8 * g + 4 * hi32;
+                    const int f = fbase + jn;
+                    if (f >= (p.n >> 1)) continue;
+                    half4_t o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float hv = acc[2 * blk][mi][4 * g + j], gv = acc[2 * blk + 1][mi][4 * g + j];
+                        if (p.bias) { hv += p.bias[nb + jn + j]; gv += p.bias[nb + 32 + jn + j]; }
+                        o[j] = (half_t)(hv * uav_gelu_erf(gv) * p.out_scale);
+                    }
+                    *(half4_t*)(p.out + ((long long)m * p.out_stride + f) * 2) = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * 128 + ni * 32 + 8 * g + 4 * hi32;
+                    if (n >= p.n) continue;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
+                    if (p.bias) {
+                        float4_t b = *(const float4_t*)(p.bias + n);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += b[j];
+                    }
+                    if (rb) {
+                        float4_t b = *(const float4_t*)(rb + n);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += b[j];
+                    }
+                    if (p.residual) {
+                        half4_t r = *(const half4_t*)(p.residual + ((long long)m * p.res_stride + n) * 2);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= p.out_scale;
+                    if (of32) {
+                        float4_t o = {v[0], v[1], v[2], v[3]};
+                        *(float4_t*)(p.out + ((long long)m * p.out_stride + n) * 4) = o;
+                    } else {
+                        half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        *(half4_t*)(p.out + ((long long)m * p.out_stride + n) * 2) = o;
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
@@ -293,7 +488,20 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     const long long grid = mtiles * (q->n_pad / BN);
     if (grid >= (1ll << 31)) return UAV_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
-    if (small)
+    // tile selection: the 256x256 kernel needs n_pad % 256 == 0 and enough tiles to fill 256 CUs
+    const long long mtiles256 = (a.M + LM - 1) / LM;
+    const long long grid256 = mtiles256 * (q->n_pad / LN);
+    static int force_tile = -1;
+    if (force_tile < 0) { const char* e = getenv("UAV_CONV_TILE"); force_tile = e ? atoi(e) : 0; }
+    const bool big = !small && (q->n_pad % LN == 0) && (force_tile == 256 || (force_tile != 128 && grid256 >= 224));
+    if (big) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(conv_gemm256_kernel, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+    } else if (small)
         hipLaunchKernelGGL(conv_gemm_kernel<1>, dim3((unsigned)grid), dim3(256), 2 * STAGE_BYTES, s, a);
     else
         hipLaunchKernelGGL(conv_gemm_kernel<0>, dim3((unsigned)grid), dim3(256), 2 * STAGE_BYTES, s, a);
