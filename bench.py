@@ -168,6 +168,7 @@ def main():
     barrier()
     use_events = (not args.no_kernel_events) and rank == 0
     if use_events:
+        ops.PROFILER.detail = bool(os.environ.get("UAV_BENCH_DETAIL"))
         ops.PROFILER.start()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -195,6 +196,19 @@ def main():
         }
         if use_events:
             summ = ops.PROFILER.summary()
+            if ops.PROFILER.detail:                       # per-shape table to stderr, then fold back
+                tot = sum(v["seconds"] for v in summ.values())
+                for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])[:45]:
+                    print(f"{v['seconds'] * 1e3:9.2f} ms {100 * v['seconds'] / tot:5.1f}% n={v['launches']:5d} "
+                          f"{(v['flops'] / v['seconds'] / 1e12 if v['flops'] else 0):7.1f} TF/s "
+                          f"{v['bytes'] / v['seconds'] / 1e9:8.1f} GB/s  {k}", file=sys.stderr)
+                folded = {}
+                for k, v in summ.items():
+                    kk = k.split(" ")[0]
+                    d = folded.setdefault(kk, dict(launches=0, seconds=0.0, flops=0.0, bytes=0.0))
+                    for f in d:
+                        d[f] += v[f]
+                summ = folded
             total_s = sum(v["seconds"] for v in summ.values())
             dom = max(summ.items(), key=lambda kv: kv[1]["seconds"])
             name, d = dom

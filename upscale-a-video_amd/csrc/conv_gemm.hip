@@ -69,6 +69,156 @@ UAV_DEVINL int src_pixel(const ConvArgs& p, int img, int tloc, int yo, int xo, i
     return ok ? pix : -1;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Shared epilogue.  After the swapped MFMA a lane owns pixel m = mw0 + mi*32 + (lane&31) and, per
+// register quad g, channels n = nw0 + ni*32 + 8g + 4*(lane>>5) + j (j = 0..3): 8-byte pieces.
+// Pairs of quads are exchanged between the two half-waves with v_permlane32_swap (cdna guide T21)
+// so that every lane stores / loads 16 contiguous bytes: half the store instructions, 32-B
+// contiguous per row per instruction.  fp32 outputs and N tails keep the 8-byte path.
+UAV_DEVINL void swap_pair(uint32_t& a, uint32_t& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0]; b = r[1];
+}
+UAV_DEVINL uint32_t pack_h2(float x, float y) {
+    half2_t h = {(half_t)x, (half_t)y};
+    return __builtin_bit_cast(uint32_t, h);
+}
+UAV_DEVINL float2_t unpack_h2(uint32_t u) {
+    half2_t h = __builtin_bit_cast(half2_t, u);
+    return float2_t{(float)h[0], (float)h[1]};
+}
+
+template <int NI, int MI>
+UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32) {
+    const bool geglu = p.flags & UAV_CONV_GEGLU;
+    const bool of32 = p.flags & UAV_CONV_OUT_F32;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const long long m = mw0 + mi * 32 + l32;
+        const bool mok = m < p.M;
+        const long long mc = mok ? m : 0;
+        const float* rb = p.rowbias ? p.rowbias + (long long)((int)mc / p.rows_per_batch) * p.rowbias_stride : nullptr;
+        if (geglu) {
+            // packed rows come in blocks of [32 value | 32 gate]: tile pair (2b, 2b+1)
+#pragma unroll
+            for (int blk = 0; blk < NI / 2; ++blk) {
+                const int nb = nw0 + blk * 64;
+                const int fbase = nb >> 1;
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    uint32_t A[2], B[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {              // q = 0: quad 2gp, q = 1: quad 2gp+1
+                        const int g = 2 * gp + q;
+                        const int jn = 8 * g + 4 * hi32;
+                        float o[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float hv = acc[2 * blk][mi][4 * g + j], gv = acc[2 * blk + 1][mi][4 * g + j];
+                            if (p.bias) { hv += p.bias[nb + jn + j]; gv += p.bias[nb + 32 + jn + j]; }
+                            o[j] = hv * uav_gelu_erf(gv) * p.out_scale;
+                        }
+                        uint32_t* d = q == 0 ? A : B;
+                        d[0] = pack_h2(o[0], o[1]); d[1] = pack_h2(o[2], o[3]);
+                    }
+                    swap_pair(A[0], B[0]); swap_pair(A[1], B[1]);
+                    const int f = fbase + 16 * gp + 8 * hi32;
+                    if (mok && f < (p.n >> 1)) {
+                        uint4_t v = {A[0], A[1], B[0], B[1]};
+                        *(uint4_t*)(p.out + ((long long)m * p.out_stride + f) * 2) = v;
+                    }
+                }
+            }
+            continue;
+        }
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                const int nq = nw0 + ni * 32 + 16 * gp;               // first channel of this quad pair (wave-uniform)
+                const bool wide = !of32 && (nq + 16 <= p.n) && !(p.out_stride & 7) && !(p.res_stride & 7);
+                if (wide) {
+                    const int nl = nq + 8 * hi32;                     // the 8 channels this lane loads / stores
+                    uint32_t R[4] = {0, 0, 0, 0};
+                    if (p.residual) {
+                        if (mok) {
+                            uint4_t r = *(const uint4_t*)(p.residual + ((long long)m * p.res_stride + nl) * 2);
+                            R[0] = r[0]; R[1] = r[1]; R[2] = r[2]; R[3] = r[3];
+                        }
+                        swap_pair(R[0], R[2]); swap_pair(R[1], R[3]);   // -> R[0..1]: quad 2gp, R[2..3]: quad 2gp+1
+                    }
+                    uint32_t A[2], B[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int g = 2 * gp + q;
+                        const int n = nw0 + ni * 32 + 8 * g + 4 * hi32;
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
+                        if (p.bias) {
+                            float4_t b = *(const float4_t*)(p.bias + n);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += b[j];
+                        }
+                        if (rb) {
+                            float4_t b = *(const float4_t*)(rb + n);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += b[j];
+                        }
+                        if (p.residual) {
+                            float2_t r0 = unpack_h2(R[2 * q]), r1 = unpack_h2(R[2 * q + 1]);
+                            v[0] += r0[0]; v[1] += r0[1]; v[2] += r1[0]; v[3] += r1[1];
+                        }
+                        uint32_t* d = q == 0 ? A : B;
+                        d[0] = pack_h2(v[0] * p.out_scale, v[1] * p.out_scale);
+                        d[1] = pack_h2(v[2] * p.out_scale, v[3] * p.out_scale);
+                    }
+                    swap_pair(A[0], B[0]); swap_pair(A[1], B[1]);
+                    if (mok) {
+                        uint4_t v = {A[0], A[1], B[0], B[1]};
+                        *(uint4_t*)(p.out + ((long long)m * p.out_stride + nl) * 2) = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int g = 2 * gp + q;
+                        const int n = nw0 + ni * 32 + 8 * g + 4 * hi32;
+                        if (!mok || n >= p.n) continue;
+                        float v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
+                        if (p.bias) {
+                            float4_t b = *(const float4_t*)(p.bias + n);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += b[j];
+                        }
+                        if (rb) {
+                            float4_t b = *(const float4_t*)(rb + n);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += b[j];
+                        }
+                        if (p.residual) {
+                            half4_t r = *(const half4_t*)(p.residual + ((long long)m * p.res_stride + n) * 2);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                        }
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] *= p.out_scale;
+                        if (of32) {
+                            float4_t o = {v[0], v[1], v[2], v[3]};
+                            *(float4_t*)(p.out + ((long long)m * p.out_stride + n) * 4) = o;
+                        } else {
+                            half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                            *(half4_t*)(p.out + ((long long)m * p.out_stride + n) * 2) = o;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int SMALL>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -191,71 +341,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs p) {
         cur ^= 1;
     }
 
-    // ---- epilogue: lane owns pixel m, channels n = nb + 8*g + 4*hi32 + j -------------------
-    const bool geglu = p.flags & UAV_CONV_GEGLU;
-    const bool of32 = p.flags & UAV_CONV_OUT_F32;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const long long m = m0 + wm * 64 + mi * 32 + l32;
-        if (m >= p.M) continue;
-        const float* rb = p.rowbias ? p.rowbias + (long long)((int)m / p.rows_per_batch) * p.rowbias_stride : nullptr;
-        if (geglu) {
-            const int fbase = (n0 + wn * 64) >> 1;       // output feature base of this wave
-            const int nb = n0 + wn * 64;                 // packed row base (value rows; gate rows +32)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int jn = 8 * g + 4 * hi32;
-                const int f = fbase + jn;
-                if (f >= (p.n >> 1)) continue;
-                half4_t o;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float hv = acc[0][mi][4 * g + j], gv = acc[1][mi][4 * g + j];
-                    if (p.bias) { hv += p.bias[nb + jn + j]; gv += p.bias[nb + 32 + jn + j]; }
-                    o[j] = (half_t)(hv * uav_gelu_erf(gv) * p.out_scale);
-                }
-                *(half4_t*)(p.out + ((long long)m * p.out_stride + f) * 2) = o;
-            }
-        } else {
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = n0 + wn * 64 + ni * 32 + 8 * g + 4 * hi32;
-                    if (n >= p.n) continue;
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
-                    if (p.bias) {
-                        float4_t b = *(const float4_t*)(p.bias + n);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += b[j];
-                    }
-                    if (rb) {
-                        float4_t b = *(const float4_t*)(rb + n);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += b[j];
-                    }
-                    if (p.residual) {
-                        half4_t r = *(const half4_t*)(p.residual + ((long long)m * p.res_stride + n) * 2);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] *= p.out_scale;
-                    if (of32) {
-                        float4_t o = {v[0], v[1], v[2], v[3]};
-                        *(float4_t*)(p.out + ((long long)m * p.out_stride + n) * 4) = o;
-                    } else {
-                        half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                        *(half4_t*)(p.out + ((long long)m * p.out_stride + n) * 2) = o;
-                    }
-                }
-            }
-        }
-    }
+    conv_epilogue<2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, l32, hi32);
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Large-tile variant: 256(m) x 256(n) x 64(k) per 512-thread workgroup (8 waves; wave tile
@@ -382,72 +469,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
 #undef LOAD_FRAGS
 #undef MFMA_SET
 
-    // ---- epilogue (same per-lane scheme as the 128x128 kernel) ---------------------------------
-    const bool geglu = p.flags & UAV_CONV_GEGLU;
-    const bool of32 = p.flags & UAV_CONV_OUT_F32;
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const long long m = m0 + wm * 64 + mi * 32 + l32;
-        if (m >= p.M) continue;
-        const float* rb = p.rowbias ? p.rowbias + (long long)((int)m / p.rows_per_batch) * p.rowbias_stride : nullptr;
-        if (geglu) {
-#pragma unroll
-            for (int blk = 0; blk < 2; ++blk) {
-                const int nb = n0 + wn * 128 + blk * 64;             // packed rows: [32 value | 32 gate]
-                const int fbase = nb >> 1;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int jn = 8 * g + 4 * hi32;
-                    const int f = fbase + jn;
-                    if (f >= (p.n >> 1)) continue;
-                    half4_t o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float hv = acc[2 * blk][mi][4 * g + j], gv = acc[2 * blk + 1][mi][4 * g + j];
-                        if (p.bias) { hv += p.bias[nb + jn + j]; gv += p.bias[nb + 32 + jn + j]; }
-                        o[j] = (half_t)(hv * uav_gelu_erf(gv) * p.out_scale);
-                    }
-                    *(half4_t*)(p.out + ((long long)m * p.out_stride + f) * 2) = o;
-                }
-            }
-        } else {
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int n = n0 + wn * 128 + ni * 32 + 8 * g + 4 * hi32;
-                    if (n >= p.n) continue;
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
-                    if (p.bias) {
-                        float4_t b = *(const float4_t*)(p.bias + n);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += b[j];
-                    }
-                    if (rb) {
-                        float4_t b = *(const float4_t*)(rb + n);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += b[j];
-                    }
-                    if (p.residual) {
-                        half4_t r = *(const half4_t*)(p.residual + ((long long)m * p.res_stride + n) * 2);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] *= p.out_scale;
-                    if (of32) {
-                        float4_t o = {v[0], v[1], v[2], v[3]};
-                        *(float4_t*)(p.out + ((long long)m * p.out_stride + n) * 4) = o;
-                    } else {
-                        half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                        *(half4_t*)(p.out + ((long long)m * p.out_stride + n) * 2) = o;
-                    }
-                }
-            }
-        }
-    }
+    conv_epilogue<4, 2>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);
 }
 
 }  // namespace

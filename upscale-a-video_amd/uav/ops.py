@@ -41,6 +41,7 @@ class KernelProfiler:
 
     def __init__(self):
         self.enabled = False
+        self.detail = False        # key conv launches by shape (tools / UAV_BENCH_DETAIL)
         self.records = []          # (kernel, flops, bytes, start_event, end_event)
 
     def start(self):
@@ -211,7 +212,9 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
     ev = PROFILER.begin()
     _lib.check(lib.uav_conv_gemm_f16(C.byref(p), _stream()), "uav_conv_gemm_f16")
     # algorithmic work: 2*M*N*K over the LOGICAL taps x input channels (no padding counted)
-    PROFILER.end(ev, "conv_gemm", 2.0 * m * wt.n * wt.kt * wt.kh * wt.kw * wt.cin,
+    PROFILER.end(ev, "conv_gemm" if not PROFILER.detail else
+                 f"conv_gemm cin={wt.cin} n={wt.n} k={wt.kt}x{wt.kh}x{wt.kw} M={m}{' geglu' if wt.geglu else ''}{' up' if upsample else ''}{' s2' if stride == 2 else ''}",
+                 2.0 * m * wt.n * wt.kt * wt.kh * wt.kw * wt.cin,
                  2.0 * (n_img * hi * wi * wt.cin + m * n_out) + 2.0 * wt.n * wt.kt * wt.kh * wt.kw * wt.cin)
     return out
 
