@@ -454,6 +454,9 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
         __syncthreads();
         const char* st = smem + cur * LSTAGE;
         const bool more = ks + 1 < nk;
+        // DMA of the next stage is issued as early as possible: issuing it behind the first MFMA set
+        // was measured (run 12) — +2 % on L2-resident 3x3 convs, -13..-17 % on the HBM-streaming
+        // shapes (K=512 linears, (5,1,1) temporal convs), whose only prefetch distance is this k-step.
         LOAD_FRAGS(0, 0)
         if (more) issue_x(cur ^ 1);
         LOAD_FRAGS(1, 1)
@@ -471,6 +474,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
 
     conv_epilogue<4, 2>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);
 }
+
 
 }  // namespace
 
@@ -515,7 +519,7 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     const long long grid256 = mtiles256 * (q->n_pad / LN);
     static int force_tile = -1;
     if (force_tile < 0) { const char* e = getenv("UAV_CONV_TILE"); force_tile = e ? atoi(e) : 0; }
-    const bool big = !small && (q->n_pad % LN == 0) && (force_tile == 256 || (force_tile != 128 && grid256 >= 224));
+    const bool big = !small && (q->n_pad % LN == 0) && (force_tile >= 256 || (force_tile != 128 && grid256 >= 224));
     if (big) {
         static bool attr_set = false;
         if (!attr_set) {
