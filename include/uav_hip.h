@@ -193,6 +193,42 @@ int uav_propagate_step_f16(const void* feat_prev, const void* feat_cur, const vo
                            int32_t coord_f16, /* 1: replay fp16 grid arithmetic; 0: fp32 */
                            float fuse_scale, float alpha1, float alpha2, void* stream);
 
+
+/* ---- K11: RAFT optical flow (fp32; reference models_video/RAFT/*.py, raft_bi.py:26 runs it in fp32) ----
+ * uav_conv_gemm_f32: same parameter struct as the fp16 kernel with 4-byte elements (a1/a2/w/residual/
+ * out are fp32; c1,c2 multiples of 32 or c1==4 "small" mode; k = tap*cin_p + c; no upsample / rowbias /
+ * GEGLU) on the exact-fp32 MFMA v_mfma_f32_32x32x2_f32.  Replaces nn.Conv2d of extractor.py:10-55,
+ * 118-193 and update.py:6-139, and the all-pairs correlation matmul corr.py:53-60 (weights = the
+ * second feature map).  Activation flags apply after bias/residual/scale. */
+#define UAV_CONV_RELU     4u
+#define UAV_CONV_SIGMOID  8u
+#define UAV_CONV_TANH     16u
+int uav_conv_gemm_f32(const uav_conv_params* p, void* stream);
+/* nn.InstanceNorm2d (no affine) [+ReLU] on rows [n_img*hw][c] (extractor.py:27-30,48-49) */
+int uav_instnorm_f32(const float* x, float* y, int32_t n_img, int32_t hw, int32_t c, float eps,
+                     int32_t relu, void* stream);
+int uav_add_relu_f32(const float* a, const float* b, float* out, int64_t n, int32_t relu, void* stream);
+int uav_axpby_f32(const float* x, const float* z, float* y, int64_t n, float a, float b, void* stream);
+/* dst[r][dst_col+j] = act(src[r][src_col+j]), j < ncols (channel concats; act 0 none, 1 relu, 4 tanh) */
+int uav_copy_cols_f32(const float* src, int32_t src_stride, int32_t src_col, float* dst,
+                      int32_t dst_stride, int32_t dst_col, int32_t ncols, int64_t rows, int32_t act,
+                      void* stream);
+/* ConvGRU gate arithmetic (update.py:44-58); zr rows hold [z | r] (2c).  mode 0: out = r*h;
+ * mode 1: h <- (1-z)*h + z*q in place (out must equal h_in). */
+int uav_gru_gates_f32(const float* zr, const float* h_in, const float* q, float* out, int64_t rows,
+                      int32_t c, int32_t mode, void* stream);
+/* 2x2 average pooling of the correlation volume [P][h][w] (corr.py:23-27) */
+int uav_avgpool2_f32(const float* src, int64_t src_stride, int32_t h, int32_t w, float* dst,
+                     int64_t p_count, void* stream);
+/* (2r+1)^2 x 4-level bilinear correlation lookup (corr.py:29-50): out[p][l*(2r+1)^2 + a*(2r+1) + b] */
+int uav_corr_lookup_f32(const float* const* levels, const int64_t* strides, const int32_t* hs,
+                        const int32_t* ws, const float* coords, int32_t coord_stride, float* out,
+                        int32_t out_stride, int64_t p_count, int32_t radius, void* stream);
+/* convex 8x flow upsampling (raft.py:73-85): flow rows [n*h*w][flow_stride] (x,y), mask rows
+ * [n*h*w][576] -> planar (n,2,8h,8w) */
+int uav_convex_upsample_f32(const float* flow, int32_t flow_stride, const float* mask, float* out,
+                            int32_t n, int32_t h, int32_t w, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -533,3 +533,129 @@ def pipeline_call(unet_sd, unet_cfg, vae_sd, vae_cfg, image, prompt_embeds, *, n
         outs.append(dec.clamp(-1, 1))
     images = torch.cat(outs, dim=2)
     return (images, latents_out, trace) if return_trace else (images, latents_out)
+
+
+# ---------------------------------------------------------------------------------------------
+# RAFT (models_video/RAFT/*.py) — fp32, "things" configuration (non-small, no alternate corr)
+def _norm2d(x, p, kind):
+    """norm layers of extractor.py: InstanceNorm2d (no affine, eps 1e-5) for fnet, eval-mode
+    BatchNorm2d (running stats) for cnet."""
+    if kind == "instance":
+        return F.instance_norm(x, eps=1e-5)
+    return F.batch_norm(x, p["running_mean"], p["running_var"], p["weight"], p["bias"], False, 0.0, 1e-5)
+
+
+def _raft_resblock(x, p, kind, stride):
+    """ResidualBlock.forward (extractor.py:47-55)."""
+    y = F.relu(_norm2d(F.conv2d(x, p["conv1.weight"], p["conv1.bias"], stride, 1), p.sub("norm1"), kind))
+    y = F.relu(_norm2d(F.conv2d(y, p["conv2.weight"], p["conv2.bias"], 1, 1), p.sub("norm2"), kind))
+    if stride != 1:
+        x = _norm2d(F.conv2d(x, p["downsample.0.weight"], p["downsample.0.bias"], stride), p.sub("downsample.1"), kind)
+    return F.relu(x + y)
+
+
+def raft_encoder(x, p, kind):
+    """BasicEncoder.forward (extractor.py:166-193)."""
+    x = F.relu(_norm2d(F.conv2d(x, p["conv1.weight"], p["conv1.bias"], 2, 3), p.sub("norm1"), kind))
+    for name, stride in (("layer1", 1), ("layer2", 2), ("layer3", 2)):
+        x = _raft_resblock(x, p.sub(name + ".0"), kind, stride)
+        x = _raft_resblock(x, p.sub(name + ".1"), kind, 1)
+    return F.conv2d(x, p["conv2.weight"], p["conv2.bias"])
+
+
+def _bilinear_sampler(img, coords):
+    """utils/utils.py:57-71 (pixel coordinates, align_corners=True, zero padding)."""
+    h, w = img.shape[-2:]
+    xg, yg = coords.split([1, 1], dim=-1)
+    grid = torch.cat([2 * xg / (w - 1) - 1, 2 * yg / (h - 1) - 1], dim=-1)
+    return F.grid_sample(img, grid, align_corners=True)
+
+
+def raft_corr_pyramid(f1, f2, levels=4):
+    """CorrBlock.__init__ / corr (corr.py:12-27,53-60)."""
+    b, d, h, w = f1.shape
+    corr = (f1.view(b, d, h * w).transpose(1, 2) @ f2.view(b, d, h * w)) / torch.sqrt(torch.tensor(d).float())
+    corr = corr.reshape(b * h * w, 1, h, w)
+    pyr = [corr]
+    for _ in range(levels - 1):
+        corr = F.avg_pool2d(corr, 2, stride=2)
+        pyr.append(corr)
+    return pyr
+
+
+def raft_corr_lookup(pyr, coords, r=4):
+    """CorrBlock.__call__ (corr.py:29-50)."""
+    coords = coords.permute(0, 2, 3, 1)
+    b, h, w, _ = coords.shape
+    out = []
+    d = torch.linspace(-r, r, 2 * r + 1)
+    delta = torch.stack(torch.meshgrid(d, d, indexing="ij"), dim=-1)        # (dy-index, dx-index, 2) added to (x, y)!
+    for i, corr in enumerate(pyr):
+        cl = coords.reshape(b * h * w, 1, 1, 2) / 2 ** i + delta.view(1, 2 * r + 1, 2 * r + 1, 2)
+        out.append(_bilinear_sampler(corr, cl).view(b, h, w, -1))
+    return torch.cat(out, dim=-1).permute(0, 3, 1, 2).contiguous().float()
+
+
+def raft_update(net, inp, corr, flow, p):
+    """BasicUpdateBlock.forward (update.py:129-139) with BasicMotionEncoder (:94-103), SepConvGRU (:44-60),
+    FlowHead (:13-14).  Returns (net, delta_flow); the mask head is evaluated by the caller."""
+    e = p.sub("encoder")
+    cor = F.relu(F.conv2d(corr, e["convc1.weight"], e["convc1.bias"]))
+    cor = F.relu(F.conv2d(cor, e["convc2.weight"], e["convc2.bias"], padding=1))
+    flo = F.relu(F.conv2d(flow, e["convf1.weight"], e["convf1.bias"], padding=3))
+    flo = F.relu(F.conv2d(flo, e["convf2.weight"], e["convf2.bias"], padding=1))
+    out = F.relu(F.conv2d(torch.cat([cor, flo], 1), e["conv.weight"], e["conv.bias"], padding=1))
+    x = torch.cat([inp, out, flow], dim=1)
+    g = p.sub("gru")
+    for sfx, pad in (("1", (0, 2)), ("2", (2, 0))):
+        hx = torch.cat([net, x], dim=1)
+        z = torch.sigmoid(F.conv2d(hx, g["convz" + sfx + ".weight"], g["convz" + sfx + ".bias"], padding=pad))
+        r = torch.sigmoid(F.conv2d(hx, g["convr" + sfx + ".weight"], g["convr" + sfx + ".bias"], padding=pad))
+        q = torch.tanh(F.conv2d(torch.cat([r * net, x], 1), g["convq" + sfx + ".weight"], g["convq" + sfx + ".bias"], padding=pad))
+        net = (1 - z) * net + z * q
+    fh = p.sub("flow_head")
+    delta = F.conv2d(F.relu(F.conv2d(net, fh["conv1.weight"], fh["conv1.bias"], padding=1)), fh["conv2.weight"], fh["conv2.bias"], padding=1)
+    return net, delta
+
+
+def raft_upsample_flow(flow, mask):
+    """RAFT.upsample_flow (raft.py:73-85): convex combination over the 3x3 neighbourhood, x8."""
+    n, _, h, w = flow.shape
+    mask = torch.softmax(mask.view(n, 1, 9, 8, 8, h, w), dim=2)
+    up = F.unfold(8 * flow, [3, 3], padding=1).view(n, 2, 9, 1, 1, h, w)
+    up = torch.sum(mask * up, dim=2).permute(0, 1, 4, 2, 5, 3)
+    return up.reshape(n, 2, 8 * h, 8 * w)
+
+
+def raft_forward(sd, image1, image2, iters=20):
+    """RAFT.forward(test_mode=True) (raft.py:87-145) -> upsampled flow (N,2,H,W)."""
+    p = P(sd)
+    f = raft_encoder(torch.cat([image1, image2], 0), p.sub("fnet"), "instance").float()
+    f1, f2 = f.split(image1.shape[0], 0)
+    pyr = raft_corr_pyramid(f1, f2)
+    c = raft_encoder(image1, p.sub("cnet"), "batch")
+    net, inp = torch.tanh(c[:, :128]), torch.relu(c[:, 128:])
+    n, _, h, w = image1.shape
+    ys, xs = torch.meshgrid(torch.arange(h // 8), torch.arange(w // 8), indexing="ij")
+    coords0 = torch.stack([xs, ys], 0).float()[None].repeat(n, 1, 1, 1)
+    coords1 = coords0.clone()
+    u = p.sub("update_block")
+    for _ in range(iters):
+        corr = raft_corr_lookup(pyr, coords1)
+        net, delta = raft_update(net, inp, corr, coords1 - coords0, u)
+        coords1 = coords1 + delta
+    m = u.sub("mask")
+    mask = 0.25 * F.conv2d(F.relu(F.conv2d(net, m["0.weight"], m["0.bias"], padding=1)), m["2.weight"], m["2.bias"])
+    return raft_upsample_flow(coords1 - coords0, mask)
+
+
+def raft_bi_forward(sd, frames, iters=20):
+    """RAFT_bi.forward (raft_bi.py:47-68) for H, W multiples of 8 (the trilinear pre-resize and the
+    bilinear flow resize are identities then).  frames (B,3,T,H,W) -> flows fwd/bwd (B,2,T-1,H,W)."""
+    b, c, t, h, w = frames.shape
+    assert h % 8 == 0 and w % 8 == 0
+    a = frames[:, :, :-1].permute(0, 2, 1, 3, 4).reshape(b * (t - 1), c, h, w)
+    bb = frames[:, :, 1:].permute(0, 2, 1, 3, 4).reshape(b * (t - 1), c, h, w)
+    ff = raft_forward(sd, a, bb, iters).reshape(b, t - 1, 2, h, w).permute(0, 2, 1, 3, 4)
+    fb = raft_forward(sd, bb, a, iters).reshape(b, t - 1, 2, h, w).permute(0, 2, 1, 3, 4)
+    return ff.contiguous(), fb.contiguous()

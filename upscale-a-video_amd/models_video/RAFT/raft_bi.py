@@ -1,42 +1,50 @@
-"""RAFT_bi — bidirectional RAFT optical flow for the flow-guided propagation (drop-in surface of the
-reference's `models_video/RAFT/raft_bi.py`: RAFT_bi.forward :47-68, forward_slicing :71-104).
-
-STATUS (round 1): the class surface and the clip-slicing schedule are in place; the RAFT network
-itself (fp32 encoders, all-pairs correlation pyramid, 20 GRU iterations, convex upsampling — K11 of
-SURVEY.md §7) is not built yet, so `forward` raises.  Pre-computed flows can be handed to the
-pipeline through `flows_bi` (that is the only way flows enter the hot loop: pipeline :652-657), which
-is how BASELINE config 3 style runs are exercised until K11 lands.  RAFT is 0.06 % of the FLOPs of a
-clip and runs once per video, outside the reference's own timed region (inference :191 vs :205).
+"""RAFT_bi — bidirectional RAFT optical flow for the flow-guided propagation (drop-in for the
+reference's `models_video/RAFT/raft_bi.py`: initialize_RAFT :19-33, RAFT_bi.forward :47-68,
+forward_slicing :71-104).  fp32, like the reference.  The trilinear pre-resize / bilinear flow
+resize of the reference (:53,:62-63) are identities when H and W are multiples of 8, which is the
+only case built so far.
 """
 import torch
 import torch.nn as nn
+
+from .raft import RAFT
 
 
 def clip_slices(video_length, width):
     """Frame ranges of forward_slicing (reference :73-92): 12/8/4/2-frame clips by width with a
     one-frame halo on every clip but the first."""
-    if width <= 640:
-        n = 12
-    elif width <= 720:
-        n = 8
-    elif width <= 1280:
-        n = 4
-    else:
-        n = 2
+    n = 12 if width <= 640 else 8 if width <= 720 else 4 if width <= 1280 else 2
     if video_length <= n:
         return [(0, video_length)]
     return [((f if f == 0 else f - 1), min(video_length, f + n)) for f in range(0, video_length, n)]
 
 
+def initialize_RAFT(model_path="pretrained_models/raft-things.pth", device="cuda"):
+    model = RAFT()
+    if model_path is not None:
+        sd = torch.load(model_path, map_location="cpu")
+        sd = {(k[7:] if k.startswith("module.") else k): v for k, v in sd.items()}     # saved from nn.DataParallel
+        model.load_state_dict(sd)
+    return model.to(device)
+
+
 class RAFT_bi(nn.Module):
     def __init__(self, model_path="weights/raft-things.pth", device="cuda"):
         super().__init__()
-        self.model_path, self._device = model_path, device
+        self.fix_raft = initialize_RAFT(model_path, device=device)
+        for p in self.fix_raft.parameters():
+            p.requires_grad = False
         self.eval()
 
     def forward(self, gt_local_frames, iters=20):
-        raise NotImplementedError("RAFT (K11) is not built yet in the MI355X engine; pass precomputed `flows_bi` "
-                                  "to the pipeline (see DESIGN.md, 'Not built yet')")
+        b, c, t, h, w = gt_local_frames.size()
+        if h % 8 or w % 8:
+            raise NotImplementedError("H, W not multiples of 8: the reference's trilinear pre-resize is not built yet")
+        ff, fb = [], []
+        for i in range(b):
+            f, bwd = self.fix_raft.flows_bidirectional(gt_local_frames[i].permute(1, 0, 2, 3).contiguous(), iters=iters)
+            ff.append(f.permute(1, 0, 2, 3)); fb.append(bwd.permute(1, 0, 2, 3))
+        return torch.stack(ff).contiguous(), torch.stack(fb).contiguous()
 
     def forward_slicing(self, gt_local_frames, iters=20):
         t = gt_local_frames.size(2)

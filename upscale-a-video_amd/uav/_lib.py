@@ -35,6 +35,7 @@ class ConvParams(C.Structure):
 
 CONV_GEGLU = 1
 CONV_OUT_F32 = 2
+CONV_RELU, CONV_SIGMOID, CONV_TANH = 4, 8, 16
 
 # name -> (restype, argtypes); the complete export list of include/uav_hip.h
 SIGNATURES = {
@@ -54,6 +55,15 @@ SIGNATURES = {
     "uav_cfg_ddim_v0": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, f32, f32, f32, i32, f32, c_p]),
     "uav_ddim_vt": (C.c_int, [c_p, c_p, c_p, c_p, i64, f32, f32, f32, f32, f32, i32, f32, c_p]),
     "uav_axpby_f16": (C.c_int, [c_p, c_p, c_p, i64, f32, f32, c_p]),
+    "uav_conv_gemm_f32": (C.c_int, [C.POINTER(ConvParams), c_p]),
+    "uav_instnorm_f32": (C.c_int, [c_p, c_p, i32, i32, i32, f32, i32, c_p]),
+    "uav_add_relu_f32": (C.c_int, [c_p, c_p, c_p, i64, i32, c_p]),
+    "uav_axpby_f32": (C.c_int, [c_p, c_p, c_p, i64, f32, f32, c_p]),
+    "uav_copy_cols_f32": (C.c_int, [c_p, i32, i32, c_p, i32, i32, i32, i64, i32, c_p]),
+    "uav_gru_gates_f32": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, i32, c_p]),
+    "uav_avgpool2_f32": (C.c_int, [c_p, i64, i32, i32, c_p, i64, c_p]),
+    "uav_corr_lookup_f32": (C.c_int, [C.POINTER(c_p), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), c_p, i32, c_p, i32, i64, i32, c_p]),
+    "uav_convex_upsample_f32": (C.c_int, [c_p, i32, c_p, c_p, i32, i32, i32, c_p]),
     "uav_propagate_step_f16": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i64, i64, i32, i32, f32, f32, f32, c_p]),
 }
 

@@ -412,3 +412,144 @@ def propagate_step(feat_prev, feat_cur, flow_prop, flow_check, out, *, c, h, w, 
                                     alpha1, alpha2, _stream())
     _lib.check(rc, "uav_propagate_step_f16")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# fp32 path (RAFT optical flow, K11)
+F32 = torch.float32
+
+
+def pack_conv_f32(weight, bias=None, device=None, cin_pad_to=None):
+    """fp32 packing for uav_conv_gemm_f32: [n_pad][k_pad], k = tap*cin_p + c; cin_p = cin rounded up to a
+    multiple of 32 (zero weights for the padding channels) or 4 in small mode (cin <= 4)."""
+    w = weight.detach().float()
+    if w.dim() == 2:
+        w = w[:, :, None, None]
+    o, i, kh, kw = w.shape
+    if cin_pad_to is not None:
+        cin_p = cin_pad_to
+    elif i <= 4:
+        cin_p = 4
+    else:
+        cin_p = _round_up(i, 32)
+    w = w.permute(0, 2, 3, 1)
+    if cin_p != i:
+        w = torch.nn.functional.pad(w, (0, cin_p - i))
+    w = w.reshape(o, kh * kw * cin_p)
+    b = None if bias is None else bias.detach().float()
+    n = _round_up(o, 4)
+    k = w.shape[1]
+    n_pad, k_pad = _round_up(n, 128), _round_up(k, 32)
+    wp = torch.zeros(n_pad, k_pad, dtype=F32)
+    wp[:o, :k] = w
+    bp = torch.zeros(n_pad, dtype=F32)
+    if b is not None:
+        bp[:o] = b
+    dev = device if device is not None else weight.device
+    return ConvW(wp.to(dev), bp.to(dev), n, n_pad, k_pad, i, cin_p, 1, kh, kw, False)
+
+
+def conv_gemm_f32(a1, wt: ConvW, *, n_img, hi, wi, stride=1, pad=None, a2=None, residual=None, out_scale=1.0, act=0,
+                  out=None):
+    """fp32 conv / linear on channels-last rows.  act: 0 none, 1 relu, 2 sigmoid, 4 tanh.  `out` may be a
+    column-slice view of a wider row buffer (used to write channel concats in place)."""
+    lib = _lib.load()
+    _req(a1, F32, "a1")
+    c1 = a1.shape[-1]
+    c2 = 0 if a2 is None else _req(a2, F32, "a2").shape[-1]
+    if c1 + c2 != wt.cin_p:
+        raise _lib.UavError(f"conv_f32 input channels {c1}+{c2} != packed {wt.cin_p}")
+    if pad is None:
+        pad = (wt.kh // 2, wt.kw // 2)
+    ph, pw = pad
+    ho = (hi + 2 * ph - wt.kh) // stride + 1
+    wo = (wi + 2 * pw - wt.kw) // stride + 1
+    m = n_img * ho * wo
+    if out is None:
+        out = torch.empty((m, wt.n), dtype=F32, device=a1.device)
+    if out.stride(-1) != 1 or out.dtype != F32 or out.shape[0] != m:
+        raise _lib.UavError("conv_f32: bad output view")
+    p = _lib.ConvParams()
+    p.a1 = _p(a1); p.a2 = _p(a2); p.c1 = c1; p.c2 = c2
+    p.w = _p(wt.w); p.bias = _p(wt.bias); p.rowbias = None; p.rows_per_batch = 0; p.rowbias_stride = 0
+    p.residual = _p(residual); p.res_stride = 0 if residual is None else residual.stride(0)
+    p.out = _p(out); p.out_stride = out.stride(0)
+    p.n_img = n_img; p.t_len = 1; p.hi = hi; p.wi = wi; p.ho = ho; p.wo = wo
+    p.kt = 1; p.kh = wt.kh; p.kw = wt.kw; p.stride = stride; p.pad_t = 0; p.pad_h = ph; p.pad_w = pw; p.upsample = 0
+    p.n = wt.n; p.n_pad = wt.n_pad; p.k_pad = wt.k_pad; p.out_scale = out_scale
+    p.flags = {0: 0, 1: _lib.CONV_RELU, 2: _lib.CONV_SIGMOID, 4: _lib.CONV_TANH}[act]
+    p.zero_page = _p(zero_page(a1.device))
+    ev = PROFILER.begin()
+    _lib.check(lib.uav_conv_gemm_f32(C.byref(p), _stream()), "uav_conv_gemm_f32")
+    PROFILER.end(ev, "conv_gemm_f32", 2.0 * m * wt.n * wt.kh * wt.kw * wt.cin, 4.0 * (n_img * hi * wi * wt.cin + m * wt.n))
+    return out
+
+
+def instnorm_f32(x, *, n_img, hw, relu, eps=1e-5):
+    lib = _lib.load()
+    y = torch.empty_like(_req(x, F32, "x"))
+    _lib.check(lib.uav_instnorm_f32(_p(x), _p(y), n_img, hw, x.shape[-1], eps, int(relu), _stream()), "uav_instnorm_f32")
+    return y
+
+
+def add_relu_f32(a, b, relu=True):
+    lib = _lib.load()
+    o = torch.empty_like(_req(a, F32, "a"))
+    _lib.check(lib.uav_add_relu_f32(_p(a), _p(_req(b, F32, "b")), _p(o), a.numel(), int(relu), _stream()), "uav_add_relu_f32")
+    return o
+
+
+def axpby_f32(x, z, a, b, out=None):
+    lib = _lib.load()
+    y = torch.empty_like(x) if out is None else out
+    _lib.check(lib.uav_axpby_f32(_p(_req(x, F32)), _p(_req(z, F32)), _p(y), x.numel(), a, b, _stream()), "uav_axpby_f32")
+    return y
+
+
+def copy_cols_f32(src, src_col, dst, dst_col, ncols, act=0):
+    """dst[:, dst_col:dst_col+ncols] = act(src[:, src_col:src_col+ncols]) on row-major fp32 buffers."""
+    lib = _lib.load()
+    rows = src.shape[0]
+    rc = lib.uav_copy_cols_f32(_p(src), src.stride(0), src_col, _p(dst), dst.stride(0), dst_col, ncols, rows, act, _stream())
+    _lib.check(rc, "uav_copy_cols_f32")
+    return dst
+
+
+def gru_rh_f32(zr, h):
+    lib = _lib.load()
+    out = torch.empty_like(h)
+    _lib.check(lib.uav_gru_gates_f32(_p(zr), _p(h), None, _p(out), h.shape[0], h.shape[1], 0, _stream()), "uav_gru_gates_f32")
+    return out
+
+
+def gru_blend_f32(zr, q, h):
+    lib = _lib.load()
+    _lib.check(lib.uav_gru_gates_f32(_p(zr), _p(h), _p(q), _p(h), h.shape[0], h.shape[1], 1, _stream()), "uav_gru_gates_f32")
+    return h
+
+
+def avgpool2_f32(src, src_stride, h, w, p_count):
+    lib = _lib.load()
+    dst = torch.empty((p_count, (h // 2) * (w // 2)), dtype=F32, device=src.device)
+    _lib.check(lib.uav_avgpool2_f32(_p(src), src_stride, h, w, _p(dst), p_count, _stream()), "uav_avgpool2_f32")
+    return dst
+
+
+def corr_lookup_f32(levels, strides, hs, ws, coords, out, radius=4):
+    lib = _lib.load()
+    ptrs = (C.c_void_p * 4)(*[_p(t) for t in levels])
+    st = (C.c_int64 * 4)(*strides)
+    hh = (C.c_int32 * 4)(*hs)
+    ww = (C.c_int32 * 4)(*ws)
+    rc = lib.uav_corr_lookup_f32(ptrs, st, hh, ww, _p(coords), coords.stride(0), _p(out), out.stride(0), coords.shape[0],
+                                 radius, _stream())
+    _lib.check(rc, "uav_corr_lookup_f32")
+    return out
+
+
+def convex_upsample_f32(flow_rows, mask_rows, n, h, w):
+    lib = _lib.load()
+    out = torch.empty((n, 2, 8 * h, 8 * w), dtype=F32, device=flow_rows.device)
+    rc = lib.uav_convex_upsample_f32(_p(flow_rows), flow_rows.stride(0), _p(mask_rows), _p(out), n, h, w, _stream())
+    _lib.check(rc, "uav_convex_upsample_f32")
+    return out
