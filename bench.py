@@ -126,6 +126,9 @@ def main():
     ap.add_argument("--width", type=int, default=320)
     ap.add_argument("--frames", type=int, default=8)
     ap.add_argument("--ddim-steps", type=int, default=30)
+    ap.add_argument("--propagation", action="store_true",
+                    help="BASELINE configs[2]: RAFT flows (computed before the timed region, like the reference CLI "
+                         "inference:191 vs :205) + latent propagation at DDIM steps 24,26,28")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -149,8 +152,23 @@ def main():
 
     pipe = build_pipeline(dev, args.height, args.width)
     clip = synthetic_clip(args.frames, args.height, args.width, seed=rank, dev=dev)
-    kw = dict(image=clip, flows_bi=None, num_inference_steps=args.ddim_steps, guidance_scale=6.0, noise_level=120,
-              negative_prompt="blur, worst quality", propagation_steps=[])
+    flows, psteps = None, []
+    if args.propagation:
+        from uav import init_weights
+        from models_video.RAFT.raft_bi import RAFT_bi
+        from models_video.propagation_module import Propagation
+        raft = RAFT_bi(model_path=None, device=dev)
+        init_weights.random_init_(raft, seed=777)
+        with torch.no_grad():
+            for name in ("conv2.weight", "conv2.bias"):     # damp the random flow head: few-pixel flows
+                getattr(raft.fix_raft.update_block.flow_head.conv2, name.split(".")[1]).mul_(0.05)
+        torch.cuda.synchronize(); t_r = time.perf_counter()
+        flows = list(raft.forward_slicing(clip, iters=20))
+        torch.cuda.synchronize(); raft_s = time.perf_counter() - t_r
+        pipe.propagator = Propagation(4, learnable=False)
+        psteps = [s for s in (24, 26, 28) if s < args.ddim_steps]
+    kw = dict(image=clip, flows_bi=flows, num_inference_steps=args.ddim_steps, guidance_scale=6.0, noise_level=120,
+              negative_prompt="blur, worst quality", propagation_steps=psteps)
     prompt = "best quality, extremely detailed"
 
     def one_step(seed):
@@ -189,9 +207,11 @@ def main():
             "metric": METRIC, "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {args.frames}-frame {args.height}x{args.width}->{4 * args.height}x{4 * args.width}, "
-                                   f"{args.ddim_steps} DDIM steps, guidance 6, noise_level 120, vae_3d, no propagation; "
-                                   "one clip per GPU per step (clip-parallel, no collective)",
+            "config": {"workload": f"configs[{2 if args.propagation else 1}]: {args.frames}-frame {args.height}x{args.width}->{4 * args.height}x{4 * args.width}, "
+                                   f"{args.ddim_steps} DDIM steps, guidance 6, noise_level 120, vae_3d, "
+                                   + (f"RAFT flows (20 iters, {raft_s * 1e3:.0f} ms, outside the timed region like the reference) + "
+                                      f"latent propagation at steps {psteps}; " if args.propagation else "no propagation; ")
+                                   + "one clip per GPU per step (clip-parallel, no collective)",
                        "clips_per_step": world, "frames_per_clip": args.frames},
         }
         if use_events:

@@ -130,3 +130,55 @@ def test_raft_bi_vs_oracle_and_reference_fixture(dev):
     if os.path.isdir(d):
         with open(os.path.join(d, "parity.jsonl"), "a") as fh:
             fh.write(json.dumps(dict(case="raft_bi_t3_128x160_iters4", rel_l2_fwd_vs_oracle=e_f, rel_l2_bwd_vs_oracle=e_b)) + "\n")
+
+
+def test_pipeline_with_raft_flows_and_propagation(dev):
+    """BASELINE config-3 style run at reduced width: RAFT_bi flows -> x0-space propagation at one
+    DDIM step, engine vs oracle (both consume their OWN RAFT flows)."""
+    import golden_cases as GC
+    import synth
+    import uav_oracle as O
+    from models_video.RAFT.raft_bi import RAFT_bi
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
+    from models_video.propagation_module import Propagation
+    from models_video.scheduling_ddim import DDIMScheduler, DDPMScheduler
+    from models_video.unet_video import UNetVideoModel
+    from uav.standin_text import StandInTextEncoder, StandInTokenizer
+    t, h, w = 4, 128, 128
+    clip = synth.synth_clip(1, t, h, w, seed=9, motion=(2, 1))
+    rb = RAFT_bi(model_path=None, device="cpu")
+    rsd = synth.synth_state_dict(rb.fix_raft.state_dict(), seed=777)
+    # damp the random flow head so that flows stay in a few-pixel range (nearest warp far from clamping)
+    for k in ("update_block.flow_head.conv2.weight", "update_block.flow_head.conv2.bias"):
+        rsd[k] = rsd[k] * 0.05
+    rb.fix_raft.load_state_dict(rsd); rb = rb.to(dev)
+    flows = rb.forward_slicing(clip.to(dev), iters=3)
+    with torch.no_grad():
+        oflows = O.raft_bi_forward(rsd, clip, iters=3)
+    assert rel_l2(flows[0], oflows[0]) < 1e-3
+    unet = UNetVideoModel.from_config(dict(GC.UNET_TINY)); usd = synth.synth_state_dict(unet.state_dict(), seed=1234)
+    unet.load_state_dict(usd); unet = unet.to(dev).eval()
+    vae = AutoencoderKLVideo.from_config(dict(GC.VAE3D_TINY)); vsd = synth.synth_state_dict(vae.state_dict(), seed=4321)
+    vae.load_state_dict(vsd); vae = vae.to(dev).eval()
+    tok = StandInTokenizer()
+    prop = Propagation(4, learnable=False); prop.coord_f16 = False
+    dim = GC.UNET_TINY["cross_attention_dim"]
+    pipe = VideoUpscalePipeline(text_encoder=StandInTextEncoder(tok, dim, dtype=torch.float32), tokenizer=tok,
+                                low_res_scheduler=DDPMScheduler(), scheduler=DDIMScheduler(**GC.SCHED), vae=vae, unet=unet,
+                                propagator=prop).to(dev)
+    gen = torch.Generator().manual_seed(10)
+    out, lat = pipe("a prompt", image=clip.to(dev), flows_bi=list(flows), generator=gen, num_inference_steps=2, guidance_scale=6.0,
+                    noise_level=120, negative_prompt="bad", propagation_steps=[1], return_dict=False)
+    gen = torch.Generator().manual_seed(10)
+    lr_noise = torch.randn(clip.shape, generator=gen); lat0 = torch.randn((1, 4, t, h, w), generator=gen)
+    pe = torch.cat([synth.synth_prompt_embeds("bad", dim), synth.synth_prompt_embeds("a prompt", dim)])
+    with torch.no_grad():
+        _, olat = O.pipeline_call(usd, GC.UNET_TINY, vsd, GC.VAE3D_TINY, clip, pe, num_inference_steps=2, guidance_scale=6.0,
+                                  noise_level=120, lr_noise=lr_noise, latents=lat0, flows_bi=list(oflows), propagation_steps=(1,),
+                                  scheduler_kwargs=GC.SCHED, decode=False)
+    # nearest-neighbour warps may pick a different source pixel where the two flow fields differ in the
+    # last ulp around .5: compare robustly (fraction of latent elements off by more than 5e-2)
+    bad = ((lat.float().cpu() - olat).abs() > 5e-2).float().mean().item()
+    assert bad < 2e-2, f"{bad} of latent elements differ"
+    assert out.shape == (1, 3, t, 4 * h, 4 * w)
