@@ -356,6 +356,7 @@ constexpr int LM = 256, LN = 256;
 constexpr int LA_BYTES = LM * BK * 2;            // 32 KiB
 constexpr int LSTAGE = 2 * LA_BYTES;             // 64 KiB (X tile + W tile)
 
+template <int DBG>   // DBG: ablation builds for profiling only (bit0: no DMA in the loop, bit1: no MFMA); 0 in production
 __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -443,8 +444,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
 #define MFMA_SET(SET)                                                                            \
     {                                                                                            \
         _Pragma("unroll") for (int i = 0; i < 4; ++i)                                            \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                        \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[SET][i], fx[SET][j], acc[i][j], 0, 0, 0); \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                      \
+                if (DBG & 2) { asm volatile("" ::"v"(fw[SET][i]), "v"(fx[SET][j])); }            \
+                else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[SET][i], fx[SET][j], acc[i][j], 0, 0, 0); \
+            }                                                                                    \
     }
 
     issue_x(0); issue_w(0, 0);
@@ -454,14 +457,13 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
         __syncthreads();
         const char* st = smem + cur * LSTAGE;
         const bool more = ks + 1 < nk;
-        // DMA of the next stage is issued as early as possible: issuing it behind the first MFMA set
-        // was measured (run 12) — +2 % on L2-resident 3x3 convs, -13..-17 % on the HBM-streaming
-        // shapes (K=512 linears, (5,1,1) temporal convs), whose only prefetch distance is this k-step.
+        // The whole DMA of the next stage (X gather + W rows) is issued FIRST: an ablation (run 15) showed the
+        // loop is latency-bound — without MFMAs a k-step still takes 1.3 us (L2-hit DMA round trip), and
+        // with the W half issued behind the first MFMA set only ~0.35 us of MFMA work was left to cover it.
+        if (more && !(DBG & 1)) { issue_x(cur ^ 1); issue_w(cur ^ 1, ks + 1); }
         LOAD_FRAGS(0, 0)
-        if (more) issue_x(cur ^ 1);
         LOAD_FRAGS(1, 1)
         MFMA_SET(0)
-        if (more) issue_w(cur ^ 1, ks + 1);
         LOAD_FRAGS(0, 2)
         MFMA_SET(1)
         LOAD_FRAGS(1, 3)
@@ -521,12 +523,16 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     if (force_tile < 0) { const char* e = getenv("UAV_CONV_TILE"); force_tile = e ? atoi(e) : 0; }
     const bool big = !small && (q->n_pad % LN == 0) && (force_tile >= 256 || (force_tile != 128 && grid256 >= 224));
     if (big) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
-            attr_set = true;
+        static int dbg = -1;
+        if (dbg < 0) {
+            const char* e = getenv("UAV_CONV_DBG"); dbg = e ? atoi(e) : 0;
+            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
+            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
+            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
         }
-        hipLaunchKernelGGL(conv_gemm256_kernel, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+        if (dbg == 1) hipLaunchKernelGGL(conv_gemm256_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+        else if (dbg == 2) hipLaunchKernelGGL(conv_gemm256_kernel<2>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+        else hipLaunchKernelGGL(conv_gemm256_kernel<0>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
     } else if (small)
         hipLaunchKernelGGL(conv_gemm_kernel<1>, dim3((unsigned)grid), dim3(256), 2 * STAGE_BYTES, s, a);
     else
