@@ -129,6 +129,8 @@ def main():
     ap.add_argument("--propagation", action="store_true",
                     help="BASELINE configs[2]: RAFT flows (computed before the timed region, like the reference CLI "
                          "inference:191 vs :205) + latent propagation at DDIM steps 24,26,28")
+    ap.add_argument("--no-cfg-share", action="store_true",
+                    help="A/B switch: run the text-independent UNet head for both guidance branches like the reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -153,6 +155,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (gfx950)")
 
     pipe = build_pipeline(dev, args.height, args.width)
+    pipe.cfg_shared_input = not args.no_cfg_share
     clip = synthetic_clip(args.frames, args.height, args.width, seed=rank, dev=dev)
     flows, psteps = None, []
     if args.propagation:

@@ -165,10 +165,14 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_kernel(AttnArgs 
         }
         l_run = l_run * alpha + ps;
         m_run = m_new;
+        // exact deferred rescale (cdna guide T13 with threshold 0): once the running maxima of all the
+        // wave's rows have settled alpha == 1 for every lane and the O-wide multiply is skipped
+        if (!__all(alpha == 1.0f)) {
 #pragma unroll
-        for (int i = 0; i < D / 32; ++i)
+            for (int i = 0; i < D / 32; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        }
         // ---- O^T += V^T P^T -------------------------------------------------------------------
 #pragma unroll
         for (int i = 0; i < D / 32; ++i) {
@@ -327,10 +331,12 @@ __global__ __launch_bounds__(512, 2) void attn512_kernel(AttnArgs p) {
         }
         l_run = l_run * alpha + ps;
         m_run = m_new;
+        if (!__all(alpha == 1.0f)) {                           // exact deferred rescale, see attn_kernel
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+            for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const char* vrow = Vt + ((dh * 8 + i) * 32 + l32) * VT_STRIDE + hi * 8;

@@ -69,6 +69,9 @@ class VideoUpscalePipeline(ConfigMixin):
                               low_res_scheduler=low_res_scheduler, scheduler=scheduler, propagator=propagator)
         self.register_to_config(max_noise_level=max_noise_level)
         self._device = torch.device("cpu")
+        # under classifier-free guidance both UNet batch entries see identical latents / low_res / timestep, so the
+        # text-independent head of the UNet is computed once (UNetVideoModel.forward cfg_shared_input; bit-identical)
+        self.cfg_shared_input = True
 
     def register_modules(self, **kwargs):
         for k, v in kwargs.items():
@@ -254,7 +257,8 @@ class VideoUpscalePipeline(ConfigMixin):
                 for (s, e) in wins:
                     if (s, e) != prev_win:                                        # duplicate tail window: reuse `o`
                         o = self.unet(lin[:, :, s:e].contiguous(), t, image[:, :, s:e].contiguous(),
-                                      encoder_hidden_states=prompt_embeds, class_labels=level).sample
+                                      encoder_hidden_states=prompt_embeds, class_labels=level,
+                                      cfg_shared_input=do_cfg and self.cfg_shared_input).sample
                     prev_win = (s, e)
                     if eps is None:
                         eps = torch.empty((o.shape[0], o.shape[1], t_total) + tuple(o.shape[3:]), dtype=o.dtype, device=device)
@@ -265,7 +269,8 @@ class VideoUpscalePipeline(ConfigMixin):
                         else:                                                     # running 0.5/0.5 blend (:634)
                             eps[:, :, idx] = ops.axpby(eps[:, :, idx].contiguous(), o[:, :, k].contiguous(), 0.5, 0.5)
             else:
-                eps = self.unet(lin, t, image, encoder_hidden_states=prompt_embeds, class_labels=level).sample
+                eps = self.unet(lin, t, image, encoder_hidden_states=prompt_embeds, class_labels=level,
+                                cfg_shared_input=do_cfg and self.cfg_shared_input).sample
             eps = eps.contiguous()
             if do_cfg:
                 guided, x0 = self.scheduler.cfg_step_v0(eps[0:1], eps[1:2], guidance_scale, t, latents)

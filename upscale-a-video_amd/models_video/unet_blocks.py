@@ -110,6 +110,7 @@ class DownBlock3D(nn.Module):
         self.downsamplers = nn.ModuleList([Downsample3D(out_channels, use_conv=True, out_channels=out_channels,
                                                         padding=downsample_padding, name="op")]) if add_downsample else None
         self.gradient_checkpointing = False
+        self.has_cross_attention = False
 
     def run(self, x, g, temb, ehs_rows=None, n_text=0):
         outs = []

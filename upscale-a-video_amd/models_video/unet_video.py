@@ -195,7 +195,7 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
         return emb.contiguous()
 
     def forward(self, sample, timestep, low_res, encoder_hidden_states=None, class_labels=20, attention_mask=None,
-                return_dict: bool = True):
+                return_dict: bool = True, cfg_shared_input: bool = False):
         if attention_mask is not None:
             raise NotImplementedError("attention_mask is never passed by the pipeline")
         if sample.shape[1] + low_res.shape[1] != self.config.in_channels:
@@ -218,9 +218,26 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
         ehs_rows = self.__dict__["_ehs_src"][2]
         n_text = ehs.shape[1]
 
-        x = self.conv_in.run(x, g)
-        skips = [(x, g)]
-        for blk, tblk in zip(self.down_blocks, self.down_temp_blocks):
+        # Classifier-free guidance feeds the same latents / low_res / timestep to both batch entries and only the
+        # text differs, so everything ahead of the first text-conditioned block is computed once and duplicated
+        # (bit-identical to running it twice; the pipeline sets `cfg_shared_input`, default off).
+        first = 0
+        if cfg_shared_input and bsz == 2 and not getattr(self.down_blocks[0], "has_cross_attention", True):
+            rows1 = g.rows // 2
+            g1 = E.Geom(1, g.t, g.h, g.w)
+            emb1 = emb[:1].contiguous()
+            x1 = self.conv_in.run(x[:rows1], g1)
+            skips1 = [(x1, g1)]
+            x1, g1, outs = self.down_blocks[0].run(x1, g1, emb1, ehs_rows, n_text)
+            skips1.extend(outs)
+            x1 = self.down_temp_blocks[0].run(x1, g1, emb1)
+            skips = [(torch.cat([s_, s_]), E.Geom(2, sg.t, sg.h, sg.w)) for (s_, sg) in skips1]
+            x, g = torch.cat([x1, x1]), E.Geom(2, g1.t, g1.h, g1.w)
+            first = 1
+        else:
+            x = self.conv_in.run(x, g)
+            skips = [(x, g)]
+        for blk, tblk in list(zip(self.down_blocks, self.down_temp_blocks))[first:]:
             x, g, outs = blk.run(x, g, emb, ehs_rows, n_text)
             skips.extend(outs)
             x = tblk.run(x, g, emb)
