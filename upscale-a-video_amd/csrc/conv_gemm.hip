@@ -42,6 +42,7 @@ struct ConvArgs {
     int n, n_pad, k_pad; float out_scale; unsigned flags;
     const char* zero_page;
     long long M;
+    int korder;
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -255,12 +256,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs p) {
     const int nk = p.k_pad / BK;
     const char* wrow = p.w + ((long long)(n0 + rbase) * p.k_pad + slot_log * 8) * 2;
 
+    // k-steps visit the K axis TAP-INNERMOST: (chunk 0: tap 0..ntaps-1), (chunk 1: ...).  The taps of a 3x3 conv
+    // re-read almost the same source pixels, so consecutive k-steps of a workgroup (and of its neighbours on the
+    // XCD) hit the lines the previous step just pulled into the 4 MiB L2; with the channel-innermost order the reuse
+    // distance was cin/64 k-steps x 32 workgroups = 8 MB per XCD and 65 % of the X requests missed L2 (PMC run 21).
     int pix[4] = {-1, -1, -1, -1};
     int nxt_tap = 0, nxt_c = 0;          // (tap, channel offset) of the NEXT k-step to issue
 
     auto issue = [&](int stage, int ks) {
         char* sA = smem + stage * STAGE_BYTES;
         char* sB = sA + A_BYTES;
+        long long wk = (long long)ks * BK;   // k offset of this step's weight slice
         if (SMALL) {
             // cin_p == 8: every 16-B slot is one tap of one pixel.
             int tap = ks * 8 + slot_log;
@@ -273,7 +279,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs p) {
                 dma16(g, sA + (ps * 256 + wave * 64) * 16);
             }
         } else {
-            if (nxt_c == 0) {            // tap changed (uniform branch): refresh source pixels
+            if (ntaps > 1 || ks == 0) {  // uniform branch: source pixels of this tap
                 int dt = nxt_tap / khw; int rem = nxt_tap - dt * khw; int dy = rem / p.kw; int dx = rem - dy * p.kw;
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps)
@@ -288,12 +294,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs p) {
                 const char* g = pix[ps] >= 0 ? src + ((long long)pix[ps] * cs + coff) * 2 : p.zero_page;
                 dma16(g, sA + (ps * 256 + wave * 64) * 16);
             }
-            nxt_c += BK;
-            if (nxt_c >= cin) { nxt_c = 0; ++nxt_tap; }
+            wk = nxt_tap * cin + nxt_c;
+            if (p.korder) { if (++nxt_tap >= ntaps) { nxt_tap = 0; nxt_c += BK; } }
+            else { nxt_c += BK; if (nxt_c >= cin) { nxt_c = 0; ++nxt_tap; } }
         }
 #pragma unroll
         for (int ps = 0; ps < 4; ++ps)
-            dma16(wrow + ((long long)ps * 32 * p.k_pad + (long long)ks * BK) * 2, sB + (ps * 256 + wave * 64) * 16);
+            dma16(wrow + ((long long)ps * 32 * p.k_pad + wk) * 2, sB + (ps * 256 + wave * 64) * 16);
     };
 
     // ---- accumulators: acc[ni][mi], wave tile = rows n [wn*64,+64) x cols m [wm*64,+64) -----
@@ -356,7 +363,7 @@ constexpr int LM = 256, LN = 256;
 constexpr int LA_BYTES = LM * BK * 2;            // 32 KiB
 constexpr int LSTAGE = 2 * LA_BYTES;             // 64 KiB (X tile + W tile)
 
-template <int DBG>   // DBG: ablation builds for profiling only (bit0: no DMA in the loop, bit1: no MFMA); 0 in production
+template <int DBG>   // DBG: ablation builds for profiling only (bit0: no DMA in the loop, bit1: no MFMA, 4: compiler-scheduled k-step); 0 in production
 __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -372,53 +379,68 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
 
     const int slot_log = (tid & 7) ^ ((tid >> 4) & 7);
     const int rbase = tid >> 3;                          // 0..63; rows r = pass*64 + rbase
-    int img[4], tloc[4], yx[4];
-    bool mval[4];
+    // Per-row gather constants.  Source pixel of tap (dt,dy,dx): frame rimg+dt, y = (rys+dy) >> ups, x = (rxs+dx) >> ups,
+    // valid iff 0 <= rtl+dt < t_len and 0 <= rys+dy < ylim and 0 <= rxs+dx < xlim (unsigned compares); rows past M get an
+    // rys that can never pass.  Everything below is branch-free: the previous formulation went through divergent
+    // branches and kept its k-step counters in scratch (12 B/lane), both on the post-barrier critical path.
+    int rimg[4], rtl[4], rys[4], rxs[4];
     const int hw_o = p.ho * p.wo;
+    const int ups = p.upsample ? 1 : 0;
+    const int ylim = p.upsample ? p.ho : p.hi, xlim = p.upsample ? p.wo : p.wi;
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         long long m = m0 + ps * 64 + rbase;
-        mval[ps] = m < p.M;
-        int mm = mval[ps] ? (int)m : 0;
+        const bool ok = m < p.M;
+        int mm = ok ? (int)m : 0;
         int im = mm / hw_o; int rem = mm - im * hw_o;
         int yo = rem / p.wo; int xo = rem - yo * p.wo;
-        img[ps] = im; tloc[ps] = im % p.t_len; yx[ps] = (yo << 16) | xo;
+        rimg[ps] = im - p.pad_t; rtl[ps] = im % p.t_len - p.pad_t;
+        rys[ps] = ok ? yo * p.stride - p.pad_h : -(1 << 28); rxs[ps] = xo * p.stride - p.pad_w;
     }
     const int cin = p.c1 + p.c2;
     const int khw = p.kh * p.kw;
+    const int ntaps = p.kt * khw;
     const int nk = p.k_pad / BK;
     const char* wrow = p.w + ((long long)(n0 + rbase) * p.k_pad + slot_log * 8) * 2;
 
+    // k-step state (wave-uniform): tap (dt,dy,dx) and channel offset of the NEXT k-step to issue
+    int kdt = 0, kdy = 0, kdx = 0, ktap = 0, kc = 0;
     int pix[4] = {-1, -1, -1, -1};
-    int nxt_tap = 0, nxt_c = 0;
-    const char* xsrc = p.a1; int xcs = p.c1; int xcoff = 0;
+    bool pix_valid = false;
 
-    // DMA of one stage is split in two halves (X pieces, then W pieces) issued in different k-slices
-    auto issue_x = [&](int stage) {
-        char* sA = smem + stage * LSTAGE;
-        if (nxt_c == 0) {
-            int dt = nxt_tap / khw; int rem = nxt_tap - dt * khw; int dy = rem / p.kw; int dx = rem - dy * p.kw;
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps)
-                pix[ps] = mval[ps] ? src_pixel(p, img[ps], tloc[ps], yx[ps] >> 16, yx[ps] & 0xffff, dt, dy, dx) : -1;
-        }
-        const bool first = nxt_c < p.c1;
-        xsrc = first ? p.a1 : p.a2; xcs = first ? p.c1 : p.c2;
-        xcoff = (first ? nxt_c : nxt_c - p.c1) + slot_log * 8;
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const char* g = pix[ps] >= 0 ? xsrc + ((long long)pix[ps] * xcs + xcoff) * 2 : p.zero_page;
-            dma16(g, sA + (ps * 512 + wave * 64) * 16);
-        }
-        nxt_c += BK;
-        if (nxt_c >= cin) { nxt_c = 0; ++nxt_tap; }
-    };
-    auto issue_w = [&](int stage, int ks) {
-        char* sB = smem + stage * LSTAGE + LA_BYTES;
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps)
-            dma16(wrow + ((long long)ps * 64 * p.k_pad + (long long)ks * BK) * 2, sB + (ps * 512 + wave * 64) * 16);
-    };
+#define ISSUE_STAGE(STAGE)                                                                                   \
+    {                                                                                                        \
+        char* sA = smem + (STAGE) * LSTAGE;                                                                  \
+        if (ntaps > 1 || !pix_valid) {                                                                       \
+            _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                               \
+                const int tt = rtl[ps] + kdt, yv = rys[ps] + kdy, xv = rxs[ps] + kdx;                        \
+                const bool ok = ((unsigned)tt < (unsigned)p.t_len) & ((unsigned)yv < (unsigned)ylim) &       \
+                                ((unsigned)xv < (unsigned)xlim);                                             \
+                const int px = ((rimg[ps] + kdt) * p.hi + (yv >> ups)) * p.wi + (xv >> ups);                 \
+                pix[ps] = ok ? px : -1;                                                                      \
+            }                                                                                                \
+            pix_valid = true;                                                                                \
+        }                                                                                                    \
+        const bool first = kc < p.c1;                                                                        \
+        const char* xsrc = first ? p.a1 : p.a2;                                                              \
+        const int xcs = first ? p.c1 : p.c2;                                                                 \
+        const int xcoff = (first ? kc : kc - p.c1) + slot_log * 8;                                           \
+        _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                   \
+            const char* g = pix[ps] >= 0 ? xsrc + ((long long)pix[ps] * xcs + xcoff) * 2 : p.zero_page;      \
+            dma16(g, sA + (ps * 512 + wave * 64) * 16);                                                      \
+        }                                                                                                    \
+        const long long wk = (long long)ktap * cin + kc;                                                     \
+        _Pragma("unroll") for (int ps = 0; ps < 4; ++ps)                                                     \
+            dma16(wrow + ((long long)ps * 64 * p.k_pad + wk) * 2, sA + LA_BYTES + (ps * 512 + wave * 64) * 16); \
+        if (p.korder) {                          /* tap-innermost K order (see conv_gemm_kernel) */          \
+            ++ktap;                                                                                          \
+            if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } }                           \
+            if (ktap == ntaps) { ktap = 0; kdt = 0; kdy = 0; kdx = 0; kc += BK; }                            \
+        } else {                                                                                             \
+            kc += BK;                                                                                        \
+            if (kc >= cin) { kc = 0; ++ktap; if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } } } \
+        }                                                                                                    \
+    }
 
     const int wn = wave & 1, wm = wave >> 1;
     float16_t acc[4][2];
@@ -438,8 +460,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
 #define LOAD_FRAGS(SET, KK)                                                                      \
     {                                                                                            \
         const int so = (((KK) * 2 + hi32) ^ sw) << 4;                                            \
+        if (DBG != 5 || ks == 0) {                                                                \
         _Pragma("unroll") for (int i = 0; i < 4; ++i) fw[SET][i] = *(const half8_t*)(st + offW + i * 4096 + so); \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) fx[SET][j] = *(const half8_t*)(st + offX + j * 4096 + so); \
+        }                                                                                         \
     }
 #define MFMA_SET(SET)                                                                            \
     {                                                                                            \
@@ -450,8 +474,63 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
             }                                                                                    \
     }
 
-    issue_x(0); issue_w(0, 0);
+    ISSUE_STAGE(0)
     int cur = 0;
+    if constexpr (DBG == 0) {
+        // Production k-loop: the 24 ds_read_b128 + 32 MFMA of one k-step are one hand-scheduled asm block.  The
+        // compiler's own waitcnt insertion put `s_waitcnt lgkmcnt(0)` in front of every MFMA group (it does not
+        // count LDS reads past an LDS-DMA), which exposed the LDS latency twice per k-step; here each MFMA waits
+        // for exactly the fragments it consumes (LDS returns in order), and the reads of slice kk+2 are issued
+        // into the registers slice kk just released.  Read order per slice: w0 x0 x1 w1 w2 w3.
+        const unsigned ldsb = (unsigned)(size_t)(lptr_t)smem;
+        const unsigned bW = ldsb + (wn * 128 + l32) * 128, bX = ldsb + (wm * 64 + l32) * 128;
+        unsigned so[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) so[kk] = ((kk * 2 + hi32) ^ sw) << 4;
+        for (int ks = 0; ks < nk; ++ks) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const unsigned sb = cur * LSTAGE;
+            if (ks + 1 < nk) ISSUE_STAGE(cur ^ 1)
+            const unsigned aw0 = bW + sb + so[0], aw1 = bW + sb + so[1], aw2 = bW + sb + so[2], aw3 = bW + sb + so[3];
+            const unsigned ax0 = bX + sb + so[0], ax1 = bX + sb + so[1], ax2 = bX + sb + so[2], ax3 = bX + sb + so[3];
+            half8_t w00, w01, w02, w03, x00, x01, w10, w11, w12, w13, x10, x11;
+#define RD(D, A, OFF) "ds_read_b128 %[" #D "], %[" #A "] offset:" #OFF "\n"
+#define RDSET(S, A, AX) RD(w##S##0, A, 32768) RD(x##S##0, AX, 0) RD(x##S##1, AX, 4096) RD(w##S##1, A, 36864) RD(w##S##2, A, 40960) RD(w##S##3, A, 45056)
+#define MF(C, A, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #A "], %[" #B "], %[" #C "]\n"
+#define WT(N) "s_waitcnt lgkmcnt(" #N ")\n"
+#define MFSET(S, N0, N1, N2, N3, N4)                                                           \
+    WT(N0) MF(c00, w##S##0, x##S##0) WT(N1) MF(c01, w##S##0, x##S##1)                          \
+    WT(N2) MF(c10, w##S##1, x##S##0) MF(c11, w##S##1, x##S##1)                                 \
+    WT(N3) MF(c20, w##S##2, x##S##0) MF(c21, w##S##2, x##S##1)                                 \
+    WT(N4) MF(c30, w##S##3, x##S##0) MF(c31, w##S##3, x##S##1)
+            asm volatile(
+                "s_waitcnt lgkmcnt(0)\n"          // nothing of the compiler's (SMEM) may be counted below
+                RDSET(0, aw0, ax0) RDSET(1, aw1, ax1)
+                MFSET(0, 10, 9, 8, 7, 6)
+                RDSET(0, aw2, ax2)
+                MFSET(1, 10, 9, 8, 7, 6)
+                RDSET(1, aw3, ax3)
+                MFSET(0, 10, 9, 8, 7, 6)
+                MFSET(1, 4, 3, 2, 1, 0)
+                : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]),
+                  [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]), [c30] "+v"(acc[3][0]), [c31] "+v"(acc[3][1]),
+                  [w00] "=&v"(w00), [w01] "=&v"(w01), [w02] "=&v"(w02), [w03] "=&v"(w03), [x00] "=&v"(x00), [x01] "=&v"(x01),
+                  [w10] "=&v"(w10), [w11] "=&v"(w11), [w12] "=&v"(w12), [w13] "=&v"(w13), [x10] "=&v"(x10), [x11] "=&v"(x11)
+                : [aw0] "v"(aw0), [aw1] "v"(aw1), [aw2] "v"(aw2), [aw3] "v"(aw3),
+                  [ax0] "v"(ax0), [ax1] "v"(ax1), [ax2] "v"(ax2), [ax3] "v"(ax3)
+                : "memory");
+#undef RD
+#undef RDSET
+#undef MF
+#undef WT
+#undef MFSET
+            cur ^= 1;
+        }
+        // the MFMAs issued last may still be in flight and the compiler cannot see them: cover the XDL-write ->
+        // VALU-read hazard window before the epilogue touches the accumulators
+        asm volatile("s_nop 15\ns_nop 15" ::: "memory");
+    } else {
     for (int ks = 0; ks < nk; ++ks) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -460,19 +539,25 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
         // The whole DMA of the next stage (X gather + W rows) is issued FIRST: an ablation (run 15) showed the
         // loop is latency-bound — without MFMAs a k-step still takes 1.3 us (L2-hit DMA round trip), and
         // with the W half issued behind the first MFMA set only ~0.35 us of MFMA work was left to cover it.
-        if (more && !(DBG & 1)) { issue_x(cur ^ 1); issue_w(cur ^ 1, ks + 1); }
+        if (more && !(DBG & 1)) ISSUE_STAGE(cur ^ 1)
+        // sched_barrier(0) pins the source order: without it the machine scheduler sinks every ds_read next to its
+        // first use and waits lgkmcnt(0) in front of each MFMA group (checked in the ISA)
+#define SB __builtin_amdgcn_sched_barrier(0);
         LOAD_FRAGS(0, 0)
-        LOAD_FRAGS(1, 1)
-        MFMA_SET(0)
-        LOAD_FRAGS(0, 2)
+        LOAD_FRAGS(1, 1) SB
+        MFMA_SET(0) SB
+        LOAD_FRAGS(0, 2) SB
+        MFMA_SET(1) SB
+        LOAD_FRAGS(1, 3) SB
+        MFMA_SET(0) SB
         MFMA_SET(1)
-        LOAD_FRAGS(1, 3)
-        MFMA_SET(0)
-        MFMA_SET(1)
+#undef SB
         cur ^= 1;
+    }
     }
 #undef LOAD_FRAGS
 #undef MFMA_SET
+#undef ISSUE_STAGE
 
     conv_epilogue<4, 2>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);
 }
@@ -512,6 +597,9 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     a.zero_page = (const char*)q->zero_page;
     a.M = (long long)q->n_img * q->ho * q->wo;
     if (a.M <= 0 || a.M >= (1ll << 31)) return UAV_ESHAPE;
+    static int korder = -1;
+    if (korder < 0) { const char* e = getenv("UAV_CONV_KORDER"); korder = e ? atoi(e) : 1; }
+    a.korder = korder;
     const long long mtiles = (a.M + BM - 1) / BM;
     const long long grid = mtiles * (q->n_pad / BN);
     if (grid >= (1ll << 31)) return UAV_ESHAPE;
@@ -529,9 +617,15 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
             (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
             (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
             (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
+            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
+            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
+            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
         }
         if (dbg == 1) hipLaunchKernelGGL(conv_gemm256_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 2) hipLaunchKernelGGL(conv_gemm256_kernel<2>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+        else if (dbg == 4) hipLaunchKernelGGL(conv_gemm256_kernel<4>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+        else if (dbg == 3) hipLaunchKernelGGL(conv_gemm256_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+        else if (dbg == 5) hipLaunchKernelGGL(conv_gemm256_kernel<5>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else hipLaunchKernelGGL(conv_gemm256_kernel<0>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
     } else if (small)
         hipLaunchKernelGGL(conv_gemm_kernel<1>, dim3((unsigned)grid), dim3(256), 2 * STAGE_BYTES, s, a);

@@ -82,6 +82,11 @@ def load(build_if_missing=True):
     if _LIB is not None:
         return _LIB
     path = _build.LIB
+    override = os.environ.get("UAV_HIP_LIB")        # development A/B only: load another build of the same ABI
+    if override:
+        if not os.path.exists(override):
+            raise UavError(f"UAV_HIP_LIB={override} does not exist")
+        path, build_if_missing = override, False
     if build_if_missing and not _build.is_fresh():
         if os.path.exists(_build.HIPCC):
             _build.build()

@@ -47,6 +47,20 @@ def build(force=False, verbose=True):
         raise RuntimeError(f"hipcc not found at {HIPCC}; cannot build libuav_hip.so")
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
+    # one builder at a time: with one process per GPU all ranks import the package at once
+    import fcntl
+    lock = open(os.path.join(objdir, ".lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and is_fresh():     # another rank built it while we waited
+            return LIB
+        return _build_locked(objdir, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(objdir, verbose):
 
     def cc(src):
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
