@@ -217,6 +217,11 @@ int uav_copy_cols_f32(const float* src, int32_t src_stride, int32_t src_col, flo
  * mode 1: h <- (1-z)*h + z*q in place (out must equal h_in). */
 int uav_gru_gates_f32(const float* zr, const float* h_in, const float* q, float* out, int64_t rows,
                       int32_t c, int32_t mode, void* stream);
+/* bilinear plane resize, align_corners=False: RAFT_bi pre-resize of the frames to multiples of 8 (raft_bi.py:53,
+ * trilinear with T unchanged) and resize_flow_pytorch (raft_bi.py:11-16); row0_scale / row1_scale multiply output
+ * rows 0 and 1 (the reference's `flow[:, :, 0] *= newh/oldh; flow[:, :, 1] *= neww/oldw` indexes rows) */
+int uav_resize_bilinear_f32(const float* src, float* dst, int64_t planes, int32_t hi, int32_t wi, int32_t ho,
+                            int32_t wo, float row0_scale, float row1_scale, void* stream);
 /* 2x2 average pooling of the correlation volume [P][h][w] (corr.py:23-27) */
 int uav_avgpool2_f32(const float* src, int64_t src_stride, int32_t h, int32_t w, float* dst,
                      int64_t p_count, void* stream);

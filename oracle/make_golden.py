@@ -82,20 +82,7 @@ def main():
     pin = {"reference_root": ref_stubs.REFERENCE_ROOT, "torch": torch.__version__, "cases": {}}
 
     # ---------------- UNet ----------------------------------------------------------------------
-    unet = ns.unet_video.UNetVideoModel.from_config(dict(UNET_TINY)).eval()
-    usd = synth.synth_state_dict(unet.state_dict(), seed=1234)
-    unet.load_state_dict(usd, strict=True)
-    for name, (bsz, t, h, w) in {"unet_t4_16": (2, 4, 16, 16), "unet_t8_32": (2, 8, 32, 32)}.items():
-        sample, low, ehs, ts, cl = unet_inputs(bsz, t, h, w, UNET_TINY["cross_attention_dim"])
-        with torch.no_grad():
-            t0 = time.time()
-            ref = unet(sample, torch.tensor(ts), low, encoder_hidden_states=ehs, class_labels=cl).sample
-            t_ref = time.time() - t0
-            mine = O.unet_forward(usd, UNET_TINY, sample, ts, low, ehs, cl)
-        pin["cases"][name] = {"maxabs_oracle_vs_reference": maxabs(mine, ref), "rel_l2": rel_l2(mine, ref),
-                              "ref_absmean": ref.abs().mean().item(), "ref_seconds": t_ref}
-        torch.save(ref.half(), os.path.join(GOLD, name + ".pt"))
-        print(name, pin["cases"][name], flush=True)
+    unet, usd = make_unet_goldens(ns, pin)
 
     # ---------------- VAE (both configs) --------------------------------------------------------
     vaes = {}
@@ -180,9 +167,74 @@ def main():
         torch.save({"latents": ref_lat.half(), "images": ref_img.half()}, os.path.join(GOLD, name + ".pt"))
         print(name, pin["cases"][name], flush=True)
 
+    make_raft_goldens(ns, pin)
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
     print("wrote", GOLD)
 
 
+UNET_CASES = {  # name -> (B, T, H, W); the last one has H, W not multiples of 8 (forced-upsample-size path)
+    "unet_t4_16": (2, 4, 16, 16), "unet_t8_32": (2, 8, 32, 32), "unet_t3_20x28": (2, 3, 20, 28),
+}
+
+
+def make_unet_goldens(ns, pin):
+    unet = ns.unet_video.UNetVideoModel.from_config(dict(UNET_TINY)).eval()
+    usd = synth.synth_state_dict(unet.state_dict(), seed=1234)
+    unet.load_state_dict(usd, strict=True)
+    for name, (bsz, t, h, w) in UNET_CASES.items():
+        sample, low, ehs, ts, cl = unet_inputs(bsz, t, h, w, UNET_TINY["cross_attention_dim"])
+        with torch.no_grad():
+            t0 = time.time()
+            ref = unet(sample, torch.tensor(ts), low, encoder_hidden_states=ehs, class_labels=cl).sample
+            t_ref = time.time() - t0
+            mine = O.unet_forward(usd, UNET_TINY, sample, ts, low, ehs, cl)
+        pin["cases"][name] = {"maxabs_oracle_vs_reference": maxabs(mine, ref), "rel_l2": rel_l2(mine, ref),
+                              "ref_absmean": ref.abs().mean().item(), "ref_seconds": t_ref}
+        torch.save(ref.half(), os.path.join(GOLD, name + ".pt"))
+        print(name, pin["cases"][name], flush=True)
+    return unet, usd
+
+
+RAFT_CASES = {  # name -> (T, H, W, iters); the second one exercises the pre-resize / flow-resize path (H, W not /8)
+    "raft_bi_t3_128x160": (3, 128, 160, 4),
+    "raft_bi_t3_132x164": (3, 132, 164, 3),
+}
+
+
+def make_raft_goldens(ns, pin):
+    """Reference RAFT_bi (models_video/RAFT/raft_bi.py, unmodified) with seeded synthetic weights vs the
+    restatement; writes tests/golden/raft_bi_*.pt.  `initialize_RAFT` wants a checkpoint file, so the RAFT_bi
+    object is assembled around the reference RAFT class directly (same forward code)."""
+    import argparse
+    args = argparse.Namespace(small=False, mixed_precision=False, alternate_corr=False)
+    raft = ns.raft.RAFT(args).eval()
+    sd = synth.synth_state_dict(raft.state_dict(), seed=777)
+    raft.load_state_dict(sd, strict=True)
+    rb = ns.raft_bi.RAFT_bi.__new__(ns.raft_bi.RAFT_bi)
+    torch.nn.Module.__init__(rb)
+    rb.fix_raft = raft
+    rb.eval()
+    json.dump({k: list(v.shape) for k, v in sd.items()}, open(os.path.join(GOLD, "raft_keys.json"), "w"))
+    for name, (t, h, w, iters) in RAFT_CASES.items():
+        clip = synth.synth_clip(1, t, h, w, seed=5, motion=(2, 1))
+        with torch.no_grad():
+            rf, rbk = rb.forward(clip.clone(), iters=iters)
+            of, ob = O.raft_bi_forward(sd, clip.clone(), iters=iters)
+        key = f"{name}_iters{iters}"
+        pin["cases"][key] = {"maxabs_oracle_vs_reference": max(maxabs(of, rf), maxabs(ob, rbk)),
+                             "ref_absmean": rf.abs().mean().item()}
+        torch.save({"forward": rf.half(), "backward": rbk.half()}, os.path.join(GOLD, name + ".pt"))   # |flow| ~ 10 px: fp16 is 1e-3 relative
+        print(key, pin["cases"][key], flush=True)
+
+
+def only(section):
+    """`python oracle/make_golden.py --raft | --unet`: regenerate one section's fixtures and PINNING.json entries."""
+    torch.set_num_threads(8)
+    ns = ref_stubs.import_reference()
+    pin = json.load(open(os.path.join(GOLD, "PINNING.json")))
+    {"raft": make_raft_goldens, "unet": make_unet_goldens}[section](ns, pin)
+    json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
-    main()
+    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else main()

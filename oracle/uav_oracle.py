@@ -650,12 +650,25 @@ def raft_forward(sd, image1, image2, iters=20):
 
 
 def raft_bi_forward(sd, frames, iters=20):
-    """RAFT_bi.forward (raft_bi.py:47-68) for H, W multiples of 8 (the trilinear pre-resize and the
-    bilinear flow resize are identities then).  frames (B,3,T,H,W) -> flows fwd/bwd (B,2,T-1,H,W)."""
+    """RAFT_bi.forward (raft_bi.py:47-68).  frames (B,3,T,H,W) -> flows fwd/bwd (B,2,T-1,H,W).
+    H, W not multiples of 8: trilinear pre-resize to the next multiple (:49-53; T is unchanged, so per-frame
+    bilinear) and resize_flow_pytorch back (:11-16,:62-63) — including the reference's rescale of
+    `flow[:, :, 0]` / `flow[:, :, 1]`, which indexes ROWS 0 and 1 of both flow channels."""
     b, c, t, h, w = frames.shape
-    assert h % 8 == 0 and w % 8 == 0
-    a = frames[:, :, :-1].permute(0, 2, 1, 3, 4).reshape(b * (t - 1), c, h, w)
-    bb = frames[:, :, 1:].permute(0, 2, 1, 3, 4).reshape(b * (t - 1), c, h, w)
-    ff = raft_forward(sd, a, bb, iters).reshape(b, t - 1, 2, h, w).permute(0, 2, 1, 3, 4)
-    fb = raft_forward(sd, bb, a, iters).reshape(b, t - 1, 2, h, w).permute(0, 2, 1, 3, 4)
+    h8, w8 = -(-h // 8) * 8, -(-w // 8) * 8
+    if (h8, w8) != (h, w):
+        frames = F.interpolate(frames, (t, h8, w8), mode="trilinear")
+    a = frames[:, :, :-1].permute(0, 2, 1, 3, 4).reshape(b * (t - 1), c, h8, w8)
+    bb = frames[:, :, 1:].permute(0, 2, 1, 3, 4).reshape(b * (t - 1), c, h8, w8)
+    ff = raft_forward(sd, a, bb, iters)
+    fb = raft_forward(sd, bb, a, iters)
+    if (h8, w8) != (h, w):
+        def back(flow):
+            flow = F.interpolate(flow, (h, w), mode="bilinear")
+            flow[:, :, 0] *= h / h8
+            flow[:, :, 1] *= w / w8
+            return flow
+        ff, fb = back(ff), back(fb)
+    ff = ff.reshape(b, t - 1, 2, h, w).permute(0, 2, 1, 3, 4)
+    fb = fb.reshape(b, t - 1, 2, h, w).permute(0, 2, 1, 3, 4)
     return ff.contiguous(), fb.contiguous()

@@ -40,12 +40,33 @@ def unet_sd():
     return synth.synth_state_dict(m.state_dict(), seed=1234)
 
 
-def test_oracle_unet_vs_golden(unet_sd):
-    sample, low, ehs, ts, cl = GC.unet_inputs(2, 4, 16, 16, GC.UNET_TINY["cross_attention_dim"])
+def RAFT_model():
+    from models_video.RAFT.raft import RAFT
+    return RAFT()
+
+
+@pytest.mark.parametrize("name,shape", [("unet_t4_16", (2, 4, 16, 16)), ("unet_t3_20x28", (2, 3, 20, 28))])
+def test_oracle_unet_vs_golden(unet_sd, name, shape):
+    """The second case has H, W not multiples of 8: forced upsample size (reference unet_video.py:443-445,541-542)."""
+    sample, low, ehs, ts, cl = GC.unet_inputs(*shape, GC.UNET_TINY["cross_attention_dim"])
     with torch.no_grad():
         out = O.unet_forward(unet_sd, GC.UNET_TINY, sample, ts, low, ehs, cl)
-    gold = torch.load(os.path.join(GOLD, "unet_t4_16.pt"))
+    gold = torch.load(os.path.join(GOLD, name + ".pt"))
+    assert out.shape == gold.shape
     assert rel_l2(out, gold) < 1e-3          # fixture stored in fp16
+
+
+def test_oracle_raft_bi_resize_path_vs_golden():
+    """RAFT_bi on frames whose H, W are not multiples of 8 (pre-resize + flow resize with the reference's
+    row-indexed rescale, raft_bi.py:11-16,49-53,62-63) against the reference-generated fixture."""
+    m = RAFT_model()
+    sd = synth.synth_state_dict(m.state_dict(), seed=777)
+    clip = synth.synth_clip(1, 3, 132, 164, seed=5, motion=(2, 1))
+    with torch.no_grad():
+        ff, fb = O.raft_bi_forward(sd, clip, iters=3)
+    gold = torch.load(os.path.join(GOLD, "raft_bi_t3_132x164.pt"))
+    assert ff.shape == (1, 2, 2, 132, 164)
+    assert rel_l2(ff, gold["forward"]) < 1e-3 and rel_l2(fb, gold["backward"]) < 1e-3     # fixture stored in fp16
 
 
 @pytest.mark.parametrize("name,cfg", [("vae3d", GC.VAE3D_TINY), ("vaevideo", GC.VAEVIDEO_TINY)])

@@ -132,6 +132,45 @@ def test_raft_bi_vs_oracle_and_reference_fixture(dev):
             fh.write(json.dumps(dict(case="raft_bi_t3_128x160_iters4", rel_l2_fwd_vs_oracle=e_f, rel_l2_bwd_vs_oracle=e_b)) + "\n")
 
 
+def test_resize_bilinear_matches_interpolate(dev):
+    from uav import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 3, 4, 45, 52, generator=g)
+    ref = F.interpolate(x.reshape(2, 12, 45, 52), (48, 56), mode="bilinear")
+    out = ops.resize_bilinear_f32(x.to(dev), 48, 56)
+    assert out.shape == (2, 3, 4, 48, 56)
+    assert (out.cpu().reshape(2, 12, 48, 56) - ref).abs().max().item() < 1e-5       # fp32 both sides
+    flow = torch.randn(4, 2, 48, 56, generator=g) * 5
+    ref = F.interpolate(flow, (45, 52), mode="bilinear")
+    ref[:, :, 0] *= 45 / 48; ref[:, :, 1] *= 52 / 56                                # the reference's row-indexed rescale
+    out = ops.resize_bilinear_f32(flow.to(dev), 45, 52, row0_scale=45 / 48, row1_scale=52 / 56)
+    assert (out.cpu() - ref).abs().max().item() < 1e-4
+
+
+def test_raft_bi_non_multiple_of_8_vs_oracle_and_reference_fixture(dev):
+    """H, W not multiples of 8: pre-resize + flow resize path (reference raft_bi.py:49-53,11-16,62-63)."""
+    import synth
+    import uav_oracle as O
+    from models_video.RAFT.raft_bi import RAFT_bi
+    rb = RAFT_bi(model_path=None, device="cpu")
+    sd = synth.synth_state_dict(rb.fix_raft.state_dict(), seed=777)
+    rb.fix_raft.load_state_dict(sd)
+    rb = rb.to(dev)
+    clip = synth.synth_clip(1, 3, 132, 164, seed=5, motion=(2, 1))
+    ff, fb = rb(clip.to(dev), iters=3)
+    with torch.no_grad():
+        off, ofb = O.raft_bi_forward(sd, clip, iters=3)
+    assert ff.shape == (1, 2, 2, 132, 164) and fb.shape == ff.shape
+    e_f, e_b = rel_l2(ff, off), rel_l2(fb, ofb)
+    assert e_f < 2e-3 and e_b < 2e-3, (e_f, e_b)
+    gold = torch.load(os.path.join(GOLD, "raft_bi_t3_132x164.pt"))
+    assert rel_l2(ff, gold["forward"]) < 3e-3 and rel_l2(fb, gold["backward"]) < 3e-3
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity.jsonl"), "a") as fh:
+            fh.write(json.dumps(dict(case="raft_bi_t3_132x164_iters3", rel_l2_fwd_vs_oracle=e_f, rel_l2_bwd_vs_oracle=e_b)) + "\n")
+
+
 def test_pipeline_with_raft_flows_and_propagation(dev):
     """BASELINE config-3 style run at reduced width: RAFT_bi flows -> x0-space propagation at one
     DDIM step, engine vs oracle (both consume their OWN RAFT flows)."""

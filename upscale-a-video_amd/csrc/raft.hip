@@ -90,6 +90,30 @@ __global__ void avgpool2_kernel(const float* src, long long sstride, int h, int 
     dst[i] = 0.25f * (s[0] + s[1] + s[w] + s[w + 1]);
 }
 
+// ---- bilinear plane resize (align_corners = False) ---------------------------------------------------
+// RAFT_bi pre-resizes frames to multiples of 8 (`F.interpolate(..., mode='trilinear')` with T unchanged, i.e.
+// bilinear per frame, raft_bi.py:53) and resizes the flows back (`resize_flow_pytorch`, :11-16).  The reference
+// scales `flow[:, :, 0]` and `flow[:, :, 1]` afterwards, which indexes ROWS 0 and 1 of both channels, not the
+// channels: row0_scale / row1_scale reproduce exactly that.
+__global__ void resize_bilinear_kernel(const float* src, float* dst, long long planes, int hi, int wi, int ho, int wo,
+                                       float sy, float sx, float row0_scale, float row1_scale) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * ho * wo) return;
+    const long long pl = i / ((long long)ho * wo); const int rem = (int)(i - pl * ho * wo);
+    const int y = rem / wo, x = rem - y * wo;
+    const float fy = fmaxf(sy * ((float)y + 0.5f) - 0.5f, 0.0f), fx = fmaxf(sx * ((float)x + 0.5f) - 0.5f, 0.0f);
+    const int y0 = min((int)fy, hi - 1), x0 = min((int)fx, wi - 1);
+    const int y1 = y0 + (y0 < hi - 1), x1 = x0 + (x0 < wi - 1);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* s = src + pl * (long long)hi * wi;
+    const float top = (1.0f - lx) * s[(long long)y0 * wi + x0] + lx * s[(long long)y0 * wi + x1];
+    const float bot = (1.0f - lx) * s[(long long)y1 * wi + x0] + lx * s[(long long)y1 * wi + x1];
+    float v = (1.0f - ly) * top + ly * bot;
+    if (y == 0) v *= row0_scale;
+    if (y == 1) v *= row1_scale;
+    dst[i] = v;
+}
+
 struct LookupArgs {
     const float* lvl[4]; long long stride[4]; int h[4], w[4];
     const float* coords; int coord_stride;       // rows [P][coord_stride]: x, y
@@ -189,6 +213,13 @@ extern "C" int uav_gru_gates_f32(const float* zr, const float* h_in, const float
         if (!q || out != h_in) return UAV_EINVAL;
         hipLaunchKernelGGL(gru_blend_kernel, dim3(nb(rows * c)), dim3(256), 0, s, zr, q, out, (long long)rows, c);
     }
+    return uav_launch_status();
+}
+extern "C" int uav_resize_bilinear_f32(const float* src, float* dst, int64_t planes, int32_t hi, int32_t wi, int32_t ho,
+                                       int32_t wo, float row0_scale, float row1_scale, void* stream) {
+    if (!src || !dst || planes <= 0 || hi <= 0 || wi <= 0 || ho <= 0 || wo <= 0) return UAV_EINVAL;
+    hipLaunchKernelGGL(resize_bilinear_kernel, dim3(nb(planes * ho * wo)), dim3(256), 0, (hipStream_t)stream, src, dst,
+                       (long long)planes, hi, wi, ho, wo, (float)hi / (float)ho, (float)wi / (float)wo, row0_scale, row1_scale);
     return uav_launch_status();
 }
 extern "C" int uav_avgpool2_f32(const float* src, int64_t src_stride, int32_t h, int32_t w, float* dst, int64_t p_count,

@@ -1,11 +1,13 @@
 """RAFT_bi — bidirectional RAFT optical flow for the flow-guided propagation (drop-in for the
 reference's `models_video/RAFT/raft_bi.py`: initialize_RAFT :19-33, RAFT_bi.forward :47-68,
 forward_slicing :71-104).  fp32, like the reference.  The trilinear pre-resize / bilinear flow
-resize of the reference (:53,:62-63) are identities when H and W are multiples of 8, which is the
-only case built so far.
+resize of the reference (:53,:62-63) run on `uav_resize_bilinear_f32` when H or W is not a multiple
+of 8 (they are identities otherwise and skipped).
 """
 import torch
 import torch.nn as nn
+
+from uav import ops
 
 from .raft import RAFT
 
@@ -38,11 +40,18 @@ class RAFT_bi(nn.Module):
 
     def forward(self, gt_local_frames, iters=20):
         b, c, t, h, w = gt_local_frames.size()
-        if h % 8 or w % 8:
-            raise NotImplementedError("H, W not multiples of 8: the reference's trilinear pre-resize is not built yet")
+        h8, w8 = -(-h // 8) * 8, -(-w // 8) * 8
+        frames = gt_local_frames
+        if (h8, w8) != (h, w):
+            # reference :53 — trilinear to (T, H_, W_); T is unchanged, so it is a per-frame bilinear resize
+            frames = ops.resize_bilinear_f32(frames.float(), h8, w8)
         ff, fb = [], []
         for i in range(b):
-            f, bwd = self.fix_raft.flows_bidirectional(gt_local_frames[i].permute(1, 0, 2, 3).contiguous(), iters=iters)
+            f, bwd = self.fix_raft.flows_bidirectional(frames[i].permute(1, 0, 2, 3).contiguous(), iters=iters)
+            if (h8, w8) != (h, w):
+                # resize_flow_pytorch (:11-16), including its row-indexed rescale (`flow[:, :, 0] *= newh/oldh`)
+                f = ops.resize_bilinear_f32(f, h, w, row0_scale=h / h8, row1_scale=w / w8)
+                bwd = ops.resize_bilinear_f32(bwd, h, w, row0_scale=h / h8, row1_scale=w / w8)
             ff.append(f.permute(1, 0, 2, 3)); fb.append(bwd.permute(1, 0, 2, 3))
         return torch.stack(ff).contiguous(), torch.stack(fb).contiguous()
 

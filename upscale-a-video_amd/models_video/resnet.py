@@ -80,10 +80,31 @@ class Upsample3D(E.EngineModule):
             self.Conv2d_0 = conv
 
     def run(self, x, g: E.Geom, output_size=None):
-        if output_size is not None and tuple(output_size[-2:]) != (2 * g.h, 2 * g.w):
-            raise NotImplementedError("forced upsample size (H,W not multiples of 8) is not supported yet")
         conv = self.conv if self.name == "conv" else self.Conv2d_0
-        return conv.run(x, g, upsample=True), g.with_hw(2 * g.h, 2 * g.w)
+        if output_size is None or tuple(output_size[-2:]) == (2 * g.h, 2 * g.w):
+            return conv.run(x, g, upsample=True), g.with_hw(2 * g.h, 2 * g.w)
+        # Forced size (reference resnet.py:147-150, used when H, W are not multiples of 2^num_upsamplers,
+        # unet_video.py:443-445,541-542): F.interpolate(size=..., mode="nearest"), i.e. src = floor(dst * in / out)
+        # in fp32.  Rare path (odd intermediate sizes): the resized rows are materialised by an index gather and
+        # the 3x3 conv then runs on the target geometry.
+        ho, wo = int(output_size[-2]), int(output_size[-1])
+        idx = self._nearest_rows(g, ho, wo, x.device)
+        g2 = g.with_hw(ho, wo)
+        return conv.run(x.index_select(0, idx), g2), g2
+
+    def _nearest_rows(self, g, ho, wo, device):
+        key = (g.n_img, g.h, g.w, ho, wo, str(device))
+        cache = self.__dict__.setdefault("_nearest_cache", {})
+        if key not in cache:
+            def src(n_in, n_out):
+                scale = torch.tensor(n_in / n_out, dtype=torch.float32)
+                return torch.clamp((torch.arange(n_out, dtype=torch.float32) * scale).floor().long(), max=n_in - 1)
+            ys, xs = src(g.h, ho), src(g.w, wo)
+            per_img = (ys[:, None] * g.w + xs[None, :]).reshape(-1)
+            idx = (torch.arange(g.n_img)[:, None] * (g.h * g.w) + per_img[None, :]).reshape(-1)
+            cache.clear()
+            cache[key] = idx.to(device)
+        return cache[key]
 
     def forward(self, hidden_states, output_size=None):
         rows, g = E.to_rows(hidden_states, c_pad=self.channels)

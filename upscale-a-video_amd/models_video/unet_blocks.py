@@ -123,6 +123,18 @@ class DownBlock3D(nn.Module):
         return x, g, outs
 
 
+def _target_size(skips, upsample_size):
+    """Size the upsampler must produce: the next skip connection's (reference `upsample_size =
+    down_block_res_samples[-1].shape[2:]`, unet_video.py:541-542).  Equal to 2x unless H or W is not a multiple of
+    2^num_upsamplers, where the stride-2 convs rounded up on the way down."""
+    if upsample_size is not None:
+        return upsample_size
+    if skips:
+        gs = skips[-1][1]
+        return (gs.h, gs.w)
+    return None
+
+
 class CrossAttnUpBlock3D(nn.Module):
     def __init__(self, in_channels, out_channels, prev_output_channel, temb_channels, dropout=0.0, num_layers=1,
                  resnet_eps=1e-6, resnet_time_scale_shift="default", resnet_act_fn="swish", resnet_groups=32,
@@ -153,7 +165,7 @@ class CrossAttnUpBlock3D(nn.Module):
             x = resnet.run(x, g, temb, x2=skip)              # cat([hidden, skip], C) without the cat
             x = attn.run(x, g, ehs_rows, n_text)
         if self.upsamplers is not None:
-            x, g = self.upsamplers[0].run(x, g, upsample_size)
+            x, g = self.upsamplers[0].run(x, g, _target_size(skips, upsample_size))
         return x, g
 
 
@@ -178,7 +190,7 @@ class UpBlock3D(nn.Module):
             skip, _ = skips.pop()
             x = resnet.run(x, g, temb, x2=skip)
         if self.upsamplers is not None:
-            x, g = self.upsamplers[0].run(x, g, upsample_size)
+            x, g = self.upsamplers[0].run(x, g, _target_size(skips, upsample_size))
         return x, g
 
 

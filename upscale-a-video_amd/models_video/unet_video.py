@@ -200,9 +200,6 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
             raise NotImplementedError("attention_mask is never passed by the pipeline")
         if sample.shape[1] + low_res.shape[1] != self.config.in_channels:
             raise ValueError(f"expected {self.config.in_channels} input channels, got {sample.shape[1]}+{low_res.shape[1]}")
-        up_factor = 2 ** self.num_upsamplers
-        if any(s % up_factor != 0 for s in sample.shape[-2:]):
-            raise NotImplementedError(f"H and W must be multiples of {up_factor} (forced-upsample-size path not built yet)")
         dev = sample.device
         if self.config.center_input_sample:
             sample = 2 * sample - 1.0

@@ -62,6 +62,7 @@ SIGNATURES = {
     "uav_copy_cols_f32": (C.c_int, [c_p, i32, i32, c_p, i32, i32, i32, i64, i32, c_p]),
     "uav_gru_gates_f32": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, i32, c_p]),
     "uav_avgpool2_f32": (C.c_int, [c_p, i64, i32, i32, c_p, i64, c_p]),
+    "uav_resize_bilinear_f32": (C.c_int, [c_p, c_p, i64, i32, i32, i32, i32, C.c_float, C.c_float, c_p]),
     "uav_corr_lookup_f32": (C.c_int, [C.POINTER(c_p), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), c_p, i32, c_p, i32, i64, i32, c_p]),
     "uav_convex_upsample_f32": (C.c_int, [c_p, i32, c_p, c_p, i32, i32, i32, c_p]),
     "uav_propagate_step_f16": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i64, i64, i32, i32, f32, f32, f32, c_p]),

@@ -528,6 +528,18 @@ def gru_blend_f32(zr, q, h):
     return h
 
 
+def resize_bilinear_f32(x, ho, wo, row0_scale=1.0, row1_scale=1.0):
+    """x (..., hi, wi) fp32 contiguous -> (..., ho, wo), bilinear, align_corners=False (F.interpolate semantics)."""
+    lib = _lib.load()
+    x = _req(x.contiguous(), F32, "x")
+    hi, wi = x.shape[-2:]
+    planes = x.numel() // (hi * wi)
+    out = torch.empty(tuple(x.shape[:-2]) + (ho, wo), dtype=F32, device=x.device)
+    _lib.check(lib.uav_resize_bilinear_f32(_p(x), _p(out), planes, hi, wi, ho, wo, float(row0_scale), float(row1_scale),
+                                           _stream()), "uav_resize_bilinear_f32")
+    return out
+
+
 def avgpool2_f32(src, src_stride, h, w, p_count):
     lib = _lib.load()
     dst = torch.empty((p_count, (h // 2) * (w // 2)), dtype=F32, device=src.device)
