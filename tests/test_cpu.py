@@ -299,7 +299,35 @@ def _dist_worker(rank, world, port, q):
     elapsed = D.max_over_ranks(1.0 + r)
     total = D.sum_over_ranks(len(mine))
     gathered = D.gather_to_rank0(mine)
-    q.put((r, mine, elapsed, total, gathered))
+    # --- one long clip over the ranks (BASELINE config 4): windows of a DDIM step + decode chunks via sharded_map ---
+    from models_video.pipeline_upscale_a_video import window_schedule
+    t_total = 32
+    wins = window_schedule(t_total)
+    uniq = [w_ for k, w_ in enumerate(wins) if w_ not in wins[:k]]
+    g = torch.Generator().manual_seed(3)
+    lat = torch.randn(2, 4, t_total, 6, 5, generator=g)
+    calls = []
+
+    def fake_unet(se):                       # stands in for UNetVideoModel on one 8-frame window (CPU)
+        calls.append(se)
+        x = lat[:, :, se[0]:se[1]]
+        return torch.tanh(x * 1.7 + x.mean(dim=2, keepdim=True)) * (1 + 0.01 * se[0])
+
+    def blend(outs):                         # the running 0.5/0.5 overlap blend of pipeline_upscale_a_video.py
+        eps, written = torch.zeros_like(lat), [False] * t_total
+        for (s_, e_) in wins:
+            o = outs[(s_, e_)]
+            for k, idx in enumerate(range(s_, e_)):
+                eps[:, :, idx] = o[:, :, k] if not written[idx] else 0.5 * eps[:, :, idx] + 0.5 * o[:, :, k]
+                written[idx] = True
+        return eps
+    sharded = blend(dict(zip(uniq, D.sharded_map(uniq, fake_unet))))
+    n_local = len(calls)
+    serial = blend({w_: fake_unet(w_) for w_ in uniq})
+    chunks = D.sharded_map(list(range(0, t_total, 3)), lambda s_: torch.full((1, 3, 3, 2, 2), float(s_)))
+    single = D.sharded_map([5], lambda s_: torch.full((2,), float(s_)))          # one item: no collective
+    q.put((r, mine, elapsed, total, gathered, torch.equal(sharded, serial), n_local, len(uniq),
+           [float(c.flatten()[0]) for c in chunks], float(single[0][0])))
     D.finalize()
 
 
@@ -315,7 +343,12 @@ def test_dist_gloo_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, m0, e0, t0, g0), (r1, m1, e1, t1, g1) = res
+    (r0, m0, e0, t0, g0, *x0), (r1, m1, e1, t1, g1, *x1) = res
     assert m0 == [0, 2, 4, 6] and m1 == [1, 3, 5]
     assert e0 == e1 == 2.0 and t0 == t1 == 7.0
     assert g0 == [[0, 2, 4, 6], [1, 3, 5]] and g1 is None
+    # window-sharded long clip: bit-identical to the serial schedule on BOTH ranks, each rank ran only its share
+    for x in (x0, x1):
+        same, n_local, n_uniq, chunk_ids, single = x
+        assert same and n_uniq == 5 and chunk_ids == [float(s) for s in range(0, 32, 3)] and single == 5.0
+    assert x0[1] == 3 and x1[1] == 2           # 5 unique windows dealt 3 / 2

@@ -26,6 +26,7 @@ from typing import List, Optional, Union
 
 import torch
 
+from uav import dist as D
 from uav import ops
 
 from ._compat import BaseOutput, ConfigMixin
@@ -72,6 +73,9 @@ class VideoUpscalePipeline(ConfigMixin):
         # under classifier-free guidance both UNet batch entries see identical latents / low_res / timestep, so the
         # text-independent head of the UNet is computed once (UNetVideoModel.forward cfg_shared_input; bit-identical)
         self.cfg_shared_input = True
+        # one LONG clip over several GPUs (BASELINE config 4): deal the temporal windows of each DDIM step and the decode
+        # chunks over the ranks of the default process group; results are bit-identical to the single-GPU call
+        self.shard_windows = False
 
     def register_modules(self, **kwargs):
         for k, v in kwargs.items():
@@ -253,13 +257,18 @@ class VideoUpscalePipeline(ConfigMixin):
             if len(wins) > 1:
                 eps = None
                 written = [False] * t_total
-                prev_win, o = None, None
+                # the windows of one step are independent UNet evaluations: with `shard_windows` and an initialised
+                # process group they are dealt over the ranks and all-gathered (uav/dist.py:sharded_map); the blend
+                # below is replayed identically on every rank.  A duplicate tail window is evaluated once.
+                uniq = [w for k, w in enumerate(wins) if w not in wins[:k]]
+
+                def eval_window(se):
+                    return self.unet(lin[:, :, se[0]:se[1]].contiguous(), t, image[:, :, se[0]:se[1]].contiguous(),
+                                     encoder_hidden_states=prompt_embeds, class_labels=level,
+                                     cfg_shared_input=do_cfg and self.cfg_shared_input).sample.contiguous()
+                outs = dict(zip(uniq, D.sharded_map(uniq, eval_window) if self.shard_windows else map(eval_window, uniq)))
                 for (s, e) in wins:
-                    if (s, e) != prev_win:                                        # duplicate tail window: reuse `o`
-                        o = self.unet(lin[:, :, s:e].contiguous(), t, image[:, :, s:e].contiguous(),
-                                      encoder_hidden_states=prompt_embeds, class_labels=level,
-                                      cfg_shared_input=do_cfg and self.cfg_shared_input).sample
-                    prev_win = (s, e)
+                    o = outs[(s, e)]
                     if eps is None:
                         eps = torch.empty((o.shape[0], o.shape[1], t_total) + tuple(o.shape[3:]), dtype=o.dtype, device=device)
                     for k, idx in enumerate(range(s, e)):
@@ -285,10 +294,16 @@ class VideoUpscalePipeline(ConfigMixin):
         # 11. decode in chunks of 3 frames on the GLOBAL frame index (:685-702)
         short_seq = 3
         if t_total > short_seq:
-            chunks = [self.decode_latents_vsr(latents[:, :, s:min(t_total, s + short_seq)].contiguous(),
-                                              image_dec[:, :, s:min(t_total, s + short_seq)].contiguous(), w_lr)
-                      for s in range(0, t_total, short_seq)]
-            out = torch.cat(chunks, dim=2)
+            starts = list(range(0, t_total, short_seq))
+
+            def decode_chunk(s):
+                e = min(t_total, s + short_seq)
+                y = self.decode_latents_vsr(latents[:, :, s:e].contiguous(), image_dec[:, :, s:e].contiguous(), w_lr)
+                if self.shard_windows and e - s < short_seq:      # ragged last chunk: pad to a common shape for the gather
+                    y = torch.cat([y, y.new_zeros(y.shape[:2] + (short_seq - (e - s),) + y.shape[3:])], dim=2)
+                return y.contiguous()
+            chunks = D.sharded_map(starts, decode_chunk) if self.shard_windows else [decode_chunk(s) for s in starts]
+            out = torch.cat(chunks, dim=2)[:, :, :t_total]
         else:
             out = self.decode_latents_vsr(latents, image_dec, w_lr)
         if not return_dict:

@@ -32,6 +32,39 @@ def shard(items, rank, world):
     return [it for i, it in enumerate(items) if i % world == rank]
 
 
+def sharded_map(items, fn, group=None):
+    """Evaluate `fn(item) -> tensor` for every item with the items dealt round-robin over the ranks, then
+    all-gather: every rank returns the full list, in item order, bit-identical to the unsharded evaluation.
+
+    This is how ONE long clip is spread over GPUs (BASELINE config 4): the temporal windows of a DDIM step are
+    independent UNet evaluations — the only coupling is the epsilon blend on the overlap frames, which
+    every rank then replays on the gathered outputs — and so are the 3-frame VAE decode chunks.  All results of one
+    call must share shape and dtype (windows are all 8 frames; the ragged last decode chunk is padded by the
+    caller).  One all_gather of (ceil(n/world), *shape) per call; RCCL over xGMI
+    when the backend is nccl."""
+    items = list(items)
+    if not dist.is_initialized() or dist.get_world_size(group) == 1 or len(items) <= 1:
+        return [fn(it) for it in items]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    mine = [fn(it) for it in items[rank::world]]
+    per_rank = -(-len(items) // world)
+    # the result shape is known to every rank that owns an item; rank 0 always does (more ranks than items is allowed)
+    shape_dtype = [(tuple(mine[0].shape), mine[0].dtype) if mine else None]
+    dist.broadcast_object_list(shape_dtype, src=0, group=group)
+    shape, dtype = shape_dtype[0]
+    device = mine[0].device if mine else _default_device()
+    buf = torch.zeros((per_rank,) + shape, dtype=dtype, device=device)
+    for i, t in enumerate(mine):
+        buf[i] = t
+    gathered = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(gathered, buf, group=group)
+    return [gathered[i % world][i // world] for i in range(len(items))]
+
+
+def _default_device():
+    return torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+
+
 def barrier(device=None):
     if dist.is_initialized():
         dist.barrier()
