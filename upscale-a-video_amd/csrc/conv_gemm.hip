@@ -90,10 +90,158 @@ UAV_DEVINL float2_t unpack_h2(uint32_t u) {
     return float2_t{(float)h[0], (float)h[1]};
 }
 
+// Fast paths: the whole wave tile lies inside M and N, fp16 output, 16-B aligned rows, one time-embedding row for the
+// tile.  No predicates and no flag tests inside -> ONE basic block, so the scheduler issues every bias / residual load
+// up front instead of load -> wait -> store per 16-B piece (the generic path below has ~130 s_waitcnt and ~270 branches;
+// on the K = 512 linears the epilogue was 35-40 % of the kernel time, `tools/ab_conv.sh` DBG=6).  Same arithmetic
+// order as the generic path: ((acc + bias) + rowbias) + residual, then * out_scale.
+template <int NI, int MI, bool RES, bool BIAS, bool RB>
+UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32,
+                                   const float* rbrow) {
+    char* orow[MI];
+    const char* rrow[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const long long m = mw0 + mi * 32 + l32;
+        orow[mi] = p.out + (m * p.out_stride + nw0 + 8 * hi32) * 2;
+        rrow[mi] = RES ? p.residual + (m * p.res_stride + nw0 + 8 * hi32) * 2 : nullptr;
+    }
+    const float* bptr = BIAS ? p.bias + nw0 + 4 * hi32 : nullptr;
+    const float* rptr = RB ? rbrow + nw0 + 4 * hi32 : nullptr;
+    const float osc = p.out_scale;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        float4_t bq[4], rq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (BIAS) bq[g] = *(const float4_t*)(bptr + ni * 32 + 8 * g);
+            if (RB) rq[g] = *(const float4_t*)(rptr + ni * 32 + 8 * g);
+        }
+        uint4_t R[MI][2];
+        if (RES) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) R[mi][gp] = *(const uint4_t*)(rrow[mi] + (ni * 32 + 16 * gp) * 2);
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                uint32_t Rr[4] = {0, 0, 0, 0};
+                if (RES) {
+                    Rr[0] = R[mi][gp][0]; Rr[1] = R[mi][gp][1]; Rr[2] = R[mi][gp][2]; Rr[3] = R[mi][gp][3];
+                    swap_pair(Rr[0], Rr[2]); swap_pair(Rr[1], Rr[3]);     // -> Rr[0..1]: quad 2gp, Rr[2..3]: quad 2gp+1
+                }
+                uint32_t A[2], B[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int g = 2 * gp + q;
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
+                    if (BIAS) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += bq[g][j];
+                    }
+                    if (RB) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += rq[g][j];
+                    }
+                    if (RES) {
+                        float2_t r0 = unpack_h2(Rr[2 * q]), r1 = unpack_h2(Rr[2 * q + 1]);
+                        v[0] += r0[0]; v[1] += r0[1]; v[2] += r1[0]; v[3] += r1[1];
+                    }
+                    uint32_t* d = q == 0 ? A : B;
+                    d[0] = pack_h2(v[0] * osc, v[1] * osc);
+                    d[1] = pack_h2(v[2] * osc, v[3] * osc);
+                }
+                swap_pair(A[0], B[0]); swap_pair(A[1], B[1]);
+                uint4_t o = {A[0], A[1], B[0], B[1]};
+                *(uint4_t*)(orow[mi] + (ni * 32 + 16 * gp) * 2) = o;
+            }
+    }
+}
+
+// GEGLU fast path (same preconditions; no residual / rowbias by contract): value/gate tile pairs (2b, 2b+1).
+template <int NI, int MI, bool BIAS>
+UAV_DEVINL void conv_epilogue_geglu_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32) {
+    const float osc = p.out_scale;
+#pragma unroll
+    for (int blk = 0; blk < NI / 2; ++blk) {
+        const int nb = nw0 + blk * 64;
+        float4_t bv[4], bg[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (BIAS) {
+                bv[g] = *(const float4_t*)(p.bias + nb + 8 * g + 4 * hi32);
+                bg[g] = *(const float4_t*)(p.bias + nb + 32 + 8 * g + 4 * hi32);
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const long long m = mw0 + mi * 32 + l32;
+            char* orow = p.out + (m * p.out_stride + (nb >> 1) + 8 * hi32) * 2;
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                uint32_t A[2], B[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int g = 2 * gp + q;
+                    float o[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float hv = acc[2 * blk][mi][4 * g + j], gv = acc[2 * blk + 1][mi][4 * g + j];
+                        if (BIAS) { hv += bv[g][j]; gv += bg[g][j]; }
+                        o[j] = hv * uav_gelu_erf(gv) * osc;
+                    }
+                    uint32_t* d = q == 0 ? A : B;
+                    d[0] = pack_h2(o[0], o[1]); d[1] = pack_h2(o[2], o[3]);
+                }
+                swap_pair(A[0], B[0]); swap_pair(A[1], B[1]);
+                uint4_t v = {A[0], A[1], B[0], B[1]};
+                *(uint4_t*)(orow + 16 * gp * 2) = v;
+            }
+        }
+    }
+}
+
 template <int NI, int MI>
 UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32) {
     const bool geglu = p.flags & UAV_CONV_GEGLU;
     const bool of32 = p.flags & UAV_CONV_OUT_F32;
+    // wave-uniform fast-path test
+    if (!of32 && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n && !(p.out_stride & 7) &&
+        (!p.residual || !(p.res_stride & 7))) {
+        if (geglu) {
+            if (p.bias) conv_epilogue_geglu_fast<NI, MI, true>(p, acc, mw0, nw0, l32, hi32);
+            else conv_epilogue_geglu_fast<NI, MI, false>(p, acc, mw0, nw0, l32, hi32);
+            return;
+        }
+        const float* rbrow = nullptr;
+        bool uniform = true;
+        if (p.rowbias) {
+            const int b0 = (int)(mw0 / p.rows_per_batch), b1 = (int)((mw0 + MI * 32 - 1) / p.rows_per_batch);
+            uniform = b0 == b1;
+            rbrow = p.rowbias + (long long)b0 * p.rowbias_stride;
+        }
+        if (uniform) {
+#define UAV_EPI(RES, BIAS, RB) conv_epilogue_fast<NI, MI, RES, BIAS, RB>(p, acc, mw0, nw0, l32, hi32, rbrow)
+            const int sel = (p.residual ? 4 : 0) | (p.bias ? 2 : 0) | (rbrow ? 1 : 0);
+            switch (sel) {
+                case 0: UAV_EPI(false, false, false); break;
+                case 1: UAV_EPI(false, false, true); break;
+                case 2: UAV_EPI(false, true, false); break;
+                case 3: UAV_EPI(false, true, true); break;
+                case 4: UAV_EPI(true, false, false); break;
+                case 5: UAV_EPI(true, false, true); break;
+                case 6: UAV_EPI(true, true, false); break;
+                default: UAV_EPI(true, true, true); break;
+            }
+#undef UAV_EPI
+            return;
+        }
+    }
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const long long m = mw0 + mi * 32 + l32;
@@ -476,7 +624,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
 
     ISSUE_STAGE(0)
     int cur = 0;
-    if constexpr (DBG == 0) {
+    if constexpr (DBG == 0 || DBG == 6) {
         // Production k-loop: the 24 ds_read_b128 + 32 MFMA of one k-step are one hand-scheduled asm block.  The
         // compiler's own waitcnt insertion put `s_waitcnt lgkmcnt(0)` in front of every MFMA group (it does not
         // count LDS reads past an LDS-DMA), which exposed the LDS latency twice per k-step; here each MFMA waits
@@ -559,6 +707,17 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
 #undef MFMA_SET
 #undef ISSUE_STAGE
 
+    if constexpr (DBG == 6) {          // ablation: no epilogue (one dword per lane keeps the accumulators alive)
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+        if (sum == 12345.678f) *(float*)p.out = sum;
+        return;
+    }
     conv_epilogue<4, 2>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);
 }
 
@@ -620,12 +779,14 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
             (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
             (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
             (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
+            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
         }
         if (dbg == 1) hipLaunchKernelGGL(conv_gemm256_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 2) hipLaunchKernelGGL(conv_gemm256_kernel<2>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 4) hipLaunchKernelGGL(conv_gemm256_kernel<4>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 3) hipLaunchKernelGGL(conv_gemm256_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 5) hipLaunchKernelGGL(conv_gemm256_kernel<5>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+        else if (dbg == 6) hipLaunchKernelGGL(conv_gemm256_kernel<6>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else hipLaunchKernelGGL(conv_gemm256_kernel<0>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
     } else if (small)
         hipLaunchKernelGGL(conv_gemm_kernel<1>, dim3((unsigned)grid), dim3(256), 2 * STAGE_BYTES, s, a);
