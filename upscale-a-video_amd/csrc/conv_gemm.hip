@@ -42,7 +42,7 @@ struct ConvArgs {
     int n, n_pad, k_pad; float out_scale; unsigned flags;
     const char* zero_page;
     long long M;
-    int korder;
+    int korder, tile_order;
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -521,7 +521,20 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
 
     const unsigned n_tiles = p.n_pad / LN;
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    const unsigned mt = bid / n_tiles, nt = bid - mt * n_tiles;
+    unsigned mt = bid / n_tiles;
+    const unsigned nt = bid - mt * n_tiles;
+    // Temporal (k,1,1) / 3x3x3 convs: output frame t reads input frames t-k/2..t+k/2 at the SAME pixels, so the tiles
+    // of one spatial position are made neighbours in launch order (frame index fastest): the k re-reads of an input
+    // tile then come from workgroups that run together on one XCD and hit its L2 instead of the fabric.
+    if (p.kt > 1 && p.tile_order) {
+        const unsigned hw = (unsigned)(p.ho * p.wo);
+        if (hw % LM == 0) {
+            const unsigned S = hw / LM, per_clip = S * (unsigned)p.t_len;
+            const unsigned c = mt / per_clip, r = mt - c * per_clip;
+            const unsigned sp = r / (unsigned)p.t_len, t = r - sp * (unsigned)p.t_len;
+            mt = c * per_clip + t * S + sp;
+        }
+    }
     const long long m0 = (long long)mt * LM;
     const int n0 = nt * LN;
 
@@ -759,6 +772,9 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     static int korder = -1;
     if (korder < 0) { const char* e = getenv("UAV_CONV_KORDER"); korder = e ? atoi(e) : 1; }
     a.korder = korder;
+    static int tile_order = -1;
+    if (tile_order < 0) { const char* e = getenv("UAV_CONV_TILE_ORDER"); tile_order = e ? atoi(e) : 1; }
+    a.tile_order = tile_order;
     const long long mtiles = (a.M + BM - 1) / BM;
     const long long grid = mtiles * (q->n_pad / BN);
     if (grid >= (1ll << 31)) return UAV_ESHAPE;
