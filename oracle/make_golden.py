@@ -168,6 +168,7 @@ def main():
         print(name, pin["cases"][name], flush=True)
 
     make_raft_goldens(ns, pin)
+    make_tile_goldens()
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
     print("wrote", GOLD)
 
@@ -236,14 +237,75 @@ def make_raft_goldens(ns, pin):
         print(key, pin["cases"][key], flush=True)
 
 
+TILE_CASES = [(540, 960, 256), (540, 960, 320), (384, 384, 256), (400, 700, 256), (720, 1280, 320), (300, 320, 256),
+              (384, 600, 320), (448, 1000, 384)]
+
+
+def make_tile_goldens(ns=None, pin=None):
+    """Executes the reference CLI's OWN tile loop (inference_upscale_a_video.py, the `if args.perform_tile:` block,
+    read from /root/reference at run time, never copied) around a recording stand-in for `pipeline`, and stores the
+    boxes it used: padded input box, output box and crop origin per tile -> tests/golden/cli_tiles.json."""
+    import math
+    import textwrap
+    import types
+    src = open(os.path.join(ref_stubs.REFERENCE_ROOT, "inference_upscale_a_video.py")).read().split("\n")
+    start = next(i for i, l in enumerate(src) if l.strip() == "if args.perform_tile:" and "start_time" in src[i - 1])
+    indent = len(src[start]) - len(src[start].lstrip())
+    end = next(i for i in range(start + 1, len(src)) if src[i].strip() == "else:" and len(src[i]) - len(src[i].lstrip()) == indent)
+    body = textwrap.dedent("\n".join(src[start + 1:end]))
+    cases = {}
+    for (h, w, tile) in TILE_CASES:
+        calls = []
+
+        def pipeline(prompt, image=None, **kw):
+            k = len(calls)
+            th, tw = image.shape[-2:]
+            yy = torch.arange(4 * th, dtype=torch.float64)[:, None]; xx = torch.arange(4 * tw, dtype=torch.float64)[None, :]
+            img = (k * 1e8 + yy * 1e4 + xx).expand(1, 1, 1, 4 * th, 4 * tw).clone()
+            calls.append((th, tw))
+            return types.SimpleNamespace(images=img)
+        vframes = torch.zeros(1, 1, 1, h, w, dtype=torch.float64)
+        # mark every LR pixel with its coordinates so the padded input box can be read back from what the loop slices
+        coords = torch.arange(h, dtype=torch.float64)[:, None] * 1e4 + torch.arange(w, dtype=torch.float64)[None, :]
+        vframes[0, 0, 0] = coords
+        seen = []
+        real_pipeline = pipeline
+
+        def pipeline_rec(prompt, image=None, **kw):
+            seen.append((int(image[0, 0, 0, 0, 0] // 1e4), int(image[0, 0, 0, 0, 0] % 1e4), image.shape[-2], image.shape[-1]))
+            return real_pipeline(prompt, image=image, **kw)
+        env = dict(args=types.SimpleNamespace(tile_size=tile, inference_steps=1, guidance_scale=1.0, noise_level=1, n_prompt="",
+                                              propagation_steps=[]), vframes=vframes, b=1, c=1, t=1, h=h, w=w, math=math,
+                   torch=torch, pipeline=pipeline_rec, flows_bi=None, prompt="", generator=None, index_str="")
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):
+            exec(body, env)
+        out = env["output"][0, 0, 0]
+        ids = (out // 1e8).long()
+        tiles = []
+        for k, (y0p, x0p, th, tw) in enumerate(seen):
+            ys, xs = torch.nonzero(ids == k, as_tuple=True)
+            if k == 0:                       # tile 0 shares id 0 with "never written": every pixel must be written
+                assert int((out == 0).sum()) <= 1
+            dy0, dy1, dx0, dx1 = int(ys.min()), int(ys.max()) + 1, int(xs.min()), int(xs.max()) + 1
+            assert int((ids[dy0:dy1, dx0:dx1] == k).all())
+            v = out[dy0, dx0] - k * 1e8
+            cy0, cx0 = int(v // 1e4), int(v % 1e4)
+            tiles.append({"src": [y0p, y0p + th, x0p, x0p + tw], "dst": [dy0, dy1, dx0, dx1],
+                          "crop": [cy0, cy0 + dy1 - dy0, cx0, cx0 + dx1 - dx0]})
+        cases[f"{h}x{w}_tile{tile}"] = tiles
+        print(f"tiles {h}x{w} tile {tile}: {len(tiles)} tiles", flush=True)
+    json.dump(cases, open(os.path.join(GOLD, "cli_tiles.json"), "w"))
+
+
 def only(section):
     """`python oracle/make_golden.py --raft | --unet`: regenerate one section's fixtures and PINNING.json entries."""
     torch.set_num_threads(8)
     ns = ref_stubs.import_reference()
     pin = json.load(open(os.path.join(GOLD, "PINNING.json")))
-    {"raft": make_raft_goldens, "unet": make_unet_goldens}[section](ns, pin)
+    {"raft": make_raft_goldens, "unet": make_unet_goldens, "tiles": make_tile_goldens}[section](ns, pin)
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
-    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else main()
+    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else only("tiles") if "--tiles" in sys.argv else main()

@@ -287,6 +287,74 @@ def test_relative_position_bucket_table():
 
 
 # ---------------------------------------------------------------------------------------------
+# 4b. spatial tiling (the reference CLI's tile loop as a work list)
+def test_tile_grid_matches_reference_cli_loop():
+    """tests/golden/cli_tiles.json was produced by EXECUTING the reference's own tile loop
+    (inference_upscale_a_video.py:207-303) around a recording pipeline (oracle/make_golden.py --tiles)."""
+    from uav import tiling
+    gold = json.load(open(os.path.join(GOLD, "cli_tiles.json")))
+    assert len(gold) >= 8
+    for key, ref in gold.items():
+        hw, tile = key.split("_tile")
+        h, w = map(int, hw.split("x"))
+        mine = tiling.tile_grid(h, w, int(tile))
+        assert [list(t.src) for t in mine] == [r["src"] for r in ref], key
+        assert [list(t.dst) for t in mine] == [r["dst"] for r in ref], key
+        assert [list(t.crop) for t in mine] == [r["crop"] for r in ref], key
+        # the output boxes tile the 4x canvas exactly once
+        cover = torch.zeros(4 * h, 4 * w, dtype=torch.int32)
+        for t in mine:
+            cover[t.dst[0]:t.dst[1], t.dst[2]:t.dst[3]] += 1
+        assert int(cover.min()) == 1 and int(cover.max()) == 1
+    assert tiling.needs_tiling(384, 384) and not tiling.needs_tiling(320, 320) and tiling.needs_tiling(64, 64, True)
+
+
+class _FakeTilePipeline:
+    """CPU stand-in with the pipeline's draw order: LR noise, then latents, from the shared generator."""
+
+    class _Cfg:
+        latent_channels = 4
+
+    def __init__(self):
+        self.vae = type("V", (), {"config": self._Cfg})()
+        self.text_encoder = type("T", (), {"dtype": torch.float32})()
+
+    def __call__(self, prompt, image=None, flows_bi=None, generator=None, **kw):
+        from models_video.pipeline_upscale_a_video import randn_tensor
+        n = randn_tensor(image.shape, generator=generator, device=image.device, dtype=torch.float32)
+        lat = randn_tensor((1, 4) + tuple(image.shape[2:]), generator=generator, device=image.device, dtype=torch.float32)
+        up = torch.nn.functional.interpolate((image + 0.1 * n)[0].permute(1, 0, 2, 3), scale_factor=4, mode="nearest")
+        up = up.permute(1, 0, 2, 3)[None] + torch.nn.functional.interpolate(lat[0, :1].permute(1, 0, 2, 3), scale_factor=4).permute(1, 0, 2, 3)[None]
+        return type("O", (), {"images": up})()
+
+
+def _serial_cli_loop(pipe, vframes, gen, tile):
+    """The CLI loop itself, restated for the test: one shared generator, tiles in order."""
+    from uav import tiling
+    out = vframes.new_zeros(vframes.shape[:3] + (vframes.shape[3] * 4, vframes.shape[4] * 4))
+    for t in tiling.tile_grid(vframes.shape[3], vframes.shape[4], tile):
+        res = pipe("p", image=vframes[:, :, :, t.src[0]:t.src[1], t.src[2]:t.src[3]], generator=gen).images
+        out[:, :, :, t.dst[0]:t.dst[1], t.dst[2]:t.dst[3]] = res[:, :, :, t.crop[0]:t.crop[1], t.crop[2]:t.crop[3]]
+    return out
+
+
+def test_upscale_tiled_serial_equals_cli_loop():
+    from uav import tiling
+    g = torch.Generator().manual_seed(4)
+    vframes = torch.randn(1, 3, 2, 96, 150, generator=g)
+    pipe = _FakeTilePipeline()
+    ref = _serial_cli_loop(pipe, vframes, torch.Generator().manual_seed(10), 64)
+    gen = torch.Generator().manual_seed(10)
+    out = tiling.upscale_tiled(pipe, "p", vframes, None, gen, tile_size=64)
+    assert torch.equal(out, ref)
+    # replaying the draws reproduces the generator state each tile starts from
+    gen2 = torch.Generator().manual_seed(10)
+    tiles = tiling.tile_grid(96, 150, 64)
+    states = tiling.generator_states(gen2, tiles, 2, 3, 4, torch.float32, "cpu")
+    assert len(states) == len(tiles) and torch.equal(gen2.get_state(), gen.get_state())
+
+
+# ---------------------------------------------------------------------------------------------
 # 5. multi-GPU helpers on gloo, world_size 2
 def _dist_worker(rank, world, port, q):
     os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -326,8 +394,15 @@ def _dist_worker(rank, world, port, q):
     serial = blend({w_: fake_unet(w_) for w_ in uniq})
     chunks = D.sharded_map(list(range(0, t_total, 3)), lambda s_: torch.full((1, 3, 3, 2, 2), float(s_)))
     single = D.sharded_map([5], lambda s_: torch.full((2,), float(s_)))          # one item: no collective
+    # --- spatial tiles of one clip over the ranks (BASELINE config 5): bit-identical to the serial CLI loop ---
+    from uav import tiling
+    gv = torch.Generator().manual_seed(4)
+    vframes = torch.randn(1, 3, 2, 96, 150, generator=gv)
+    pipe = _FakeTilePipeline()
+    tiled = tiling.upscale_tiled(pipe, "p", vframes, None, torch.Generator().manual_seed(10), tile_size=64)
+    tiles_same = torch.equal(tiled, _serial_cli_loop(pipe, vframes, torch.Generator().manual_seed(10), 64))
     q.put((r, mine, elapsed, total, gathered, torch.equal(sharded, serial), n_local, len(uniq),
-           [float(c.flatten()[0]) for c in chunks], float(single[0][0])))
+           [float(c.flatten()[0]) for c in chunks], float(single[0][0]), tiles_same))
     D.finalize()
 
 
@@ -349,6 +424,7 @@ def test_dist_gloo_world2():
     assert g0 == [[0, 2, 4, 6], [1, 3, 5]] and g1 is None
     # window-sharded long clip: bit-identical to the serial schedule on BOTH ranks, each rank ran only its share
     for x in (x0, x1):
-        same, n_local, n_uniq, chunk_ids, single = x
+        same, n_local, n_uniq, chunk_ids, single, tiles_same = x
+        assert tiles_same                          # tile-sharded clip == serial CLI loop, on both ranks
         assert same and n_uniq == 5 and chunk_ids == [float(s) for s in range(0, 32, 3)] and single == 5.0
     assert x0[1] == 3 and x1[1] == 2           # 5 unique windows dealt 3 / 2
