@@ -52,25 +52,6 @@ UAV_DEVINL void dma16(const char* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-// Source pixel (linear index into the [n_img*hi*wi] rows) read by output pixel (img,yo,xo) at
-// tap (dt,dy,dx); -1 when the tap falls into the zero padding.
-UAV_DEVINL int src_pixel(const ConvArgs& p, int img, int tloc, int yo, int xo, int dt, int dy, int dx) {
-    int tt = tloc + dt - p.pad_t;
-    int yi, xi;
-    bool ok = (tt >= 0) & (tt < p.t_len);
-    if (p.upsample) {
-        int yv = yo + dy - p.pad_h, xv = xo + dx - p.pad_w;
-        ok = ok & (yv >= 0) & (yv < p.ho) & (xv >= 0) & (xv < p.wo);
-        yi = yv >> 1; xi = xv >> 1;
-    } else {
-        yi = yo * p.stride + dy - p.pad_h; xi = xo * p.stride + dx - p.pad_w;
-        ok = ok & (yi >= 0) & (yi < p.hi) & (xi >= 0) & (xi < p.wi);
-    }
-    int pix = ((img + dt - p.pad_t) * p.hi + yi) * p.wi + xi;
-    return ok ? pix : -1;
-}
-
-
 // ---------------------------------------------------------------------------------------------
 // Shared epilogue.  After the swapped MFMA a lane owns pixel m = mw0 + mi*32 + (lane&31) and, per
 // register quad g, channels n = nw0 + ni*32 + 8g + 4*(lane>>5) + j (j = 0..3): 8-byte pieces.
@@ -386,17 +367,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs p) {
     // ---- DMA role of this thread: rows r = pass*32 + (tid>>3), physical slot tid&7 ----------
     const int slot_log = (tid & 7) ^ ((tid >> 4) & 7);   // logical k-slot fetched into phys slot
     const int rbase = tid >> 3;                          // 0..31
-    int img[4], tloc[4], yx[4];
-    bool mval[4];
+    // per-row gather constants, branch-free validity test (same scheme as conv_gemm256_kernel)
+    int rimg[4], rtl[4], rys[4], rxs[4];
     const int hw_o = p.ho * p.wo;
+    const int ups = p.upsample ? 1 : 0;
+    const int ylim = p.upsample ? p.ho : p.hi, xlim = p.upsample ? p.wo : p.wi;
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
         long long m = m0 + ps * 32 + rbase;
-        mval[ps] = m < p.M;
-        int mm = mval[ps] ? (int)m : 0;
+        const bool ok = m < p.M;
+        int mm = ok ? (int)m : 0;
         int im = mm / hw_o; int rem = mm - im * hw_o;
         int yo = rem / p.wo; int xo = rem - yo * p.wo;
-        img[ps] = im; tloc[ps] = im % p.t_len; yx[ps] = (yo << 16) | xo;
+        rimg[ps] = im - p.pad_t; rtl[ps] = im % p.t_len - p.pad_t;
+        rys[ps] = ok ? yo * p.stride - p.pad_h : -(1 << 28); rxs[ps] = xo * p.stride - p.pad_w;
     }
     const int cin = p.c1 + p.c2;
     const int khw = p.kh * p.kw;
@@ -408,48 +392,59 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs p) {
     // re-read almost the same source pixels, so consecutive k-steps of a workgroup (and of its neighbours on the
     // XCD) hit the lines the previous step just pulled into the 4 MiB L2; with the channel-innermost order the reuse
     // distance was cin/64 k-steps x 32 workgroups = 8 MB per XCD and 65 % of the X requests missed L2 (PMC run 21).
+    int kdt = 0, kdy = 0, kdx = 0, ktap = 0, kc = 0;     // wave-uniform: tap and channel offset of the NEXT k-step
     int pix[4] = {-1, -1, -1, -1};
-    int nxt_tap = 0, nxt_c = 0;          // (tap, channel offset) of the NEXT k-step to issue
+    bool pix_valid = false;
 
-    auto issue = [&](int stage, int ks) {
-        char* sA = smem + stage * STAGE_BYTES;
-        char* sB = sA + A_BYTES;
-        long long wk = (long long)ks * BK;   // k offset of this step's weight slice
-        if (SMALL) {
-            // cin_p == 8: every 16-B slot is one tap of one pixel.
-            int tap = ks * 8 + slot_log;
-            bool tok = tap < ntaps;
-            int dt = tap / khw; int rem = tap - dt * khw; int dy = rem / p.kw; int dx = rem - dy * p.kw;
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                int px = (tok && mval[ps]) ? src_pixel(p, img[ps], tloc[ps], yx[ps] >> 16, yx[ps] & 0xffff, dt, dy, dx) : -1;
-                const char* g = px >= 0 ? p.a1 + (long long)px * 16 : p.zero_page;
-                dma16(g, sA + (ps * 256 + wave * 64) * 16);
-            }
-        } else {
-            if (ntaps > 1 || ks == 0) {  // uniform branch: source pixels of this tap
-                int dt = nxt_tap / khw; int rem = nxt_tap - dt * khw; int dy = rem / p.kw; int dx = rem - dy * p.kw;
-#pragma unroll
-                for (int ps = 0; ps < 4; ++ps)
-                    pix[ps] = mval[ps] ? src_pixel(p, img[ps], tloc[ps], yx[ps] >> 16, yx[ps] & 0xffff, dt, dy, dx) : -1;
-            }
-            const bool first = nxt_c < p.c1;
-            const char* src = first ? p.a1 : p.a2;
-            const int cs = first ? p.c1 : p.c2;
-            const int coff = (first ? nxt_c : nxt_c - p.c1) + slot_log * 8;
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const char* g = pix[ps] >= 0 ? src + ((long long)pix[ps] * cs + coff) * 2 : p.zero_page;
-                dma16(g, sA + (ps * 256 + wave * 64) * 16);
-            }
-            wk = nxt_tap * cin + nxt_c;
-            if (p.korder) { if (++nxt_tap >= ntaps) { nxt_tap = 0; nxt_c += BK; } }
-            else { nxt_c += BK; if (nxt_c >= cin) { nxt_c = 0; ++nxt_tap; } }
-        }
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps)
-            dma16(wrow + ((long long)ps * 32 * p.k_pad + wk) * 2, sB + (ps * 256 + wave * 64) * 16);
-    };
+#define ISSUE128(STAGE, KS)                                                                                  \
+    {                                                                                                        \
+        char* sA = smem + (STAGE) * STAGE_BYTES;                                                             \
+        char* sB = sA + A_BYTES;                                                                             \
+        long long wk = (long long)(KS) * BK;                                                                 \
+        if (SMALL) {                                                                                         \
+            /* cin_p == 8: every 16-B slot is one tap of one pixel */                                        \
+            const int tap = (KS) * 8 + slot_log;                                                             \
+            const int dt = tap / khw; const int rem = tap - dt * khw; const int dy = rem / p.kw; const int dx = rem - dy * p.kw; \
+            _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                               \
+                const int tt = rtl[ps] + dt, yv = rys[ps] + dy, xv = rxs[ps] + dx;                           \
+                const bool ok = (tap < ntaps) & ((unsigned)tt < (unsigned)p.t_len) & ((unsigned)yv < (unsigned)ylim) & \
+                                ((unsigned)xv < (unsigned)xlim);                                             \
+                const int px = ((rimg[ps] + dt) * p.hi + (yv >> ups)) * p.wi + (xv >> ups);                  \
+                const char* g = ok ? p.a1 + (long long)px * 16 : p.zero_page;                                \
+                dma16(g, sA + (ps * 256 + wave * 64) * 16);                                                  \
+            }                                                                                                \
+        } else {                                                                                             \
+            if (ntaps > 1 || !pix_valid) {                                                                   \
+                _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                           \
+                    const int tt = rtl[ps] + kdt, yv = rys[ps] + kdy, xv = rxs[ps] + kdx;                    \
+                    const bool ok = ((unsigned)tt < (unsigned)p.t_len) & ((unsigned)yv < (unsigned)ylim) &   \
+                                    ((unsigned)xv < (unsigned)xlim);                                         \
+                    const int px = ((rimg[ps] + kdt) * p.hi + (yv >> ups)) * p.wi + (xv >> ups);             \
+                    pix[ps] = ok ? px : -1;                                                                  \
+                }                                                                                            \
+                pix_valid = true;                                                                            \
+            }                                                                                                \
+            const bool first = kc < p.c1;                                                                    \
+            const char* src = first ? p.a1 : p.a2;                                                           \
+            const int cs = first ? p.c1 : p.c2;                                                              \
+            const int coff = (first ? kc : kc - p.c1) + slot_log * 8;                                        \
+            _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                               \
+                const char* g = pix[ps] >= 0 ? src + ((long long)pix[ps] * cs + coff) * 2 : p.zero_page;     \
+                dma16(g, sA + (ps * 256 + wave * 64) * 16);                                                  \
+            }                                                                                                \
+            wk = (long long)ktap * cin + kc;                                                                 \
+            if (p.korder) {                                                                                  \
+                ++ktap;                                                                                      \
+                if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } }                       \
+                if (ktap == ntaps) { ktap = 0; kdt = 0; kdy = 0; kdx = 0; kc += BK; }                        \
+            } else {                                                                                         \
+                kc += BK;                                                                                    \
+                if (kc >= cin) { kc = 0; ++ktap; if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } } } \
+            }                                                                                                \
+        }                                                                                                    \
+        _Pragma("unroll") for (int ps = 0; ps < 4; ++ps)                                                     \
+            dma16(wrow + ((long long)ps * 32 * p.k_pad + wk) * 2, sB + (ps * 256 + wave * 64) * 16);         \
+    }
 
     // ---- accumulators: acc[ni][mi], wave tile = rows n [wn*64,+64) x cols m [wm*64,+64) -----
     const int wn = wave & 1, wm = wave >> 1;
@@ -474,12 +469,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs p) {
     const int swX0 = ((wm * 64 + l32) >> 1) & 7, swX1 = ((wm * 64 + 32 + l32) >> 1) & 7;
     (void)swz;
 
-    issue(0, 0);
+    ISSUE128(0, 0)
     int cur = 0;
     for (int ks = 0; ks < nk; ++ks) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (ks + 1 < nk) issue(cur ^ 1, ks + 1);
+        if (ks + 1 < nk) ISSUE128(cur ^ 1, ks + 1)
         const char* st = smem + cur * STAGE_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
@@ -496,6 +491,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs p) {
         cur ^= 1;
     }
 
+#undef ISSUE128
     conv_epilogue<2, 2>(p, acc, m0 + wm * 64, n0 + wn * 64, l32, hi32);
 }
 
