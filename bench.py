@@ -243,8 +243,15 @@ def main():
             dom = max(summ.items(), key=lambda kv: kv[1]["seconds"])
             name, d = dom
             ach = d["flops"] / d["seconds"] / 1e12
+            # HBM traffic per launch of the dominant kernel cannot be read from inside this process: it comes from the
+            # committed PMC pass over this same command (tools/pmc_traffic.sh -> profiles/pmc_conv_traffic.json;
+            # TCC_EA0_RDREQ / WRREQ with the gfx950 corrections of MI355X_MICROARCH.md) and stays null without it.
+            traffic = None
+            tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_conv_traffic.json")
+            if name == "conv_gemm" and os.path.exists(tfile) and not (args.propagation or args.shard_windows or args.frames != 8):
+                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_TFLOPS_F16, "traffic": None, "launches": d["launches"],
+                               "frac": ach / PEAK_TFLOPS_F16, "traffic": traffic, "launches": d["launches"],
                                "avg_launch_us": d["seconds"] / d["launches"] * 1e6,
                                "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
                                "kernel_time_share": d["seconds"] / total_s}
