@@ -27,7 +27,7 @@ def _digest():
     files.append(os.path.join(os.path.dirname(os.path.dirname(HERE)), "include", "uav_hip.h"))
     for f in files:
         with open(f, "rb") as fh:
-            h.update(f.encode()); h.update(fh.read())
+            h.update(os.path.basename(f).encode()); h.update(fh.read())     # path-independent: the tree is copied to other roots
     h.update(" ".join(FLAGS).encode())
     return h.hexdigest()
 
