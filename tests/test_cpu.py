@@ -245,6 +245,47 @@ def test_pack_conv_and_kernel_addressing_spec(cin, cout, k3, stride, ups, t_len)
     assert cw.n_pad % 128 == 0 and cw.k_pad % 64 == 0
 
 
+def test_cabi_rejects_bad_arguments_without_touching_the_gpu():
+    """Error behaviour of the C ABI (include/uav_hip.h): argument checks return UAV_E* codes before any launch, so
+    they can be exercised on a box without a GPU.  Pointers are dummies and are never dereferenced."""
+    import ctypes as C
+    from uav import _lib
+    lib = _lib.load()
+    EINVAL, EALIGN, ESHAPE = -1, -2, -3
+    P = 0x1000                                   # non-null dummy "device pointer"
+    base = dict(a1=P, c1=64, c2=0, w=P, out=P, out_stride=128, n_img=2, t_len=1, hi=8, wi=8, ho=8, wo=8, kt=1, kh=3, kw=3,
+                stride=1, pad_h=1, pad_w=1, n=128, n_pad=128, k_pad=576, out_scale=1.0, zero_page=P)
+
+    def conv(**kw):
+        prm = _lib.ConvParams(**{**base, **kw})
+        return lib.uav_conv_gemm_f16(C.byref(prm), None)
+    assert conv(a1=None) == EINVAL and conv(zero_page=None) == EINVAL and conv(w=None) == EINVAL
+    assert conv(c1=48) == ESHAPE                  # channels must be a multiple of 64 (or exactly 8)
+    assert conv(c2=64) == EINVAL                  # second source announced but a2 missing
+    assert conv(k_pad=512) == ESHAPE              # k_pad != taps * cin
+    assert conv(n=126) == ESHAPE and conv(n=256) == ESHAPE       # n % 4, n > n_pad
+    assert conv(out_stride=126) == EALIGN
+    assert conv(upsample=1) == ESHAPE             # upsample needs ho = 2 hi
+    assert conv(t_len=3) == ESHAPE                # n_img % t_len
+    assert conv(flags=1, residual=P, res_stride=128) == ESHAPE   # GEGLU excludes residual
+    assert conv(rowbias=P, rows_per_batch=0) == ESHAPE
+    assert lib.uav_conv_gemm_f16(None, None) == EINVAL
+    # GroupNorm
+    assert lib.uav_groupnorm_scale_shift(None, None, 64, 0, 64, 1, 16, 32, 1e-5, None, None, P, P, P, 1 << 20, None) == EINVAL
+    assert lib.uav_groupnorm_scale_shift(P, None, 60, 0, 60, 1, 16, 30, 1e-5, None, None, P, P, P, 1 << 20, None) == ESHAPE
+    assert lib.uav_groupnorm_scale_shift(P, None, 64, 0, 64, 1, 16, 7, 1e-5, None, None, P, P, P, 1 << 20, None) == ESHAPE
+    assert lib.uav_groupnorm_scale_shift(P, None, 64, 0, 64, 1, 16, 32, 1e-5, None, None, P, P, P, 8, None) == EINVAL    # workspace too small
+    # attention: null / shape / alignment
+    assert lib.uav_attention_f16(None, 64, P, 64, P, 64, P, 64, 1, 8, 8, 1, 1, 64, 0.125, P, None) == EINVAL
+    assert lib.uav_attention_f16(P, 64, P, 64, P, 64, P, 64, 3, 8, 8, 2, 1, 64, 0.125, P, None) == ESHAPE        # bq % q_per_kv
+    assert lib.uav_attention_f16(P, 60, P, 64, P, 64, P, 64, 1, 8, 8, 1, 1, 64, 0.125, P, None) == EALIGN
+    assert lib.uav_attention_f16(P, 96, P, 96, P, 96, P, 96, 1, 8, 8, 1, 1, 96, 0.125, P, None) == ESHAPE        # head_dim not built
+    # temporal attention: T > 8 is not on the path
+    assert lib.uav_temporal_attention_f16(P, P, 1, 9, 16, 512, 8, 0.125, P, P, 32, P, None) == ESHAPE
+    assert lib.uav_resize_bilinear_f32(None, P, 1, 4, 4, 8, 8, 1.0, 1.0, None) == EINVAL
+    assert lib.uav_version() > 0
+
+
 def test_geglu_packing_order():
     from uav import ops
     f, k = 64, 64
