@@ -154,12 +154,12 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_kernel(AttnArgs 
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float ps = 0.f;
         half8_t pf[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = exp2f(sacc[r] - m_new);
+            const float e = __builtin_amdgcn_exp2f(sacc[r] - m_new);
             ps += e;
             pf[r >> 3][r & 7] = (half_t)e;
         }
@@ -320,12 +320,12 @@ __global__ __launch_bounds__(512, 2) void attn512_kernel(AttnArgs p) {
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float ps = 0.f;
         half8_t pf[2];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float e = exp2f(sacc[r] - m_new);
+            const float e = __builtin_amdgcn_exp2f(sacc[r] - m_new);
             ps += e;
             pf[r >> 3][r & 7] = (half_t)e;
         }

@@ -25,6 +25,25 @@ struct TAttnArgs {
     int groups;   // ceil(c / 512)
 };
 
+// Sum over the LPH = d/8 lanes of one head (aligned lane groups) on the DPP network: quad_perm xor-1 / xor-2, then
+// row_half_mirror (lane i <-> 7-i) and row_mirror (i <-> 15-i) bring in the other quad / half row — single v_add_f32_dpp
+// each.  (The first version looped `__shfl_xor` over a run-time lane count: 192 dependent ds_bpermute_b32 per pixel, which
+// made this HBM-class kernel latency-bound at 2 TB/s.)
+template <int CTRL> UAV_DEVINL float dpp_add(float x) {
+    const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true);
+    return x + __builtin_bit_cast(float, y);
+}
+template <int LPH> UAV_DEVINL float head_allreduce(float x) {
+    if (LPH >= 2) x = dpp_add<0xB1>(x);          // quad_perm [1,0,3,2]
+    if (LPH >= 4) x = dpp_add<0x4E>(x);          // quad_perm [2,3,0,1]
+    if (LPH >= 8) x = dpp_add<0x141>(x);         // row_half_mirror
+    if (LPH >= 16) x = dpp_add<0x140>(x);        // row_mirror
+    if (LPH >= 32) x += __shfl_xor(x, 16, 64);
+    if (LPH >= 64) x += __shfl_xor(x, 32, 64);
+    return x;
+}
+
+template <int LPH>
 __global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnArgs p) {
     const int lane = threadIdx.x & 63;
     const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -35,44 +54,42 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnArgs p) {
     const long long pix = bp % p.hw;
     const int b = (int)(bp / p.hw);
     const int c0 = grp * 512 + lane * 8;
-    if (c0 >= p.c) return;
-    const int lph = p.d >> 3;                 // lanes per head (power of two, <= 64)
-    const int head = c0 / p.d;
-    const int sub = (c0 % p.d) >> 3;          // this lane's 8-dim slice inside the head
+    // lanes past C keep running on clamped addresses (DPP reductions need the whole head group active); they only skip the store
+    const bool live = c0 < p.c;
+    const int cc = live ? c0 : 0;
+    const int head = cc / p.d;
+    const int sub = (cc % p.d) >> 3;          // this lane's 8-dim slice inside the head
     const bool rot = sub * 8 < p.rot_dim;
     const int T = p.t_len;
     const long long row_stride = 3ll * p.c * 2;       // bytes per qkv row
-    const char* base = p.qkv + ((long long)b * T * p.hw + pix) * row_stride + (long long)c0 * 2;
+    const char* base = p.qkv + ((long long)b * T * p.hw + pix) * row_stride + (long long)cc * 2;
     const long long fstride = p.hw * row_stride;      // bytes between frames of this pixel
+    const int rsub = rot ? sub * 4 : 0;
 
-    // ---- K (rotated) in fp32, V as fp16 -----------------------------------------------------
-    float kf[TMAX][8];
-    half8_t vh[TMAX];
+    // ---- K rotated (fp32 math, stored fp16 like the reference's fp16 rotary output), V in fp32 -------------------
+    half8_t kh[TMAX];
+    float vf[TMAX][8];
 #pragma unroll
     for (int j = 0; j < TMAX; ++j) {
-        if (j < T) {
-            half8_t kx = *(const half8_t*)(base + j * fstride + (long long)p.c * 2);
-            vh[j] = *(const half8_t*)(base + j * fstride + (long long)p.c * 4);
+        const int jc = j < T ? j : T - 1;                 // rows past T are never used: read a valid one
+        half8_t kx = *(const half8_t*)(base + jc * fstride + (long long)p.c * 2);
+        half8_t vx = *(const half8_t*)(base + jc * fstride + (long long)p.c * 4);
+        if (rot) {
+            const float4_t cs = *(const float4_t*)(p.rope_cos + jc * (p.rot_dim >> 1) + rsub);
+            const float4_t sn = *(const float4_t*)(p.rope_sin + jc * (p.rot_dim >> 1) + rsub);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) kf[j][e] = (float)kx[e];
-            if (rot) {
-                const float4_t cs = *(const float4_t*)(p.rope_cos + j * (p.rot_dim >> 1) + sub * 4);
-                const float4_t sn = *(const float4_t*)(p.rope_sin + j * (p.rot_dim >> 1) + sub * 4);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float a = kf[j][2 * q], bb = kf[j][2 * q + 1];
-                    kf[j][2 * q] = a * cs[q] - bb * sn[q];
-                    kf[j][2 * q + 1] = bb * cs[q] + a * sn[q];
-                }
+            for (int q = 0; q < 4; ++q) {
+                const float a = (float)kx[2 * q], bb = (float)kx[2 * q + 1];
+                kx[2 * q] = (half_t)(a * cs[q] - bb * sn[q]);
+                kx[2 * q + 1] = (half_t)(bb * cs[q] + a * sn[q]);
             }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) kf[j][e] = 0.f;
-            vh[j] = half8_t{0, 0, 0, 0, 0, 0, 0, 0};
         }
+        kh[j] = kx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vf[j][e] = (float)vx[e];
     }
 
-    char* obase = p.out + (((long long)b * T * p.hw + pix) * p.c + c0) * 2;
+    char* obase = p.out + (((long long)b * T * p.hw + pix) * p.c + cc) * 2;
     const long long ofstride = p.hw * (long long)p.c * 2;
 #pragma unroll
     for (int i = 0; i < TMAX; ++i) {
@@ -82,8 +99,8 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnArgs p) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) qf[e] = (float)qx[e] * p.scale;
         if (rot) {
-            const float4_t cs = *(const float4_t*)(p.rope_cos + i * (p.rot_dim >> 1) + sub * 4);
-            const float4_t sn = *(const float4_t*)(p.rope_sin + i * (p.rot_dim >> 1) + sub * 4);
+            const float4_t cs = *(const float4_t*)(p.rope_cos + i * (p.rot_dim >> 1) + rsub);
+            const float4_t sn = *(const float4_t*)(p.rope_sin + i * (p.rot_dim >> 1) + rsub);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float a = qf[2 * q], bb = qf[2 * q + 1];
@@ -91,21 +108,21 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnArgs p) {
                 qf[2 * q + 1] = bb * cs[q] + a * sn[q];
             }
         }
+        half2_t qh[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) qh[q] = half2_t{(half_t)qf[2 * q], (half_t)qf[2 * q + 1]};
+        // bias row of this head: T <= 8 floats
+        const float* brow = p.bias + ((long long)head * T + i) * T;
         float s[TMAX];
+        float mx = -INFINITY;
 #pragma unroll
         for (int j = 0; j < TMAX; ++j) {
             float a = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) a += qf[e] * kf[j][e];
-            // all-reduce over the lph lanes of this head
-            for (int o = 1; o < lph; o <<= 1) a += __shfl_xor(a, o, 64);
+            for (int q = 0; q < 4; ++q) a = __builtin_amdgcn_fdot2(qh[q], half2_t{kh[j][2 * q], kh[j][2 * q + 1]}, a, false);
+            a = head_allreduce<LPH>(a);
+            if (j < T) { a += brow[j]; mx = fmaxf(mx, a); }
             s[j] = a;
-        }
-        const float* brow = p.bias + ((long long)head * T + i) * T;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int j = 0; j < TMAX; ++j) {
-            if (j < T) { s[j] += brow[j]; mx = fmaxf(mx, s[j]); }
         }
         float den = 0.f;
 #pragma unroll
@@ -121,12 +138,12 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnArgs p) {
         for (int j = 0; j < TMAX; ++j) {
             const float pj = s[j] * inv;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] += pj * (float)vh[j][e];
+            for (int e = 0; e < 8; ++e) o[e] += pj * vf[j][e];
         }
         half8_t oh;
 #pragma unroll
         for (int e = 0; e < 8; ++e) oh[e] = (half_t)o[e];
-        *(half8_t*)(obase + i * ofstride) = oh;
+        if (live) *(half8_t*)(obase + i * ofstride) = oh;
     }
 }
 
@@ -146,6 +163,15 @@ extern "C" int uav_temporal_attention_f16(const void* qkv, void* out, int32_t n_
     const long long nwork = (long long)n_batch * hw * a.groups;
     const long long blocks = (nwork + 3) / 4;
     if (blocks >= (1ll << 31)) return UAV_ESHAPE;
-    hipLaunchKernelGGL(temporal_attn_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    switch (d >> 3) {                       // lanes per head
+        case 1: hipLaunchKernelGGL(temporal_attn_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+        case 2: hipLaunchKernelGGL(temporal_attn_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+        case 4: hipLaunchKernelGGL(temporal_attn_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+        case 8: hipLaunchKernelGGL(temporal_attn_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+        case 16: hipLaunchKernelGGL(temporal_attn_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+        case 32: hipLaunchKernelGGL(temporal_attn_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+        default: hipLaunchKernelGGL(temporal_attn_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+    }
     return uav_launch_status();
 }
