@@ -12,6 +12,10 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle side of the parity tests is small-tensor CPU work: on the 256-core GPU boxes torch's default of one
+    # thread per core made it 10-20x SLOWER than on 8 cores (120 s instead of 5-20 s per end-to-end test).
+    import torch
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
 
 
 @pytest.fixture(scope="session")

@@ -184,7 +184,7 @@ def test_pipeline_with_raft_flows_and_propagation(dev):
     from models_video.scheduling_ddim import DDIMScheduler, DDPMScheduler
     from models_video.unet_video import UNetVideoModel
     from uav.standin_text import StandInTextEncoder, StandInTokenizer
-    t, h, w = 4, 128, 128
+    t, h, w = 3, 128, 128
     clip = synth.synth_clip(1, t, h, w, seed=9, motion=(2, 1))
     rb = RAFT_bi(model_path=None, device="cpu")
     rsd = synth.synth_state_dict(rb.fix_raft.state_dict(), seed=777)
