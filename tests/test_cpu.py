@@ -350,6 +350,51 @@ def test_tile_grid_matches_reference_cli_loop():
     assert tiling.needs_tiling(384, 384) and not tiling.needs_tiling(320, 320) and tiling.needs_tiling(64, 64, True)
 
 
+def test_tile_grid_properties_random_sizes():
+    """For any frame size the CLI would tile (and any tile size it accepts): output boxes partition the 4x canvas,
+    every crop has its destination's shape and lies inside the 4x padded tile, every padded tile contains its core."""
+    from hypothesis import given, settings, strategies as st
+    from uav import tiling
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(130, 1300), st.integers(130, 2200), st.sampled_from([128, 192, 256, 320, 384]))
+    def check(h, w, tile):
+        tiles = tiling.tile_grid(h, w, tile)
+        area = 0
+        seen = set()
+        for t in tiles:
+            sy0, sy1, sx0, sx1 = t.src
+            dy0, dy1, dx0, dx1 = t.dst
+            cy0, cy1, cx0, cx1 = t.crop
+            assert 0 <= sy0 < sy1 <= h and 0 <= sx0 < sx1 <= w
+            assert (cy1 - cy0, cx1 - cx0) == (dy1 - dy0, dx1 - dx0)
+            assert 0 <= cy0 and cy1 <= 4 * (sy1 - sy0) and 0 <= cx0 and cx1 <= 4 * (sx1 - sx0)
+            assert dy0 == 4 * sy0 + cy0 and dx0 == 4 * sx0 + cx0          # the crop is the same pixels, not a shifted copy
+            area += (dy1 - dy0) * (dx1 - dx0)
+            assert (dy0, dx0) not in seen
+            seen.add((dy0, dx0))
+        assert area == 16 * h * w                                        # disjoint (distinct origins on a grid) and complete
+    check()
+
+
+def test_window_schedule_properties():
+    from hypothesis import given, settings, strategies as st
+    from models_video.pipeline_upscale_a_video import window_schedule
+
+    @settings(max_examples=200, deadline=None)
+    @given(st.integers(1, 200))
+    def check(t):
+        wins = window_schedule(t)
+        covered = set()
+        for (s, e) in wins:
+            assert 0 <= s < e <= t and (e - s == 8 or t < 8)
+            covered.update(range(s, e))
+        assert covered == set(range(t))
+        if t > 8:
+            assert all(b[0] - a[0] in (0, 6) or b[1] == t for a, b in zip(wins, wins[1:]))
+    check()
+
+
 class _FakeTilePipeline:
     """CPU stand-in with the pipeline's draw order: LR noise, then latents, from the shared generator."""
 
