@@ -266,7 +266,9 @@ class VideoUpscalePipeline(ConfigMixin):
                     return self.unet(lin[:, :, se[0]:se[1]].contiguous(), t, image[:, :, se[0]:se[1]].contiguous(),
                                      encoder_hidden_states=prompt_embeds, class_labels=level,
                                      cfg_shared_input=do_cfg and self.cfg_shared_input).sample.contiguous()
-                outs = dict(zip(uniq, D.sharded_map(uniq, eval_window) if self.shard_windows else map(eval_window, uniq)))
+                like = ((lin.shape[0], latents.shape[1], uniq[0][1] - uniq[0][0]) + tuple(lin.shape[3:]), torch.float16, device)
+                outs = dict(zip(uniq, D.sharded_map(uniq, eval_window, like=like) if self.shard_windows
+                                else map(eval_window, uniq)))
                 for (s, e) in wins:
                     o = outs[(s, e)]
                     if eps is None:
@@ -302,7 +304,8 @@ class VideoUpscalePipeline(ConfigMixin):
                 if self.shard_windows and e - s < short_seq:      # ragged last chunk: pad to a common shape for the gather
                     y = torch.cat([y, y.new_zeros(y.shape[:2] + (short_seq - (e - s),) + y.shape[3:])], dim=2)
                 return y.contiguous()
-            chunks = D.sharded_map(starts, decode_chunk) if self.shard_windows else [decode_chunk(s) for s in starts]
+            like = ((1, image_dec.shape[1], short_seq, 4 * height, 4 * width), torch.float32, device)
+            chunks = D.sharded_map(starts, decode_chunk, like=like) if self.shard_windows else [decode_chunk(s) for s in starts]
             out = torch.cat(chunks, dim=2)[:, :, :t_total]
         else:
             out = self.decode_latents_vsr(latents, image_dec, w_lr)

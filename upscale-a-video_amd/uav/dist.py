@@ -32,7 +32,7 @@ def shard(items, rank, world):
     return [it for i, it in enumerate(items) if i % world == rank]
 
 
-def sharded_map(items, fn, group=None):
+def sharded_map(items, fn, group=None, like=None):
     """Evaluate `fn(item) -> tensor` for every item with the items dealt round-robin over the ranks, then
     all-gather: every rank returns the full list, in item order, bit-identical to the unsharded evaluation.
 
@@ -40,19 +40,25 @@ def sharded_map(items, fn, group=None):
     independent UNet evaluations — the only coupling is the epsilon blend on the overlap frames, which
     every rank then replays on the gathered outputs — and so are the 3-frame VAE decode chunks.  All results of one
     call must share shape and dtype (windows are all 8 frames; the ragged last decode chunk is padded by the
-    caller).  One all_gather of (ceil(n/world), *shape) per call; RCCL over xGMI
-    when the backend is nccl."""
+    caller).  One all_gather of (ceil(n/world), *shape) per call; RCCL over xGMI when the backend is nccl.
+    `like` = (shape, dtype, device) of one result: lets a rank that owns no item (more ranks than items) take part
+    without the object broadcast that is otherwise needed to learn the shape."""
     items = list(items)
     if not dist.is_initialized() or dist.get_world_size(group) == 1 or len(items) <= 1:
         return [fn(it) for it in items]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     mine = [fn(it) for it in items[rank::world]]
     per_rank = -(-len(items) // world)
-    # the result shape is known to every rank that owns an item; rank 0 always does (more ranks than items is allowed)
-    shape_dtype = [(tuple(mine[0].shape), mine[0].dtype) if mine else None]
-    dist.broadcast_object_list(shape_dtype, src=0, group=group)
-    shape, dtype = shape_dtype[0]
-    device = mine[0].device if mine else _default_device()
+    if mine:
+        shape, dtype, device = tuple(mine[0].shape), mine[0].dtype, mine[0].device
+    elif like is not None:
+        shape, dtype, device = tuple(like[0]), like[1], like[2]
+    if len(items) < world and like is None:
+        # some rank owns nothing and has no hint: rank 0 (which always owns item 0) tells everybody the shape
+        meta = [(shape, dtype) if mine else None]
+        dist.broadcast_object_list(meta, src=0, group=group)
+        shape, dtype = meta[0]
+        device = mine[0].device if mine else _default_device()
     buf = torch.zeros((per_rank,) + shape, dtype=dtype, device=device)
     for i, t in enumerate(mine):
         buf[i] = t
