@@ -61,7 +61,7 @@ def synthetic_clip(frames, height, width, seed, dev):
     return (x / x.abs().max()).contiguous().to(dev)
 
 
-def cpu_baseline(sample_hw=48, frames=8, max_threads=32):
+def cpu_baseline(sample_hw=64, frames=8, max_threads=32):
     """Oracle (CPU fp32 restatement of the reference path) on the full-width model, bounded sample:
     ONE UNet forward (CFG batch 2, 8 frames) + ONE 3-frame VAE decode chunk at sample_hw x sample_hw,
     extrapolated to config 2 by the analytic FLOP model."""
