@@ -203,6 +203,10 @@ int uav_propagate_step_f16(const void* feat_prev, const void* feat_cur, const vo
 #define UAV_CONV_RELU     4u
 #define UAV_CONV_SIGMOID  8u
 #define UAV_CONV_TANH     16u
+/* uav_conv_gemm_f16 only, opt-in and experimental: run the 256x256-tile kernel as one persistent workgroup per CU that
+ * prefetches the first K stage of its next tile ahead of the current tile's epilogue.  Bit-identical output; measured
+ * neutral on MI355X in round 1, hence off by default. */
+#define UAV_CONV_PERSISTENT 64u
 int uav_conv_gemm_f32(const uav_conv_params* p, void* stream);
 /* nn.InstanceNorm2d (no affine) [+ReLU] on rows [n_img*hw][c] (extractor.py:27-30,48-49) */
 int uav_instnorm_f32(const float* x, float* y, int32_t n_img, int32_t hw, int32_t c, float eps,

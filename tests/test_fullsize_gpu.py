@@ -56,6 +56,8 @@ def test_conv_full_size_sampled(ops, dev, name, cin, cout, k3, n_img, t_len, h, 
     y = ops.conv_gemm(rows, cw, n_img=n_img, t_len=t_len, hi=h, wi=w)
     y2 = ops.conv_gemm(rows, cw, n_img=n_img, t_len=t_len, hi=h, wi=w)
     assert torch.equal(y, y2)                                                     # deterministic
+    # opt-in persistent tile walk (UAV_CONV_PERSISTENT): same tiles, same arithmetic -> same bits
+    assert torch.equal(y, ops.conv_gemm(rows, cw, n_img=n_img, t_len=t_len, hi=h, wi=w, persistent=True))
     assert y.shape == (n_img * h * w, cout) and bool(torch.isfinite(y).all())
     pix = _sample_pixels(n_img, h, w, 1500, g).to(dev)
     img, rem = pix // (h * w), pix % (h * w)

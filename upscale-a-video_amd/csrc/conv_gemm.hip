@@ -43,6 +43,7 @@ struct ConvArgs {
     const char* zero_page;
     long long M;
     int korder, tile_order;
+    unsigned ntiles;
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -507,7 +508,9 @@ constexpr int LM = 256, LN = 256;
 constexpr int LA_BYTES = LM * BK * 2;            // 32 KiB
 constexpr int LSTAGE = 2 * LA_BYTES;             // 64 KiB (X tile + W tile)
 
-template <int DBG>   // DBG: ablation builds for profiling only (bit0: no DMA in the loop, bit1: no MFMA, 4: compiler-scheduled k-step); 0 in production
+// PERSIST: the workgroup walks tiles wg, wg + gridDim.x, ... and issues the first DMA stage of its NEXT tile before
+// the epilogue of the current one (both LDS stages are idle then), so the first-stage round trip hides behind it.
+template <int DBG, int PERSIST = 0>   // DBG: ablation builds for profiling only (bit0: no DMA in the loop, bit1: no MFMA, 4: compiler-scheduled k-step); 0 in production
 __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -516,54 +519,61 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
     const int hi32 = lane >> 5, l32 = lane & 31;
 
     const unsigned n_tiles = p.n_pad / LN;
-    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    unsigned mt = bid / n_tiles;
-    const unsigned nt = bid - mt * n_tiles;
-    // Temporal (k,1,1) / 3x3x3 convs: output frame t reads input frames t-k/2..t+k/2 at the SAME pixels, so the tiles
-    // of one spatial position are made neighbours in launch order (frame index fastest): the k re-reads of an input
-    // tile then come from workgroups that run together on one XCD and hit its L2 instead of the fabric.
-    if (p.kt > 1 && p.tile_order) {
-        const unsigned hw = (unsigned)(p.ho * p.wo);
-        if (hw % LM == 0) {
-            const unsigned S = hw / LM, per_clip = S * (unsigned)p.t_len;
-            const unsigned c = mt / per_clip, r = mt - c * per_clip;
-            const unsigned sp = r / (unsigned)p.t_len, t = r - sp * (unsigned)p.t_len;
-            mt = c * per_clip + t * S + sp;
-        }
-    }
-    const long long m0 = (long long)mt * LM;
-    const int n0 = nt * LN;
-
     const int slot_log = (tid & 7) ^ ((tid >> 4) & 7);
     const int rbase = tid >> 3;                          // 0..63; rows r = pass*64 + rbase
+    const int hw_o = p.ho * p.wo;
+    const int ups = p.upsample ? 1 : 0;
+    const int ylim = p.upsample ? p.ho : p.hi, xlim = p.upsample ? p.wo : p.wi;
     // Per-row gather constants.  Source pixel of tap (dt,dy,dx): frame rimg+dt, y = (rys+dy) >> ups, x = (rxs+dx) >> ups,
     // valid iff 0 <= rtl+dt < t_len and 0 <= rys+dy < ylim and 0 <= rxs+dx < xlim (unsigned compares); rows past M get an
     // rys that can never pass.  Everything below is branch-free: the previous formulation went through divergent
     // branches and kept its k-step counters in scratch (12 B/lane), both on the post-barrier critical path.
     int rimg[4], rtl[4], rys[4], rxs[4];
-    const int hw_o = p.ho * p.wo;
-    const int ups = p.upsample ? 1 : 0;
-    const int ylim = p.upsample ? p.ho : p.hi, xlim = p.upsample ? p.wo : p.wi;
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        long long m = m0 + ps * 64 + rbase;
-        const bool ok = m < p.M;
-        int mm = ok ? (int)m : 0;
-        int im = mm / hw_o; int rem = mm - im * hw_o;
-        int yo = rem / p.wo; int xo = rem - yo * p.wo;
-        rimg[ps] = im - p.pad_t; rtl[ps] = im % p.t_len - p.pad_t;
-        rys[ps] = ok ? yo * p.stride - p.pad_h : -(1 << 28); rxs[ps] = xo * p.stride - p.pad_w;
+    long long m0; int n0;
+    const char* wrow;
+    // k-step state (wave-uniform): tap (dt,dy,dx) and channel offset of the NEXT k-step to issue
+    int kdt, kdy, kdx, ktap, kc;
+    int pix[4] = {-1, -1, -1, -1};
+    bool pix_valid;
+
+    // Tile id -> (m tile, n tile).  Temporal (k,1,1) / 3x3x3 convs: output frame t reads input frames t-k/2..t+k/2 at
+    // the SAME pixels, so the tiles of one spatial position are made neighbours in launch order (frame index fastest):
+    // the k re-reads of an input tile then come from workgroups that run together on one XCD and hit its L2.
+#define SETUP_TILE(TILE)                                                                                     \
+    {                                                                                                        \
+        unsigned mt_ = (TILE) / n_tiles;                                                                     \
+        const unsigned nt_ = (TILE) - mt_ * n_tiles;                                                         \
+        if (p.kt > 1 && p.tile_order) {                                                                      \
+            const unsigned hw_ = (unsigned)hw_o;                                                             \
+            if (hw_ % LM == 0) {                                                                             \
+                const unsigned S_ = hw_ / LM, per_clip_ = S_ * (unsigned)p.t_len;                            \
+                const unsigned c_ = mt_ / per_clip_, r_ = mt_ - c_ * per_clip_;                              \
+                const unsigned sp_ = r_ / (unsigned)p.t_len, t_ = r_ - sp_ * (unsigned)p.t_len;              \
+                mt_ = c_ * per_clip_ + t_ * S_ + sp_;                                                        \
+            }                                                                                                \
+        }                                                                                                    \
+        m0 = (long long)mt_ * LM;                                                                            \
+        n0 = nt_ * LN;                                                                                       \
+        _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                   \
+            const long long m_ = m0 + ps * 64 + rbase;                                                       \
+            const bool ok_ = m_ < p.M;                                                                       \
+            const int mm_ = ok_ ? (int)m_ : 0;                                                               \
+            const int im_ = mm_ / hw_o; const int rem_ = mm_ - im_ * hw_o;                                   \
+            const int yo_ = rem_ / p.wo; const int xo_ = rem_ - yo_ * p.wo;                                  \
+            rimg[ps] = im_ - p.pad_t; rtl[ps] = im_ % p.t_len - p.pad_t;                                     \
+            rys[ps] = ok_ ? yo_ * p.stride - p.pad_h : -(1 << 28); rxs[ps] = xo_ * p.stride - p.pad_w;       \
+        }                                                                                                    \
+        wrow = p.w + ((long long)(n0 + rbase) * p.k_pad + slot_log * 8) * 2;                                 \
+        kdt = 0; kdy = 0; kdx = 0; ktap = 0; kc = 0; pix_valid = false;                                      \
     }
+
+    const unsigned wg = xcd_remap(blockIdx.x, gridDim.x);
+    unsigned tile = wg;
+    SETUP_TILE(tile)
     const int cin = p.c1 + p.c2;
     const int khw = p.kh * p.kw;
     const int ntaps = p.kt * khw;
     const int nk = p.k_pad / BK;
-    const char* wrow = p.w + ((long long)(n0 + rbase) * p.k_pad + slot_log * 8) * 2;
-
-    // k-step state (wave-uniform): tap (dt,dy,dx) and channel offset of the NEXT k-step to issue
-    int kdt = 0, kdy = 0, kdx = 0, ktap = 0, kc = 0;
-    int pix[4] = {-1, -1, -1, -1};
-    bool pix_valid = false;
 
 #define ISSUE_STAGE(STAGE)                                                                                   \
     {                                                                                                        \
@@ -589,6 +599,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
         const long long wk = (long long)ktap * cin + kc;                                                     \
         _Pragma("unroll") for (int ps = 0; ps < 4; ++ps)                                                     \
             dma16(wrow + ((long long)ps * 64 * p.k_pad + wk) * 2, sA + LA_BYTES + (ps * 512 + wave * 64) * 16); \
+        ADVANCE_K()                                                                                          \
+    }
+#define ADVANCE_K()                                                                                          \
+    {                                                                                                        \
         if (p.korder) {                          /* tap-innermost K order (see conv_gemm_kernel) */          \
             ++ktap;                                                                                          \
             if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } }                           \
@@ -601,12 +615,11 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
 
     const int wn = wave & 1, wm = wave >> 1;
     float16_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#define ZERO_ACC()                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                            \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    ZERO_ACC()
 
     // fragment addresses: row*128 + ((slot ^ sw) << 4); all 32-row tiles share sw = (l32>>1)&7
     const int sw = (l32 >> 1) & 7;
@@ -644,6 +657,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
         unsigned so[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) so[kk] = ((kk * 2 + hi32) ^ sw) << 4;
+        for (;;) {                                   // tiles of this workgroup (one iteration unless PERSIST)
         for (int ks = 0; ks < nk; ++ks) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
@@ -687,6 +701,41 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
         // the MFMAs issued last may still be in flight and the compiler cannot see them: cover the XDL-write ->
         // VALU-read hazard window before the epilogue touches the accumulators
         asm volatile("s_nop 15\ns_nop 15" ::: "memory");
+        const long long em0 = m0;
+        const int en0 = n0;
+        bool has_next = false;
+        if constexpr (PERSIST) {
+            // Stage `cur` was last read one k-step ago and every wave has passed a barrier since: it is free.  Fill it
+            // with k-step 0 of the next tile now; the epilogue below (global loads, ~800 VALU, stores) covers the flight.
+            const unsigned next = tile + gridDim.x;
+            has_next = next < p.ntiles;
+            if (has_next) {
+                tile = next;
+                SETUP_TILE(tile)
+                ISSUE_STAGE(cur)
+            }
+        }
+        if constexpr (DBG == 6) {          // ablation: no epilogue (one dword per lane keeps the accumulators alive)
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+            if (sum == 12345.678f) *(float*)p.out = sum;
+        } else {
+            conv_epilogue<4, 2>(p, acc, em0 + wm * 64, en0 + wn * 128, l32, hi32);
+        }
+        if (!has_next) break;
+        // The gather constants of the new tile are recomputed here instead of living through the epilogue (they cost
+        // ~22 VGPRs on top of its ~230 and spilled); the opaque `tile` keeps the compiler from reusing the first copy.
+        asm volatile("" : "+s"(tile));
+        SETUP_TILE(tile)
+        ADVANCE_K()                              // k-step 0 of this tile is already in flight
+        ZERO_ACC()
+        }
+        return;
     } else {
     for (int ks = 0; ks < nk; ++ks) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -716,18 +765,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
 #undef MFMA_SET
 #undef ISSUE_STAGE
 
-    if constexpr (DBG == 6) {          // ablation: no epilogue (one dword per lane keeps the accumulators alive)
-        float sum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
-        if (sum == 12345.678f) *(float*)p.out = sum;
-        return;
-    }
-    conv_epilogue<4, 2>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);
+#undef SETUP_TILE
+#undef ZERO_ACC
+#undef ADVANCE_K
+    conv_epilogue<4, 2>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);     // ablation builds (DBG 1-5)
 }
 
 
@@ -782,7 +823,9 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     if (force_tile < 0) { const char* e = getenv("UAV_CONV_TILE"); force_tile = e ? atoi(e) : 0; }
     const bool big = !small && (q->n_pad % LN == 0) && (force_tile >= 256 || (force_tile != 128 && grid256 >= 224));
     if (big) {
-        static int dbg = -1;
+        static int dbg = -1, persist = 0;
+        static long long ncu = 256;
+        a.ntiles = (unsigned)grid256;
         if (dbg < 0) {
             const char* e = getenv("UAV_CONV_DBG"); dbg = e ? atoi(e) : 0;
             (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
@@ -792,6 +835,10 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
             (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
             (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
             (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
+            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
+            const char* pe = getenv("UAV_CONV_PERSIST"); persist = pe ? atoi(pe) : 0;      // force for whole-model A/B runs
+            int dev = 0; hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
         }
         if (dbg == 1) hipLaunchKernelGGL(conv_gemm256_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 2) hipLaunchKernelGGL(conv_gemm256_kernel<2>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
@@ -799,7 +846,10 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         else if (dbg == 3) hipLaunchKernelGGL(conv_gemm256_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 5) hipLaunchKernelGGL(conv_gemm256_kernel<5>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 6) hipLaunchKernelGGL(conv_gemm256_kernel<6>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
-        else hipLaunchKernelGGL(conv_gemm256_kernel<0>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+        else if ((persist || (q->flags & UAV_CONV_PERSISTENT)) && grid256 > ncu) {
+            // persistent form: one workgroup per CU walks tiles wg, wg + ncu, ... (UAV_CONV_PERSIST=0 disables)
+            hipLaunchKernelGGL((conv_gemm256_kernel<0, 1>), dim3((unsigned)ncu), dim3(512), 2 * LSTAGE, s, a);
+        } else hipLaunchKernelGGL(conv_gemm256_kernel<0>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
     } else if (small)
         hipLaunchKernelGGL(conv_gemm_kernel<1>, dim3((unsigned)grid), dim3(256), 2 * STAGE_BYTES, s, a);
     else

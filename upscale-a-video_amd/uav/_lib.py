@@ -35,6 +35,7 @@ class ConvParams(C.Structure):
 
 CONV_GEGLU = 1
 CONV_OUT_F32 = 2
+CONV_PERSISTENT = 64
 CONV_RELU, CONV_SIGMOID, CONV_TANH = 4, 8, 16
 
 # name -> (restype, argtypes); the complete export list of include/uav_hip.h

@@ -163,7 +163,8 @@ def pack_conv(weight, bias=None, geglu=False, device=None, n_store_align=4):
 
 
 def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None,
-              rowbias=None, rows_per_batch=0, residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None):
+              rowbias=None, rows_per_batch=0, residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None,
+              persistent=False):
     """out[M][n_out] = scale*(conv(a1|a2, W) + bias + rowbias[m//rows_per_batch] + residual)."""
     lib = _lib.load()
     _req(a1, HALF, "a1")
@@ -190,7 +191,7 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
     n_out = wt.n_out
     if out is None:
         out = torch.empty((m, n_out), dtype=torch.float32 if out_f32 else HALF, device=a1.device)
-    flags = (_lib.CONV_GEGLU if wt.geglu else 0) | (_lib.CONV_OUT_F32 if out_f32 else 0)
+    flags = (_lib.CONV_GEGLU if wt.geglu else 0) | (_lib.CONV_OUT_F32 if out_f32 else 0) | (_lib.CONV_PERSISTENT if persistent else 0)
     p = _lib.ConvParams()
     p.a1 = _p(a1); p.a2 = _p(a2); p.c1 = c1; p.c2 = c2
     p.w = _p(wt.w); p.bias = _p(wt.bias)
