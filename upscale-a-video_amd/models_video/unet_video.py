@@ -211,8 +211,9 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
         src = self.__dict__.get("_ehs_src")
         if src is None or src[0] is not ehs or src[1] != ehs._version:
             rows = ehs.to(device=dev, dtype=torch.float16).reshape(-1, ehs.shape[-1]).contiguous()
-            self.__dict__["_ehs_src"] = (ehs, ehs._version, rows)
-        ehs_rows = self.__dict__["_ehs_src"][2]
+            src = (ehs, ehs._version, rows)
+            self.__dict__["_ehs_src"] = src
+        ehs_rows = src[2]                      # the local tuple, not the attribute: another stream's thread may have replaced it
         n_text = ehs.shape[1]
 
         # Classifier-free guidance feeds the same latents / low_res / timestep to both batch entries and only the
