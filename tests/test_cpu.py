@@ -245,6 +245,48 @@ def test_pack_conv_and_kernel_addressing_spec(cin, cout, k3, stride, ups, t_len)
     assert cw.n_pad % 128 == 0 and cw.k_pad % 64 == 0
 
 
+def test_tile_order_maps_are_bijections():
+    """Python mirror of the launch-order maps in csrc (uav_common.h:xcd_remap, conv_gemm.hip SETUP_TILE frame-fastest
+    order for temporal convs, persistent tile walk): every tile is produced exactly once."""
+    def xcd_remap(bid, nwg):
+        nx = 8
+        q, r = divmod(nwg, nx)
+        xcd, idx = bid % nx, bid // nx
+        base = xcd * (q + 1) if xcd < r else r * (q + 1) + (xcd - r) * q
+        return base + idx
+
+    for nwg in (1, 7, 8, 9, 255, 256, 257, 1000, 12800):
+        assert sorted(xcd_remap(b, nwg) for b in range(nwg)) == list(range(nwg))
+        # consecutive remapped ids sit on one XCD (hardware places block b on XCD b % 8)
+        by_xcd = {}
+        for b in range(nwg):
+            by_xcd.setdefault(b % 8, []).append(xcd_remap(b, nwg))
+        for ids in by_xcd.values():
+            assert ids == list(range(ids[0], ids[0] + len(ids)))
+
+    def temporal_order(mt, hw, t_len, lm=256):
+        if hw % lm:
+            return mt
+        s_ = hw // lm
+        per_clip = s_ * t_len
+        c, r = divmod(mt, per_clip)
+        sp, t = divmod(r, t_len)
+        return c * per_clip + t * s_ + sp
+
+    for (hw, t_len, clips) in ((160 * 160, 8, 2), (320 * 320, 8, 2), (80 * 80, 5, 3), (40 * 40, 8, 2), (256, 3, 1)):
+        n = clips * t_len * (-(-hw // 256))
+        got = sorted(temporal_order(m, hw, t_len) for m in range(n))
+        assert got == list(range(n)), (hw, t_len)
+        if hw % 256 == 0:                      # neighbours in launch order = same pixels, consecutive frames
+            a, b = temporal_order(0, hw, t_len), temporal_order(1, hw, t_len)
+            assert b - a == hw // 256
+
+    # persistent walk: workgroup wg of G handles wg, wg + G, ... < ntiles
+    for ntiles, g in ((12800, 256), (3201, 256), (257, 256)):
+        seen = sorted(t for wg in range(g) for t in range(wg, ntiles, g))
+        assert seen == list(range(ntiles))
+
+
 def test_cabi_rejects_bad_arguments_without_touching_the_gpu():
     """Error behaviour of the C ABI (include/uav_hip.h): argument checks return UAV_E* codes before any launch, so
     they can be exercised on a box without a GPU.  Pointers are dummies and are never dereferenced."""
