@@ -245,6 +245,32 @@ def test_pack_conv_and_kernel_addressing_spec(cin, cout, k3, stride, ups, t_len)
     assert cw.n_pad % 128 == 0 and cw.k_pad % 64 == 0
 
 
+def test_prompt_embedding_cache():
+    """one text-encoder pass per distinct (prompt, negative prompt), not one per pipeline call / tile."""
+    from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
+    from uav.standin_text import StandInTextEncoder, StandInTokenizer
+    tok = StandInTokenizer()
+    enc = StandInTextEncoder(tok, 64, dtype=torch.float32)
+    calls = []
+    orig = enc.forward
+    enc.forward = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    pipe = VideoUpscalePipeline(text_encoder=enc, tokenizer=tok)
+    a = pipe._cached_prompt_embeds("a city street", "cpu", 1, True, "blur")
+    b = pipe._cached_prompt_embeds("a city street", "cpu", 1, True, "blur")
+    assert a is b and a.shape == (2, 77, 64) and len(calls) == 2              # prompt + negative prompt, once
+    c = pipe._cached_prompt_embeds("a forest", "cpu", 1, True, "blur")
+    assert c is not a and not torch.equal(c, a) and len(calls) == 4
+    assert torch.equal(a, pipe._encode_prompt("a city street", "cpu", 1, True, "blur"))
+    pipe.cache_prompt_embeds = False
+    assert pipe._cached_prompt_embeds("a city street", "cpu", 1, True, "blur") is not a
+    # tensors passed in by the caller are never cached
+    pipe.cache_prompt_embeds = True
+    pe = torch.zeros(1, 77, 64)
+    n = len(pipe._prompt_cache)
+    pipe._cached_prompt_embeds(None, "cpu", 1, False, None, prompt_embeds=pe)
+    assert len(pipe._prompt_cache) == n
+
+
 def test_tile_order_maps_are_bijections():
     """Python mirror of the launch-order maps in csrc (uav_common.h:xcd_remap, conv_gemm.hip SETUP_TILE frame-fastest
     order for temporal convs, persistent tile walk): every tile is produced exactly once."""

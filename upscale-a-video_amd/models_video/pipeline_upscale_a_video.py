@@ -76,6 +76,8 @@ class VideoUpscalePipeline(ConfigMixin):
         # one LONG clip over several GPUs (BASELINE config 4): deal the temporal windows of each DDIM step and the decode
         # chunks over the ranks of the default process group; results are bit-identical to the single-GPU call
         self.shard_windows = False
+        self.cache_prompt_embeds = True
+        self._prompt_cache = {}
 
     def register_modules(self, **kwargs):
         for k, v in kwargs.items():
@@ -157,6 +159,30 @@ class VideoUpscalePipeline(ConfigMixin):
             prompt_embeds = torch.cat([negative_prompt_embeds, prompt_embeds])
         return prompt_embeds
 
+    def _cached_prompt_embeds(self, prompt, device, num_images_per_prompt, do_cfg, negative_prompt=None,
+                              prompt_embeds=None, negative_prompt_embeds=None):
+        """`_encode_prompt` with a small cache for string prompts: the CLI calls the pipeline once per
+        tile with the same prompt pair, and the reference runs the CLIP text encoder twice per call.  The key holds the
+        strings, the encoder / tokenizer objects and the current stream (an entry made on one stream is not handed to
+        another stream); `cache_prompt_embeds = False` restores one encode per call.  The returned tensor is the same
+        object on a hit, so the UNet's per-prompt text K/V caches hit as well."""
+        dev = torch.device(device)
+        cacheable = (self.cache_prompt_embeds and isinstance(prompt, str) and prompt_embeds is None
+                     and negative_prompt_embeds is None and (negative_prompt is None or isinstance(negative_prompt, str)))
+        if not cacheable:
+            return self._encode_prompt(prompt, device, num_images_per_prompt, do_cfg, negative_prompt,
+                                       prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds)
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        key = (prompt, negative_prompt, bool(do_cfg), int(num_images_per_prompt), str(dev), stream,
+               id(self.text_encoder), id(self.tokenizer))
+        hit = self._prompt_cache.get(key)
+        if hit is None:
+            hit = self._encode_prompt(prompt, device, num_images_per_prompt, do_cfg, negative_prompt)
+            if len(self._prompt_cache) >= 8:
+                self._prompt_cache.clear()
+            self._prompt_cache[key] = hit
+        return hit
+
     def check_inputs(self, prompt, image, noise_level, negative_prompt=None, prompt_embeds=None,
                      negative_prompt_embeds=None):
         if prompt is not None and prompt_embeds is not None:
@@ -222,8 +248,8 @@ class VideoUpscalePipeline(ConfigMixin):
         device = self._execution_device
         do_cfg = guidance_scale > 1.0
 
-        prompt_embeds = self._encode_prompt(prompt, device, num_images_per_prompt, do_cfg, negative_prompt,
-                                            prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds)
+        prompt_embeds = self._cached_prompt_embeds(prompt, device, num_images_per_prompt, do_cfg, negative_prompt,
+                                                   prompt_embeds, negative_prompt_embeds)
         draw_dtype = prompt_embeds.dtype          # the reference draws both noises in prompt_embeds.dtype (:547,:573)
         prompt_embeds = prompt_embeds.to(torch.float16).contiguous()
 
