@@ -168,7 +168,7 @@ def main():
         print(name, pin["cases"][name], flush=True)
 
     make_raft_goldens(ns, pin)
-    make_tile_goldens()
+    make_tile_goldens(ns, pin)
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
     print("wrote", GOLD)
 
@@ -248,11 +248,7 @@ def make_tile_goldens(ns=None, pin=None):
     import math
     import textwrap
     import types
-    src = open(os.path.join(ref_stubs.REFERENCE_ROOT, "inference_upscale_a_video.py")).read().split("\n")
-    start = next(i for i, l in enumerate(src) if l.strip() == "if args.perform_tile:" and "start_time" in src[i - 1])
-    indent = len(src[start]) - len(src[start].lstrip())
-    end = next(i for i in range(start + 1, len(src)) if src[i].strip() == "else:" and len(src[i]) - len(src[i].lstrip()) == indent)
-    body = textwrap.dedent("\n".join(src[start + 1:end]))
+    body = _cli_tile_loop_source()
     cases = {}
     for (h, w, tile) in TILE_CASES:
         calls = []
@@ -296,6 +292,66 @@ def make_tile_goldens(ns=None, pin=None):
         cases[f"{h}x{w}_tile{tile}"] = tiles
         print(f"tiles {h}x{w} tile {tile}: {len(tiles)} tiles", flush=True)
     json.dump(cases, open(os.path.join(GOLD, "cli_tiles.json"), "w"))
+    if ns is not None and pin is not None:
+        make_tiled_pipeline_golden(ns, pin)
+
+
+def _cli_tile_loop_source():
+    import textwrap
+    src = open(os.path.join(ref_stubs.REFERENCE_ROOT, "inference_upscale_a_video.py")).read().split("\n")
+    start = next(i for i, l in enumerate(src) if l.strip() == "if args.perform_tile:" and "start_time" in src[i - 1])
+    indent = len(src[start]) - len(src[start].lstrip())
+    end = next(i for i in range(start + 1, len(src)) if src[i].strip() == "else:" and len(src[i]) - len(src[i].lstrip()) == indent)
+    return textwrap.dedent("\n".join(src[start + 1:end]))
+
+
+def make_tiled_pipeline_golden(ns, pin):
+    """The reference CLI's tile loop (executed from /root/reference, not copied) around the reference's OWN pipeline
+    with the tiny seeded models: the tiled, stitched output for a 2-frame 68x160 clip at tile_size 64 (two tiles that
+    share one generator; H is not a multiple of 8).  The oracle replays it tile by tile -> PINNING.json, and a
+    sub-sampled image plus the full-resolution seam strip are stored as tests/golden/pipe_tiled_t2_68x160.pt."""
+    import contextlib
+    import io
+    import math
+    import types
+    unet = ns.unet_video.UNetVideoModel.from_config(dict(UNET_TINY)).eval()
+    usd = synth.synth_state_dict(unet.state_dict(), seed=1234)
+    unet.load_state_dict(usd, strict=True)
+    vae = ns.vae.AutoencoderKLVideo.from_config(dict(VAE3D_TINY)).eval()
+    vsd = synth.synth_state_dict(vae.state_dict(), seed=4321)
+    vae.load_state_dict(vsd, strict=True)
+    tok = _Tok()
+    pipe = ns.pipeline.VideoUpscalePipeline(
+        text_encoder=_TextEnc(tok, UNET_TINY["cross_attention_dim"]), tokenizer=tok,
+        low_res_scheduler=ref_stubs.DDPMScheduler(beta_schedule="scaled_linear", beta_start=0.0001, beta_end=0.02),
+        scheduler=ns.scheduling_ddim.DDIMScheduler(**SCHED), vae=vae, unet=unet, propagator=None)
+    t, h, w, tile = 2, 68, 160, 64
+    clip = synth.synth_clip(1, t, h, w, seed=33)
+    env = dict(args=types.SimpleNamespace(tile_size=tile, inference_steps=2, guidance_scale=6.0, noise_level=120, n_prompt="n",
+                                          propagation_steps=[]), vframes=clip, b=1, c=3, t=t, h=h, w=w, math=math, torch=torch,
+               pipeline=pipe, flows_bi=None, prompt="p", generator=torch.Generator().manual_seed(10), index_str="")
+    with contextlib.redirect_stdout(io.StringIO()):
+        exec(_cli_tile_loop_source(), env)
+    ref = env["output"]
+    # oracle: same loop, draws replayed from one generator in the pipeline's order (LR noise, then latents)
+    gen = torch.Generator().manual_seed(10)
+    dim = UNET_TINY["cross_attention_dim"]
+    pe = torch.cat([synth.synth_prompt_embeds("n", dim), synth.synth_prompt_embeds("p", dim)])
+    sys.path.insert(0, os.path.join(ROOT, "upscale-a-video_amd"))
+    from uav import tiling
+    mine = torch.zeros_like(ref)
+    for tl in tiling.tile_grid(h, w, tile):
+        sub = clip[:, :, :, tl.src[0]:tl.src[1], tl.src[2]:tl.src[3]]
+        lr_noise = torch.randn(sub.shape, generator=gen); lat0 = torch.randn((1, 4) + tuple(sub.shape[2:]), generator=gen)
+        with torch.no_grad():
+            oimg, _ = O.pipeline_call(usd, UNET_TINY, vsd, VAE3D_TINY, sub, pe, num_inference_steps=2, guidance_scale=6.0,
+                                      noise_level=120, lr_noise=lr_noise, latents=lat0, scheduler_kwargs=SCHED)
+        mine[:, :, :, tl.dst[0]:tl.dst[1], tl.dst[2]:tl.dst[3]] = oimg[:, :, :, tl.crop[0]:tl.crop[1], tl.crop[2]:tl.crop[3]]
+    pin["cases"]["pipe_tiled_t2_68x160"] = {"image_maxabs_oracle_vs_reference": maxabs(mine, ref),
+                                            "image_saturated_fraction": (ref.abs() >= 1).float().mean().item()}
+    torch.save({"sub4": ref[..., ::4, ::4].half(), "seam": ref[..., :, 240:272].half()},
+               os.path.join(GOLD, "pipe_tiled_t2_68x160.pt"))
+    print("pipe_tiled_t2_68x160", pin["cases"]["pipe_tiled_t2_68x160"], flush=True)
 
 
 def only(section):

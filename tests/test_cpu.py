@@ -463,6 +463,32 @@ def test_window_schedule_properties():
     check()
 
 
+def test_oracle_tiled_pipeline_vs_reference_cli_fixture(unet_sd):
+    """tests/golden/pipe_tiled_t2_68x160.pt: the reference CLI tile loop (executed from the reference tree) around the
+    reference pipeline, tiny seeded models; here the oracle replays it tile by tile with uav.tiling's boxes and the
+    shared generator's draw order."""
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from uav import tiling
+    vsd = synth.synth_state_dict(AutoencoderKLVideo.from_config(dict(GC.VAE3D_TINY)).state_dict(), seed=4321)
+    t, h, w, tile = 2, 68, 160, 64
+    clip = synth.synth_clip(1, t, h, w, seed=33)
+    gen = torch.Generator().manual_seed(10)
+    dim = GC.UNET_TINY["cross_attention_dim"]
+    pe = torch.cat([synth.synth_prompt_embeds("n", dim), synth.synth_prompt_embeds("p", dim)])
+    out = torch.zeros(1, 3, t, 4 * h, 4 * w)
+    for tl in tiling.tile_grid(h, w, tile):
+        sub = clip[:, :, :, tl.src[0]:tl.src[1], tl.src[2]:tl.src[3]]
+        lr_noise = torch.randn(sub.shape, generator=gen); lat0 = torch.randn((1, 4) + tuple(sub.shape[2:]), generator=gen)
+        with torch.no_grad():
+            img, _ = O.pipeline_call(unet_sd, GC.UNET_TINY, vsd, GC.VAE3D_TINY, sub, pe, num_inference_steps=2,
+                                     guidance_scale=6.0, noise_level=120, lr_noise=lr_noise, latents=lat0,
+                                     scheduler_kwargs=GC.SCHED)
+        out[:, :, :, tl.dst[0]:tl.dst[1], tl.dst[2]:tl.dst[3]] = img[:, :, :, tl.crop[0]:tl.crop[1], tl.crop[2]:tl.crop[3]]
+    gold = torch.load(os.path.join(GOLD, "pipe_tiled_t2_68x160.pt"))
+    assert (out[..., ::4, ::4] - gold["sub4"].float()).abs().max().item() < 2e-3        # fixture stored in fp16
+    assert (out[..., :, 240:272] - gold["seam"].float()).abs().max().item() < 2e-3      # across the tile seam at x = 256
+
+
 class _FakeTilePipeline:
     """CPU stand-in with the pipeline's draw order: LR noise, then latents, from the shared generator."""
 
