@@ -169,6 +169,7 @@ def main():
 
     make_raft_goldens(ns, pin)
     make_tile_goldens(ns, pin)
+    make_dup_tail_golden(ns, pin)
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
     print("wrote", GOLD)
 
@@ -354,14 +355,47 @@ def make_tiled_pipeline_golden(ns, pin):
     print("pipe_tiled_t2_68x160", pin["cases"]["pipe_tiled_t2_68x160"], flush=True)
 
 
+def make_dup_tail_golden(ns, pin):
+    """T = 14: the reference's window loop visits [0,8), [6,14) and then [6,14) AGAIN (the re-anchored tail, pipeline
+    :601-634) — the second visit re-blends frames 6..13 with themselves and their neighbours' running average, it is not
+    an identity.  Reference pipeline (tiny seeded models, 2 steps) vs the oracle; latents stored as the fixture."""
+    unet = ns.unet_video.UNetVideoModel.from_config(dict(UNET_TINY)).eval()
+    usd = synth.synth_state_dict(unet.state_dict(), seed=1234)
+    unet.load_state_dict(usd, strict=True)
+    vae = ns.vae.AutoencoderKLVideo.from_config(dict(VAE3D_TINY)).eval()
+    vsd = synth.synth_state_dict(vae.state_dict(), seed=4321)
+    vae.load_state_dict(vsd, strict=True)
+    tok = _Tok()
+    pipe = ns.pipeline.VideoUpscalePipeline(
+        text_encoder=_TextEnc(tok, UNET_TINY["cross_attention_dim"]), tokenizer=tok,
+        low_res_scheduler=ref_stubs.DDPMScheduler(beta_schedule="scaled_linear", beta_start=0.0001, beta_end=0.02),
+        scheduler=ns.scheduling_ddim.DDIMScheduler(**SCHED), vae=vae, unet=unet, propagator=None)
+    t, h, w = 14, 16, 16
+    clip = synth.synth_clip(1, t, h, w, seed=14)
+    gen = torch.Generator().manual_seed(10)
+    ref_img, ref_lat = pipe("p", image=clip, generator=gen, num_inference_steps=2, guidance_scale=6.0, noise_level=120,
+                            negative_prompt="n", return_dict=False)
+    gen = torch.Generator().manual_seed(10)
+    lr_noise = torch.randn(clip.shape, generator=gen); lat0 = torch.randn((1, 4, t, h, w), generator=gen)
+    dim = UNET_TINY["cross_attention_dim"]
+    pe = torch.cat([synth.synth_prompt_embeds("n", dim), synth.synth_prompt_embeds("p", dim)])
+    with torch.no_grad():
+        img, lat = O.pipeline_call(usd, UNET_TINY, vsd, VAE3D_TINY, clip, pe, num_inference_steps=2, guidance_scale=6.0,
+                                   noise_level=120, lr_noise=lr_noise, latents=lat0, scheduler_kwargs=SCHED)
+    pin["cases"]["pipe_t14_dup_tail"] = {"latents_maxabs_oracle_vs_reference": maxabs(lat, ref_lat),
+                                         "image_maxabs_oracle_vs_reference": maxabs(img, ref_img)}
+    torch.save({"latents": ref_lat.half()}, os.path.join(GOLD, "pipe_t14_dup_tail.pt"))
+    print("pipe_t14_dup_tail", pin["cases"]["pipe_t14_dup_tail"], flush=True)
+
+
 def only(section):
     """`python oracle/make_golden.py --raft | --unet`: regenerate one section's fixtures and PINNING.json entries."""
     torch.set_num_threads(8)
     ns = ref_stubs.import_reference()
     pin = json.load(open(os.path.join(GOLD, "PINNING.json")))
-    {"raft": make_raft_goldens, "unet": make_unet_goldens, "tiles": make_tile_goldens}[section](ns, pin)
+    {"raft": make_raft_goldens, "unet": make_unet_goldens, "tiles": make_tile_goldens, "pipe14": make_dup_tail_golden}[section](ns, pin)
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
-    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else only("tiles") if "--tiles" in sys.argv else main()
+    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else only("tiles") if "--tiles" in sys.argv else only("pipe14") if "--pipe14" in sys.argv else main()

@@ -489,6 +489,26 @@ def test_oracle_tiled_pipeline_vs_reference_cli_fixture(unet_sd):
     assert (out[..., :, 240:272] - gold["seam"].float()).abs().max().item() < 2e-3      # across the tile seam at x = 256
 
 
+def test_oracle_duplicate_tail_window_vs_reference_fixture(unet_sd):
+    """T = 14 visits window [6,14) twice (pipeline :601-634); the second visit re-blends, it is not an identity.
+    Fixture: the reference pipeline's latents (oracle/make_golden.py --pipe14)."""
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from models_video.pipeline_upscale_a_video import window_schedule
+    assert window_schedule(14) == [(0, 8), (6, 14), (6, 14)]
+    vsd = synth.synth_state_dict(AutoencoderKLVideo.from_config(dict(GC.VAE3D_TINY)).state_dict(), seed=4321)
+    t, h, w = 14, 16, 16
+    clip = synth.synth_clip(1, t, h, w, seed=14)
+    gen = torch.Generator().manual_seed(10)
+    lr_noise = torch.randn(clip.shape, generator=gen); lat0 = torch.randn((1, 4, t, h, w), generator=gen)
+    dim = GC.UNET_TINY["cross_attention_dim"]
+    pe = torch.cat([synth.synth_prompt_embeds("n", dim), synth.synth_prompt_embeds("p", dim)])
+    with torch.no_grad():
+        _, lat = O.pipeline_call(unet_sd, GC.UNET_TINY, vsd, GC.VAE3D_TINY, clip, pe, num_inference_steps=2, guidance_scale=6.0,
+                                 noise_level=120, lr_noise=lr_noise, latents=lat0, scheduler_kwargs=GC.SCHED)
+    gold = torch.load(os.path.join(GOLD, "pipe_t14_dup_tail.pt"))
+    assert rel_l2(lat, gold["latents"]) < 1e-3          # fixture stored in fp16
+
+
 class _FakeTilePipeline:
     """CPU stand-in with the pipeline's draw order: LR noise, then latents, from the shared generator."""
 

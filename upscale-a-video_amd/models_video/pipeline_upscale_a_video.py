@@ -259,6 +259,9 @@ class VideoUpscalePipeline(ConfigMixin):
         noise = randn_tensor(image.shape, generator=generator, device=device, dtype=draw_dtype).to(torch.float16)
         image = self.low_res_scheduler.add_noise(image, noise, torch.tensor([noise_level]))
         level = torch.tensor([noise_level if denoise_level is None else denoise_level], dtype=torch.long)
+        # reference quirk kept: the single-window branch (T <= 8) conditions the UNet on `noise_level` even when a
+        # `denoise_level` was passed (:638), only the sliding-window branch uses `denoise_level` (:628)
+        level_single = torch.tensor([noise_level], dtype=torch.long)
         if do_cfg:
             image = torch.cat([image] * 2)
 
@@ -306,7 +309,7 @@ class VideoUpscalePipeline(ConfigMixin):
                         else:                                                     # running 0.5/0.5 blend (:634)
                             eps[:, :, idx] = ops.axpby(eps[:, :, idx].contiguous(), o[:, :, k].contiguous(), 0.5, 0.5)
             else:
-                eps = self.unet(lin, t, image, encoder_hidden_states=prompt_embeds, class_labels=level,
+                eps = self.unet(lin, t, image, encoder_hidden_states=prompt_embeds, class_labels=level_single,
                                 cfg_shared_input=do_cfg and self.cfg_shared_input).sample
             eps = eps.contiguous()
             if do_cfg:
