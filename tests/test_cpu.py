@@ -509,6 +509,109 @@ def test_oracle_duplicate_tail_window_vs_reference_fixture(unet_sd):
     assert rel_l2(lat, gold["latents"]) < 1e-3          # fixture stored in fp16
 
 
+# ---------------------------------------------------------------------------------------------
+# 4c. the REAL VideoUpscalePipeline.__call__ host logic on CPU: HIP elementwise ops replaced by their torch equivalents
+#     (same arithmetic as csrc/elementwise.hip), UNet / VAE replaced by wrappers around the oracle's forward passes.
+#     This runs the window loop, blends, CFG / DDIM stepping, decode chunking and rank sharding of the product class.
+def _install_cpu_ops(ns):
+    from uav import ops
+
+    def axpby(x, z, a, b):
+        return (a * x.float() + b * z.float()).half()
+
+    def cfg_ddim_v0(eu, ec, sample, *, guidance, coef_sample, coef_eps, clip=False, clip_range=1.0):
+        g = eu.float() if ec is None else eu.float() + guidance * (ec.float() - eu.float())
+        g = g.half()
+        x0 = coef_sample * sample.float() + coef_eps * g.float()
+        if clip:
+            x0 = x0.clamp(-clip_range, clip_range)
+        return g, x0.half()
+
+    def ddim_vt(x0, guided, sample, *, coef_x0, coef_dir, eps_from_model, eps_from_sample, eps_from_x0=0.0, clip=False,
+                clip_range=1.0):
+        a = x0.float().clamp(-clip_range, clip_range) if clip else x0.float()
+        eps = eps_from_model * guided.float() + eps_from_sample * sample.float() + eps_from_x0 * a
+        return (coef_x0 * a + coef_dir * eps).half()
+    for name, fn in (("axpby", axpby), ("cfg_ddim_v0", cfg_ddim_v0), ("ddim_vt", ddim_vt)):
+        ns.setdefault("saved", {})[name] = getattr(ops, name)
+        setattr(ops, name, fn)
+
+
+def _restore_ops(ns):
+    from uav import ops
+    for name, fn in ns.get("saved", {}).items():
+        setattr(ops, name, fn)
+
+
+def _cpu_pipeline(unet_sd, vsd, calls=None):
+    import types
+    from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
+    from models_video.scheduling_ddim import DDIMScheduler, DDPMScheduler
+    from uav.standin_text import StandInTextEncoder, StandInTokenizer
+
+    class OracleUNet(torch.nn.Module):
+        config = types.SimpleNamespace(in_channels=7)
+
+        def forward(self, sample, t, low_res, encoder_hidden_states=None, class_labels=None, cfg_shared_input=False):
+            if calls is not None:
+                calls.append((tuple(sample.shape), int(class_labels.reshape(-1)[0])))
+            with torch.no_grad():
+                out = O.unet_forward(unet_sd, GC.UNET_TINY, sample.float(), int(t), low_res.float(),
+                                     encoder_hidden_states.float(), class_labels)
+            return types.SimpleNamespace(sample=out.half())
+
+    class OracleVAE(torch.nn.Module):
+        config = types.SimpleNamespace(scaling_factor=GC.VAE3D_TINY.get("scaling_factor", 0.08333), latent_channels=4, out_channels=3)
+
+        def decode(self, z, img, w_lr=1.0):
+            with torch.no_grad():
+                return types.SimpleNamespace(sample=O.vae_decode(vsd, GC.VAE3D_TINY, z.float(), img, w_lr))
+    tok = StandInTokenizer()
+    dim = GC.UNET_TINY["cross_attention_dim"]
+    pipe = VideoUpscalePipeline(text_encoder=StandInTextEncoder(tok, dim, dtype=torch.float32), tokenizer=tok,
+                                low_res_scheduler=DDPMScheduler(), scheduler=DDIMScheduler(**GC.SCHED), vae=OracleVAE(),
+                                unet=OracleUNet(), propagator=None)
+    return pipe.to("cpu")
+
+
+def _vae_sd():
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    return synth.synth_state_dict(AutoencoderKLVideo.from_config(dict(GC.VAE3D_TINY)).state_dict(), seed=4321)
+
+
+@pytest.mark.parametrize("t,denoise", [(14, None), (5, 77)])
+def test_pipeline_host_logic_on_cpu_vs_oracle(unet_sd, t, denoise):
+    """T = 14: sliding windows with the duplicate tail window; T = 5 with an explicit denoise_level: the single-window
+    branch must still condition on noise_level (reference :638).  Product pipeline class vs oracle pipeline."""
+    ns = {}
+    _install_cpu_ops(ns)
+    try:
+        vsd = _vae_sd()
+        calls = []
+        pipe = _cpu_pipeline(unet_sd, vsd, calls)
+        h, w = 16, 16
+        clip = synth.synth_clip(1, t, h, w, seed=14)
+        out, lat = pipe("p", image=clip, generator=torch.Generator().manual_seed(10), num_inference_steps=2, guidance_scale=6.0,
+                        noise_level=120, denoise_level=denoise, negative_prompt="n", return_dict=False)
+        gen = torch.Generator().manual_seed(10)
+        lr_noise = torch.randn(clip.shape, generator=gen); lat0 = torch.randn((1, 4, t, h, w), generator=gen)
+        dim = GC.UNET_TINY["cross_attention_dim"]
+        pe = torch.cat([synth.synth_prompt_embeds("n", dim), synth.synth_prompt_embeds("p", dim)])
+        with torch.no_grad():
+            oimg, olat = O.pipeline_call(unet_sd, GC.UNET_TINY, vsd, GC.VAE3D_TINY, clip, pe, num_inference_steps=2,
+                                         guidance_scale=6.0, noise_level=120, lr_noise=lr_noise, latents=lat0,
+                                         scheduler_kwargs=GC.SCHED)
+        assert out.shape == (1, 3, t, 4 * h, 4 * w) and out.dtype == torch.float32
+        assert rel_l2(lat, olat) < 2e-2                 # fp16 latents between steps on the product side
+        if t > 8:
+            assert len(calls) == 2 * 2                  # 2 unique windows x 2 steps: the duplicate is not re-evaluated
+            assert all(shape[2] == 8 for shape, _ in calls)
+        else:
+            assert [lvl for _, lvl in calls] == [120, 120]     # not 77
+    finally:
+        _restore_ops(ns)
+
+
 class _FakeTilePipeline:
     """CPU stand-in with the pipeline's draw order: LR noise, then latents, from the shared generator."""
 
@@ -559,6 +662,7 @@ def test_upscale_tiled_serial_equals_cli_loop():
 def _dist_worker(rank, world, port, q):
     os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     sys.path.insert(0, os.path.join(ROOT, "upscale-a-video_amd"))
+    torch.set_num_threads(max(1, min(4, (os.cpu_count() or 2) // 2)))     # two workers share the host
     from uav import dist as D
     w, r, _ = D.init("gloo")
     clips = list(range(7))
@@ -601,8 +705,25 @@ def _dist_worker(rank, world, port, q):
     pipe = _FakeTilePipeline()
     tiled = tiling.upscale_tiled(pipe, "p", vframes, None, torch.Generator().manual_seed(10), tile_size=64)
     tiles_same = torch.equal(tiled, _serial_cli_loop(pipe, vframes, torch.Generator().manual_seed(10), 64))
+    # --- the REAL pipeline class with shard_windows over the two ranks (CPU ops, oracle-backed UNet / VAE) ---
+    from models_video.unet_video import UNetVideoModel
+    usd = synth.synth_state_dict(UNetVideoModel.from_config(dict(GC.UNET_TINY)).state_dict(), seed=1234)
+    vsd = _vae_sd()
+    ns = {}
+    _install_cpu_ops(ns)
+    ucalls = []
+    rp = _cpu_pipeline(usd, vsd, ucalls)
+    clip14 = synth.synth_clip(1, 14, 16, 16, seed=14)
+    kw14 = dict(image=clip14, num_inference_steps=2, guidance_scale=6.0, noise_level=120, negative_prompt="n", return_dict=False)
+    img_serial, lat_serial = rp("p", generator=torch.Generator().manual_seed(10), **kw14)
+    n_serial = len(ucalls)
+    rp.shard_windows = True
+    img_shard, lat_shard = rp("p", generator=torch.Generator().manual_seed(10), **kw14)
+    pipe_same = torch.equal(img_serial, img_shard) and torch.equal(lat_serial, lat_shard)
+    n_shard = len(ucalls) - n_serial
+    _restore_ops(ns)
     q.put((r, mine, elapsed, total, gathered, torch.equal(sharded, serial), n_local, len(uniq),
-           [float(c.flatten()[0]) for c in chunks], float(single[0][0]), tiles_same))
+           [float(c.flatten()[0]) for c in chunks], float(single[0][0]), tiles_same, pipe_same, n_serial, n_shard))
     D.finalize()
 
 
@@ -624,7 +745,9 @@ def test_dist_gloo_world2():
     assert g0 == [[0, 2, 4, 6], [1, 3, 5]] and g1 is None
     # window-sharded long clip: bit-identical to the serial schedule on BOTH ranks, each rank ran only its share
     for x in (x0, x1):
-        same, n_local, n_uniq, chunk_ids, single, tiles_same = x
+        same, n_local, n_uniq, chunk_ids, single, tiles_same, pipe_same, n_serial, n_shard = x
         assert tiles_same                          # tile-sharded clip == serial CLI loop, on both ranks
+        assert pipe_same                           # VideoUpscalePipeline(shard_windows=True) == serial call, bit for bit
+        assert n_serial == 4 and n_shard == 2      # 2 unique windows x 2 steps; each rank evaluates one window per step
         assert same and n_uniq == 5 and chunk_ids == [float(s) for s in range(0, 32, 3)] and single == 5.0
     assert x0[1] == 3 and x1[1] == 2           # 5 unique windows dealt 3 / 2
