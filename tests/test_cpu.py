@@ -612,6 +612,25 @@ def test_pipeline_host_logic_on_cpu_vs_oracle(unet_sd, t, denoise):
         _restore_ops(ns)
 
 
+def test_upscale_tiled_with_real_pipeline_on_cpu_vs_reference_fixture(unet_sd):
+    """uav.tiling.upscale_tiled driving the product pipeline class (CPU stand-ins as above) against the fixture made by
+    the reference CLI loop + reference pipeline: tile boxes, shared-generator draw order and stitching, end to end."""
+    from uav import tiling
+    ns = {}
+    _install_cpu_ops(ns)
+    try:
+        pipe = _cpu_pipeline(unet_sd, _vae_sd())
+        clip = synth.synth_clip(1, 2, 68, 160, seed=33)
+        out = tiling.upscale_tiled(pipe, "p", clip, None, torch.Generator().manual_seed(10), tile_size=64,
+                                   num_inference_steps=2, guidance_scale=6.0, noise_level=120, negative_prompt="n")
+        gold = torch.load(os.path.join(GOLD, "pipe_tiled_t2_68x160.pt"))
+        for mine, ref in ((out[..., ::4, ::4], gold["sub4"].float()), (out[..., :, 240:272], gold["seam"].float())):
+            unsat = ref.abs() < 0.999
+            assert rel_l2(mine[unsat], ref[unsat]) < 3e-2          # fp16 latents between DDIM steps on the product side
+    finally:
+        _restore_ops(ns)
+
+
 class _FakeTilePipeline:
     """CPU stand-in with the pipeline's draw order: LR noise, then latents, from the shared generator."""
 
