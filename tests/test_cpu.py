@@ -543,7 +543,7 @@ def _restore_ops(ns):
         setattr(ops, name, fn)
 
 
-def _cpu_pipeline(unet_sd, vsd, calls=None):
+def _cpu_pipeline(unet_sd, vsd, calls=None, vae_cfg=None, propagator=None):
     import types
     from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
     from models_video.scheduling_ddim import DDIMScheduler, DDPMScheduler
@@ -560,17 +560,19 @@ def _cpu_pipeline(unet_sd, vsd, calls=None):
                                      encoder_hidden_states.float(), class_labels)
             return types.SimpleNamespace(sample=out.half())
 
+    vcfg = vae_cfg or GC.VAE3D_TINY
+
     class OracleVAE(torch.nn.Module):
-        config = types.SimpleNamespace(scaling_factor=GC.VAE3D_TINY.get("scaling_factor", 0.08333), latent_channels=4, out_channels=3)
+        config = types.SimpleNamespace(scaling_factor=vcfg.get("scaling_factor", 0.08333), latent_channels=4, out_channels=3)
 
         def decode(self, z, img, w_lr=1.0):
             with torch.no_grad():
-                return types.SimpleNamespace(sample=O.vae_decode(vsd, GC.VAE3D_TINY, z.float(), img, w_lr))
+                return types.SimpleNamespace(sample=O.vae_decode(vsd, vcfg, z.float(), img, w_lr))
     tok = StandInTokenizer()
     dim = GC.UNET_TINY["cross_attention_dim"]
     pipe = VideoUpscalePipeline(text_encoder=StandInTextEncoder(tok, dim, dtype=torch.float32), tokenizer=tok,
                                 low_res_scheduler=DDPMScheduler(), scheduler=DDIMScheduler(**GC.SCHED), vae=OracleVAE(),
-                                unet=OracleUNet(), propagator=None)
+                                unet=OracleUNet(), propagator=propagator)
     return pipe.to("cpu")
 
 
@@ -608,6 +610,37 @@ def test_pipeline_host_logic_on_cpu_vs_oracle(unet_sd, t, denoise):
             assert all(shape[2] == 8 for shape, _ in calls)
         else:
             assert [lvl for _, lvl in calls] == [120, 120]     # not 77
+    finally:
+        _restore_ops(ns)
+
+
+def test_pipeline_host_logic_with_propagation_vs_reference_fixture(unet_sd):
+    """BASELINE config-3 flow on the product pipeline class (CPU stand-ins): T = 10 (two windows), video VAE, latent
+    propagation at DDIM step 1 through the propagator call protocol (pipeline :655-657) — against the fixture produced
+    by the reference pipeline itself (tests/golden/pipe_t10_vaevideo_prop.pt)."""
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    case = GC.PIPE_CASES["pipe_t10_vaevideo_prop"]
+    vsd = synth.synth_state_dict(AutoencoderKLVideo.from_config(dict(GC.VAEVIDEO_TINY)).state_dict(), seed=4321)
+    seen = []
+
+    class OraclePropagator(torch.nn.Module):
+        def forward(self, x0, flows_f, flows_b, interpolation="nearest", mode="fuse", fuse_scale=0.5, alpha1=0.001, alpha2=0.05):
+            seen.append((interpolation, mode, fuse_scale, alpha1, alpha2, tuple(flows_f.shape)))
+            with torch.no_grad():
+                return O.propagation(x0.float(), flows_f.float(), flows_b.float(), interpolation, fuse_scale, alpha1, alpha2).half()
+    ns = {}
+    _install_cpu_ops(ns)
+    try:
+        pipe = _cpu_pipeline(unet_sd, vsd, vae_cfg=GC.VAEVIDEO_TINY, propagator=OraclePropagator())
+        image, flows = GC.pipeline_inputs(case)
+        out, lat = pipe(case["prompt"], image=image, flows_bi=flows, generator=torch.Generator().manual_seed(10),
+                        num_inference_steps=case["steps"], guidance_scale=case["guidance"], noise_level=case["noise_level"],
+                        negative_prompt=case["negative"], propagation_steps=list(case["propagation_steps"]), return_dict=False)
+        gold = torch.load(os.path.join(GOLD, "pipe_t10_vaevideo_prop.pt"))
+        assert seen == [("nearest", "fuse", 0.5, 0.001, 0.05, tuple(flows[0].shape))]       # once, at step 1
+        assert rel_l2(lat, gold["latents"]) < 2e-2
+        unsat = gold["images"].float().abs() < 0.999
+        assert rel_l2(out[unsat], gold["images"].float()[unsat]) < 4e-2
     finally:
         _restore_ops(ns)
 
