@@ -1,0 +1,208 @@
+"""TEST INFRASTRUCTURE ONLY — torch/CPU stand-ins for the entry points of `uav.ops`.
+
+The product has no CPU path (`uav.ops` raises without the HIP library and a GPU, tests/test_cpu.py::test_no_cpu_fallback).
+To exercise the HOST side of the engine — weight packing, the module orchestration in `models_video/*` (skip stack,
+concatenation by two source pointers, forced upsample size, CFG-shared head, fused projections, GEGLU row order,
+window / chunk loops of the pipeline) — on a box without a GPU, `install()` swaps the ops the models call for the
+functions below, which follow the kernels' contracts (include/uav_hip.h): same packed-weight layout, same row
+layouts, fp32 arithmetic, fp16 rounding of every stored tensor.  `restore()` puts the real entry points back.
+Nothing under `upscale-a-video_amd/` imports this file.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+HALF = torch.float16
+_SAVED = {}
+
+
+def _h(x):
+    return x.to(HALF)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def conv_gemm(a1, wt, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None, rowbias=None, rows_per_batch=0,
+              residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None, persistent=False):
+    c1 = a1.shape[-1]
+    c2 = 0 if a2 is None else a2.shape[-1]
+    assert c1 + c2 == wt.cin_p, (c1, c2, wt.cin_p)
+    assert a1.dtype == HALF and a1.numel() == n_img * hi * wi * c1
+    if pad is None:
+        pad = (wt.kt // 2, wt.kh // 2, wt.kw // 2)
+    pt, ph, pw = pad
+    x = a1.float() if a2 is None else torch.cat([a1.float(), a2.float()], dim=-1)
+    nb = n_img // t_len
+    x = x.reshape(nb, t_len, hi, wi, wt.cin_p).permute(0, 4, 1, 2, 3)                 # (B, C, T, H, W)
+    if upsample:
+        x = F.interpolate(x, scale_factor=[1.0, 2.0, 2.0], mode="nearest")
+        ho, wo = 2 * hi, 2 * wi
+    else:
+        ho = (hi + 2 * ph - wt.kh) // stride + 1
+        wo = (wi + 2 * pw - wt.kw) // stride + 1
+    if out_hw is not None:                                                            # taps past the edge read zeros
+        ho, wo = out_hw
+    hin, win = x.shape[-2:]
+    need_h = (ho - 1) * stride + wt.kh - 2 * ph
+    need_w = (wo - 1) * stride + wt.kw - 2 * pw
+    if need_h > hin or need_w > win:
+        x = F.pad(x, (0, max(0, need_w - win), 0, max(0, need_h - hin)))
+    ntaps = wt.kt * wt.kh * wt.kw
+    w = wt.w[: wt.n, : ntaps * wt.cin_p].float().reshape(wt.n, wt.kt, wt.kh, wt.kw, wt.cin_p).permute(0, 4, 1, 2, 3)
+    y = F.conv3d(x, w, None, stride=(1, stride, stride), padding=(pt, ph, pw))[..., :ho, :wo]
+    assert y.shape[2:] == (t_len, ho, wo), (y.shape, t_len, ho, wo)
+    y = y.permute(0, 2, 3, 4, 1).reshape(n_img * ho * wo, wt.n)
+    m = y.shape[0]
+    if wt.bias is not None:
+        y = y + wt.bias[: wt.n].float()
+    if rowbias is not None:
+        idx = torch.arange(m) // rows_per_batch
+        y = y + rowbias.float()[idx, : wt.n]
+    if wt.geglu:
+        yb = y.reshape(m, wt.n // 64, 2, 32)                                          # [32 value | 32 gate] blocks
+        y = (yb[:, :, 0] * F.gelu(yb[:, :, 1])).reshape(m, wt.n // 2)
+    if residual is not None:
+        assert residual.shape[0] == m
+        y = y + residual.float()[:, : y.shape[1]]
+    y = y * out_scale
+    res = y if out_f32 else _h(y)
+    if out is not None:                      # the kernel writes n_out columns of a possibly wider row (out_stride)
+        out[:, : res.shape[1]].copy_(res)
+        return out
+    return res
+
+
+def _factor_rows(m):
+    return 1, m
+
+
+def linear(x, wt, *, residual=None, out_scale=1.0, rowbias=None, rows_per_batch=0, out_f32=False):
+    return conv_gemm(x, wt, n_img=1, t_len=1, hi=x.shape[0], wi=1, residual=residual, out_scale=out_scale, rowbias=rowbias,
+                     rows_per_batch=rows_per_batch, out_f32=out_f32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def groupnorm(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps, silu, x2=None, c_real=None):
+    x = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], dim=-1)
+    c = x.shape[-1]
+    c_real = c if c_real is None else c_real
+    xr = x[:, :c_real].reshape(n_inst, rows_per_inst, groups, c_real // groups).double()
+    mean = xr.mean(dim=(1, 3), keepdim=True)
+    var = xr.var(dim=(1, 3), unbiased=False, keepdim=True)
+    y = ((xr - mean) / torch.sqrt(var + eps)).float().reshape(n_inst * rows_per_inst, c_real)
+    y = y * gamma.float()[:c_real] + beta.float()[:c_real]
+    if silu:
+        y = F.silu(y)
+    if c_real < c:
+        y = F.pad(y, (0, c - c_real))
+    return _h(y)
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    return _h(F.layer_norm(x.float(), (x.shape[-1],), gamma.float(), beta.float(), eps))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def attention(q, k, v, *, bq, lq, lk, heads, head_dim, q_per_kv=1, scale=None, q_stride=None, k_stride=None, v_stride=None):
+    c = heads * head_dim
+    scale = head_dim ** -0.5 if scale is None else scale
+    qh = q.float().reshape(bq, lq, heads, head_dim).permute(0, 2, 1, 3)
+    kh = k.float().reshape(bq // q_per_kv, lk, heads, head_dim).repeat_interleave(q_per_kv, 0).permute(0, 2, 1, 3)
+    vh = v.float().reshape(bq // q_per_kv, lk, heads, head_dim).repeat_interleave(q_per_kv, 0).permute(0, 2, 1, 3)
+    p = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
+    return _h((p @ vh).permute(0, 2, 1, 3).reshape(bq * lq, c))
+
+
+def temporal_attention(qkv, *, n_batch, t_len, hw, c, heads, scale, rope_cos, rope_sin, rot_dim, bias):
+    d = c // heads
+    x = qkv.float().reshape(n_batch, t_len, hw, 3, heads, d)
+    q, k, v = x[:, :, :, 0], x[:, :, :, 1], x[:, :, :, 2]                             # (B, T, P, H, d)
+    q = q * scale
+
+    def rope(t):
+        if rot_dim == 0:
+            return t
+        cos = rope_cos.float()[:t_len].reshape(1, t_len, 1, 1, rot_dim // 2)
+        sin = rope_sin.float()[:t_len].reshape(1, t_len, 1, 1, rot_dim // 2)
+        a, b = t[..., 0:rot_dim:2], t[..., 1:rot_dim:2]
+        r = torch.stack([a * cos - b * sin, b * cos + a * sin], dim=-1).reshape(t.shape[:-1] + (rot_dim,))
+        return torch.cat([r, t[..., rot_dim:]], dim=-1)
+    q, k = _h(rope(q)).float(), _h(rope(k)).float()                                   # rotary output is fp16 (as the kernel)
+    q, k, v = (t.permute(0, 2, 3, 1, 4) for t in (q, k, v))                           # (B, P, H, T, d)
+    s = q @ k.transpose(-1, -2) + bias.float().reshape(1, 1, heads, t_len, t_len)
+    p = torch.softmax(s, dim=-1)
+    o = (p @ v).permute(0, 3, 1, 2, 4).reshape(n_batch * t_len * hw, c)               # rows (b, t, p)
+    return _h(o)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def linear_small(x, w, b, *, pre_silu=False, post_silu=False):
+    x = F.silu(x.float()) if pre_silu else x.float()
+    y = x @ w.float().t() + (0 if b is None else b.float())
+    return F.silu(y) if post_silu else y
+
+
+def timestep_embedding(t, dim, flip_sin_to_cos=True, freq_shift=0.0):
+    half = dim // 2
+    expo = -math.log(10000.0) * torch.arange(half, dtype=torch.float32) / (half - freq_shift)
+    arg = t.float()[:, None] * torch.exp(expo)[None, :]
+    sn, cs = torch.sin(arg), torch.cos(arg)
+    return torch.cat([cs, sn], dim=-1) if flip_sin_to_cos else torch.cat([sn, cs], dim=-1)
+
+
+def pack_nhwc(src1, src2=None, c_pad=8, scale=1.0):
+    x = src1.float() if src2 is None else torch.cat([src1.float(), src2.float()], dim=1)
+    b, c, t, h, w = x.shape
+    rows = (x * scale).permute(0, 2, 3, 4, 1).reshape(b * t * h * w, c)
+    return _h(F.pad(rows, (0, c_pad - c)))
+
+
+def unpack_ncthw(src, *, c, n_batch, t_len, h, w, out_dtype=HALF, clamp=None):
+    x = src.float()[:, :c].reshape(n_batch, t_len, h, w, c).permute(0, 4, 1, 2, 3)
+    if clamp is not None:
+        x = x.clamp(clamp[0], clamp[1])
+    return x.to(out_dtype).contiguous()
+
+
+def axpby(x, z, a, b):
+    return _h(a * x.float() + b * z.float())
+
+
+def cfg_ddim_v0(eu, ec, sample, *, guidance, coef_sample, coef_eps, clip=False, clip_range=1.0):
+    g = eu.float() if ec is None else eu.float() + guidance * (ec.float() - eu.float())
+    g = _h(g)
+    x0 = coef_sample * sample.float() + coef_eps * g.float()
+    if clip:
+        x0 = x0.clamp(-clip_range, clip_range)
+    return g, _h(x0)
+
+
+def ddim_vt(x0, guided, sample, *, coef_x0, coef_dir, eps_from_model, eps_from_sample, eps_from_x0=0.0, clip=False,
+            clip_range=1.0):
+    a = x0.float().clamp(-clip_range, clip_range) if clip else x0.float()
+    eps = eps_from_model * guided.float() + eps_from_sample * sample.float() + eps_from_x0 * a
+    return _h(coef_x0 * a + coef_dir * eps)
+
+
+_OPS = ("conv_gemm", "linear", "groupnorm", "layernorm", "attention", "temporal_attention", "linear_small",
+        "timestep_embedding", "pack_nhwc", "unpack_ncthw", "axpby", "cfg_ddim_v0", "ddim_vt")
+
+
+def install():
+    """Swap the uav.ops entry points (and the engine's device check) for the CPU stand-ins.  Not re-entrant."""
+    from uav import engine, ops
+    assert not _SAVED, "cpu_ops.install() is already active"
+    for name in _OPS:
+        _SAVED[name] = getattr(ops, name)
+        setattr(ops, name, globals()[name])
+    _SAVED["_dev"] = engine._dev
+    engine._dev = lambda p: p.device
+
+
+def restore():
+    from uav import engine, ops
+    for name in _OPS:
+        if name in _SAVED:
+            setattr(ops, name, _SAVED.pop(name))
+    if "_dev" in _SAVED:
+        engine._dev = _SAVED.pop("_dev")

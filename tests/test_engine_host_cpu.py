@@ -1,0 +1,114 @@
+"""Host side of the engine on a box WITHOUT a GPU: the product modules (`models_video.UNetVideoModel`,
+`AutoencoderKLVideo`, `VideoUpscalePipeline`) run with the `uav.ops` entry points swapped for the torch stand-ins of
+tests/cpu_ops.py, and are compared with the oracle / the reference fixtures.  What this covers is everything that is NOT
+a kernel: weight packing (`pack_conv`, fused q|k|v rows, GEGLU interleave), the module orchestration (skip stack, two
+source pointers instead of concatenation, forced upsample size, CFG-shared head, text K/V cache), layout conversion and
+the pipeline loops.  The kernels themselves are covered by the `-m gpu` tests through the C ABI.
+
+Tolerance: the stand-ins round every stored tensor to fp16 like the kernels do, so the distance to the fp32 oracle is
+the same fp16 noise as on the GPU (2.2e-3 there): asserted <= the reference's own fp16 deviation (PINNING.json).
+"""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import cpu_ops  # noqa: E402
+import golden_cases as GC  # noqa: E402
+import synth  # noqa: E402
+import uav_oracle as O  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def rel_l2(a, b):
+    return ((a.float() - b.float()).norm() / (b.float().norm() + 1e-12)).item()
+
+
+@pytest.fixture()
+def cpu_engine():
+    cpu_ops.install()
+    try:
+        yield
+    finally:
+        cpu_ops.restore()
+
+
+@pytest.fixture(scope="module")
+def unet_and_sd():
+    from models_video.unet_video import UNetVideoModel
+    unet = UNetVideoModel.from_config(dict(GC.UNET_TINY))
+    usd = synth.synth_state_dict(unet.state_dict(), seed=1234)
+    unet.load_state_dict(usd, strict=True)
+    return unet.eval(), usd
+
+
+@pytest.mark.parametrize("name,shape", [("unet_t4_16", (2, 4, 16, 16)), ("unet_t3_20x28", (2, 3, 20, 28))])
+def test_unet_forward_host_side(cpu_engine, unet_and_sd, name, shape):
+    unet, usd = unet_and_sd
+    sample, low, ehs, ts, cl = GC.unet_inputs(*shape, GC.UNET_TINY["cross_attention_dim"])
+    with torch.no_grad():
+        out = unet(sample.half(), ts, low.half(), encoder_hidden_states=ehs.half(), class_labels=cl).sample
+    gold = torch.load(os.path.join(GOLD, name + ".pt"))
+    noise = json.load(open(os.path.join(GOLD, "PINNING.json")))["cases"][name]["reference_fp16_vs_fp32_rel_l2"]
+    assert out.shape == gold.shape and out.dtype == torch.float16
+    assert rel_l2(out, gold) <= noise, (rel_l2(out, gold), noise)
+
+
+def test_unet_cfg_shared_head_host_side(cpu_engine, unet_and_sd):
+    unet, _ = unet_and_sd
+    sample, low, ehs, ts, cl = GC.unet_inputs(1, 3, 16, 16, GC.UNET_TINY["cross_attention_dim"])
+    g = torch.Generator().manual_seed(11)
+    ehs2 = torch.cat([ehs, torch.randn(ehs.shape, generator=g)]).half()
+    s2, l2 = torch.cat([sample] * 2).half(), torch.cat([low] * 2).half()
+    with torch.no_grad():
+        a = unet(s2, ts, l2, encoder_hidden_states=ehs2, class_labels=cl).sample
+        b = unet(s2, ts, l2, encoder_hidden_states=ehs2, class_labels=cl, cfg_shared_input=True).sample
+    # bit-identical on the GPU (tests/test_models_gpu.py).  ATen's CPU convs block batch 1 and batch 2 differently: a
+    # last-bit fp32 difference flips a few fp16 roundings in the head and those grow to the usual fp16 noise level
+    assert rel_l2(a, b) < 5e-3 and rel_l2(a[0], a[1]) > 2e-2
+
+
+@pytest.mark.parametrize("name,cfg", [("vae3d", GC.VAE3D_TINY), ("vaevideo", GC.VAEVIDEO_TINY)])
+def test_vae_decode_host_side(cpu_engine, name, cfg):
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    vae = AutoencoderKLVideo.from_config(dict(cfg))
+    vsd = synth.synth_state_dict(vae.state_dict(), seed=4321)
+    vae.load_state_dict(vsd, strict=True)
+    z, img = GC.vae_inputs(1, 3, 16, 16)
+    with torch.no_grad():
+        out = vae.eval().decode(z, img, 1.0).sample
+    gold = torch.load(os.path.join(GOLD, name + "_t3_16.pt"))
+    assert out.shape == gold.shape and out.dtype == torch.float32
+    assert rel_l2(out, gold) < 5e-3
+
+
+def test_pipeline_end_to_end_host_side(cpu_engine, unet_and_sd):
+    """The whole product stack (pipeline + UNetVideoModel + AutoencoderKLVideo + schedulers) on the CPU stand-ins
+    against the reference pipeline's fixture pipe_t8_vae3d (3 DDIM steps, guidance 6)."""
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
+    from models_video.scheduling_ddim import DDIMScheduler, DDPMScheduler
+    from uav.standin_text import StandInTextEncoder, StandInTokenizer
+    unet, _ = unet_and_sd
+    case = GC.PIPE_CASES["pipe_t8_vae3d"]
+    vae = AutoencoderKLVideo.from_config(dict(GC.VAE3D_TINY))
+    vae.load_state_dict(synth.synth_state_dict(vae.state_dict(), seed=4321), strict=True)
+    tok = StandInTokenizer()
+    pipe = VideoUpscalePipeline(text_encoder=StandInTextEncoder(tok, GC.UNET_TINY["cross_attention_dim"], dtype=torch.float32),
+                                tokenizer=tok, low_res_scheduler=DDPMScheduler(), scheduler=DDIMScheduler(**GC.SCHED),
+                                vae=vae.eval(), unet=unet, propagator=None).to("cpu")
+    image, _ = GC.pipeline_inputs(case)
+    out, lat = pipe(case["prompt"], image=image, generator=torch.Generator().manual_seed(10), num_inference_steps=case["steps"],
+                    guidance_scale=case["guidance"], noise_level=case["noise_level"], negative_prompt=case["negative"],
+                    return_dict=False)
+    gold = torch.load(os.path.join(GOLD, "pipe_t8_vae3d.pt"))
+    assert out.shape == gold["images"].shape and out.dtype == torch.float32 and float(out.abs().max()) <= 1.0
+    assert rel_l2(lat, gold["latents"]) < 1e-2                      # same bar as the GPU test
+    unsat = gold["images"].float().abs() < 0.999
+    assert rel_l2(out[unsat], gold["images"].float()[unsat]) < 3e-2
