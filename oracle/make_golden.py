@@ -170,6 +170,7 @@ def main():
     make_raft_goldens(ns, pin)
     make_tile_goldens(ns, pin)
     make_dup_tail_golden(ns, pin)
+    make_vae_wlr_golden(ns, pin)
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
     print("wrote", GOLD)
 
@@ -388,14 +389,30 @@ def make_dup_tail_golden(ns, pin):
     print("pipe_t14_dup_tail", pin["cases"]["pipe_t14_dup_tail"], flush=True)
 
 
+def make_vae_wlr_golden(ns, pin):
+    """`w_lr` != 1: weight of the low-resolution conditioning in the video VAE's SFT blocks (vae.decode(z, img, w_lr),
+    pipeline :352); the CLI leaves it at 1, the argument is public."""
+    vae = ns.vae.AutoencoderKLVideo.from_config(dict(VAEVIDEO_TINY)).eval()
+    vsd = synth.synth_state_dict(vae.state_dict(), seed=4321)
+    vae.load_state_dict(vsd, strict=True)
+    z, img = vae_inputs(1, 3, 16, 16)
+    with torch.no_grad():
+        ref = vae.decode(z, img, 0.5).sample
+        mine = O.vae_decode(vsd, VAEVIDEO_TINY, z, img, 0.5)
+    pin["cases"]["vaevideo_t3_16_wlr05"] = {"maxabs_oracle_vs_reference": maxabs(mine, ref), "ref_absmean": ref.abs().mean().item()}
+    torch.save(ref.half(), os.path.join(GOLD, "vaevideo_t3_16_wlr05.pt"))
+    print("vaevideo_t3_16_wlr05", pin["cases"]["vaevideo_t3_16_wlr05"], flush=True)
+
+
 def only(section):
     """`python oracle/make_golden.py --raft | --unet`: regenerate one section's fixtures and PINNING.json entries."""
     torch.set_num_threads(8)
     ns = ref_stubs.import_reference()
     pin = json.load(open(os.path.join(GOLD, "PINNING.json")))
-    {"raft": make_raft_goldens, "unet": make_unet_goldens, "tiles": make_tile_goldens, "pipe14": make_dup_tail_golden}[section](ns, pin)
+    {"raft": make_raft_goldens, "unet": make_unet_goldens, "tiles": make_tile_goldens, "pipe14": make_dup_tail_golden,
+     "vaewlr": make_vae_wlr_golden}[section](ns, pin)
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
-    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else only("tiles") if "--tiles" in sys.argv else only("pipe14") if "--pipe14" in sys.argv else main()
+    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else only("tiles") if "--tiles" in sys.argv else only("pipe14") if "--pipe14" in sys.argv else only("vaewlr") if "--vaewlr" in sys.argv else main()

@@ -112,3 +112,19 @@ def test_pipeline_end_to_end_host_side(cpu_engine, unet_and_sd):
     assert rel_l2(lat, gold["latents"]) < 1e-2                      # same bar as the GPU test
     unsat = gold["images"].float().abs() < 0.999
     assert rel_l2(out[unsat], gold["images"].float()[unsat]) < 3e-2
+
+
+def test_vae_decode_w_lr_host_side(cpu_engine):
+    """w_lr = 0.5 through the video VAE's SFT conditioning: oracle and product module vs the reference fixture."""
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    vae = AutoencoderKLVideo.from_config(dict(GC.VAEVIDEO_TINY))
+    vsd = synth.synth_state_dict(vae.state_dict(), seed=4321)
+    vae.load_state_dict(vsd, strict=True)
+    z, img = GC.vae_inputs(1, 3, 16, 16)
+    gold = torch.load(os.path.join(GOLD, "vaevideo_t3_16_wlr05.pt"))
+    with torch.no_grad():
+        assert rel_l2(O.vae_decode(vsd, GC.VAEVIDEO_TINY, z, img, 0.5), gold) < 1e-3          # fixture stored in fp16
+        out = vae.eval().decode(z, img, 0.5).sample
+        full = vae.decode(z, img, 1.0).sample
+    assert rel_l2(out, gold) < 5e-3
+    assert rel_l2(full, gold) > 1e-2                                                           # the weight does matter
