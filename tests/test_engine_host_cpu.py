@@ -128,3 +128,48 @@ def test_vae_decode_w_lr_host_side(cpu_engine):
         full = vae.decode(z, img, 1.0).sample
     assert rel_l2(out, gold) < 5e-3
     assert rel_l2(full, gold) > 1e-2                                                           # the weight does matter
+
+
+def test_pipeline_duplicate_tail_window_host_side(cpu_engine, unet_and_sd):
+    """T = 14 (windows [0,8), [6,14), [6,14) again) through the whole product stack vs the reference pipeline's latents."""
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
+    from models_video.scheduling_ddim import DDIMScheduler, DDPMScheduler
+    from uav.standin_text import StandInTextEncoder, StandInTokenizer
+    unet, _ = unet_and_sd
+    vae = AutoencoderKLVideo.from_config(dict(GC.VAE3D_TINY))
+    vae.load_state_dict(synth.synth_state_dict(vae.state_dict(), seed=4321), strict=True)
+    tok = StandInTokenizer()
+    pipe = VideoUpscalePipeline(text_encoder=StandInTextEncoder(tok, GC.UNET_TINY["cross_attention_dim"], dtype=torch.float32),
+                                tokenizer=tok, low_res_scheduler=DDPMScheduler(), scheduler=DDIMScheduler(**GC.SCHED),
+                                vae=vae.eval(), unet=unet, propagator=None).to("cpu")
+    clip = synth.synth_clip(1, 14, 16, 16, seed=14)
+    out, lat = pipe("p", image=clip, generator=torch.Generator().manual_seed(10), num_inference_steps=2, guidance_scale=6.0,
+                    noise_level=120, negative_prompt="n", return_dict=False)
+    gold = torch.load(os.path.join(GOLD, "pipe_t14_dup_tail.pt"))
+    assert out.shape == (1, 3, 14, 64, 64)
+    assert rel_l2(lat, gold["latents"]) < 1e-2
+
+
+def test_tiled_clip_host_side(cpu_engine, unet_and_sd):
+    """uav.tiling.upscale_tiled over the whole product stack (H = 68: forced-upsample-size path in every tile) vs the
+    fixture made by the reference CLI loop around the reference pipeline."""
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
+    from models_video.scheduling_ddim import DDIMScheduler, DDPMScheduler
+    from uav import tiling
+    from uav.standin_text import StandInTextEncoder, StandInTokenizer
+    unet, _ = unet_and_sd
+    vae = AutoencoderKLVideo.from_config(dict(GC.VAE3D_TINY))
+    vae.load_state_dict(synth.synth_state_dict(vae.state_dict(), seed=4321), strict=True)
+    tok = StandInTokenizer()
+    pipe = VideoUpscalePipeline(text_encoder=StandInTextEncoder(tok, GC.UNET_TINY["cross_attention_dim"], dtype=torch.float32),
+                                tokenizer=tok, low_res_scheduler=DDPMScheduler(), scheduler=DDIMScheduler(**GC.SCHED),
+                                vae=vae.eval(), unet=unet, propagator=None).to("cpu")
+    clip = synth.synth_clip(1, 2, 68, 160, seed=33)
+    out = tiling.upscale_tiled(pipe, "p", clip, None, torch.Generator().manual_seed(10), tile_size=64, num_inference_steps=2,
+                               guidance_scale=6.0, noise_level=120, negative_prompt="n")
+    gold = torch.load(os.path.join(GOLD, "pipe_tiled_t2_68x160.pt"))
+    for mine, ref in ((out[..., ::4, ::4], gold["sub4"].float()), (out[..., :, 240:272], gold["seam"].float())):
+        unsat = ref.abs() < 0.999
+        assert rel_l2(mine[unsat], ref[unsat]) < 3e-2
