@@ -184,7 +184,31 @@ def ddim_vt(x0, guided, sample, *, coef_x0, coef_dir, eps_from_model, eps_from_s
     return _h(coef_x0 * a + coef_dir * eps)
 
 
-_OPS = ("conv_gemm", "linear", "groupnorm", "layernorm", "attention", "temporal_attention", "linear_small",
+def _warp(x, flow, mode):
+    """flow_warp of the reference (propagation_module.py:104-135): x (1,C,h,w), flow (1,2,h,w) in pixels."""
+    _, _, h, w = x.shape
+    gy, gx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+    vx, vy = gx + flow[0, 0], gy + flow[0, 1]
+    grid = torch.stack((2.0 * vx / max(w - 1, 1) - 1.0, 2.0 * vy / max(h - 1, 1) - 1.0), dim=-1)[None]
+    return F.grid_sample(x, grid, mode=mode, padding_mode="zeros", align_corners=True)
+
+
+def propagate_step(feat_prev, feat_cur, flow_prop, flow_check, out, *, c, h, w, feat_chan_stride, flow_chan_stride, nearest,
+                   coord_f16, fuse_scale, alpha1, alpha2):
+    """One recurrence step (uav_propagate_step_f16) with fp32 coordinates: consistency mask from the bilinearly warped
+    check flow, nearest / bilinear warp of the propagated frame, fuse, mask blend; written into the `out` frame view."""
+    fp, fc = flow_prop.float()[None], flow_check.float()[None]
+    bw = _warp(fc, fp, "bilinear")
+    lsq = lambda t: (t * t).sum(dim=1, keepdim=True)
+    mask = (lsq(fp + bw) < alpha1 * (lsq(fp) + lsq(bw)) + alpha2).float()
+    cur = feat_cur.float()[None]
+    warped = _warp(feat_prev.float()[None], fp, "nearest" if nearest else "bilinear")
+    fused = fuse_scale * warped + (1.0 - fuse_scale) * cur
+    out.copy_(_h(mask * fused + (1.0 - mask) * cur)[0])
+    return out
+
+
+_OPS = ("propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "temporal_attention", "linear_small",
         "timestep_embedding", "pack_nhwc", "unpack_ncthw", "axpby", "cfg_ddim_v0", "ddim_vt")
 
 

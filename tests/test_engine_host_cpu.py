@@ -173,3 +173,40 @@ def test_tiled_clip_host_side(cpu_engine, unet_and_sd):
     for mine, ref in ((out[..., ::4, ::4], gold["sub4"].float()), (out[..., :, 240:272], gold["seam"].float())):
         unsat = ref.abs() < 0.999
         assert rel_l2(mine[unsat], ref[unsat]) < 3e-2
+
+
+def test_pipeline_with_propagation_host_side(cpu_engine, unet_and_sd):
+    """BASELINE config-3 flow through the whole product stack incl. the real Propagation module (two sweeps, in-place
+    frame views) and the video VAE, T = 10 (two windows): vs the reference pipeline's fixture."""
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
+    from models_video.propagation_module import Propagation
+    from models_video.scheduling_ddim import DDIMScheduler, DDPMScheduler
+    from uav.standin_text import StandInTextEncoder, StandInTokenizer
+    unet, _ = unet_and_sd
+    case = GC.PIPE_CASES["pipe_t10_vaevideo_prop"]
+    vae = AutoencoderKLVideo.from_config(dict(GC.VAEVIDEO_TINY))
+    vae.load_state_dict(synth.synth_state_dict(vae.state_dict(), seed=4321), strict=True)
+    tok = StandInTokenizer()
+    prop = Propagation(4, learnable=False)
+    pipe = VideoUpscalePipeline(text_encoder=StandInTextEncoder(tok, GC.UNET_TINY["cross_attention_dim"], dtype=torch.float32),
+                                tokenizer=tok, low_res_scheduler=DDPMScheduler(), scheduler=DDIMScheduler(**GC.SCHED),
+                                vae=vae.eval(), unet=unet, propagator=prop).to("cpu")
+    image, flows = GC.pipeline_inputs(case)
+    out, lat = pipe(case["prompt"], image=image, flows_bi=flows, generator=torch.Generator().manual_seed(10),
+                    num_inference_steps=case["steps"], guidance_scale=case["guidance"], noise_level=case["noise_level"],
+                    negative_prompt=case["negative"], propagation_steps=list(case["propagation_steps"]), return_dict=False)
+    gold = torch.load(os.path.join(GOLD, "pipe_t10_vaevideo_prop.pt"))
+    assert rel_l2(lat, gold["latents"]) < 1e-2
+    unsat = gold["images"].float().abs() < 0.999
+    assert rel_l2(out[unsat], gold["images"].float()[unsat]) < 3e-2
+
+
+@pytest.mark.parametrize("interp", ["nearest", "bilinear"])
+def test_propagation_module_host_side(cpu_engine, interp):
+    from models_video.propagation_module import Propagation
+    x, ff, fb = GC.prop_inputs(8, 24, 32)
+    out = Propagation(4, learnable=False)(x.half(), ff.half(), fb.half(), interpolation=interp, mode="fuse", fuse_scale=0.5,
+                                          alpha1=0.001, alpha2=0.05)
+    gold = torch.load(os.path.join(GOLD, f"propagation_{interp}.pt"))
+    assert rel_l2(out, gold) < 5e-3
