@@ -514,33 +514,16 @@ def test_oracle_duplicate_tail_window_vs_reference_fixture(unet_sd):
 #     (same arithmetic as csrc/elementwise.hip), UNet / VAE replaced by wrappers around the oracle's forward passes.
 #     This runs the window loop, blends, CFG / DDIM stepping, decode chunking and rank sharding of the product class.
 def _install_cpu_ops(ns):
-    from uav import ops
-
-    def axpby(x, z, a, b):
-        return (a * x.float() + b * z.float()).half()
-
-    def cfg_ddim_v0(eu, ec, sample, *, guidance, coef_sample, coef_eps, clip=False, clip_range=1.0):
-        g = eu.float() if ec is None else eu.float() + guidance * (ec.float() - eu.float())
-        g = g.half()
-        x0 = coef_sample * sample.float() + coef_eps * g.float()
-        if clip:
-            x0 = x0.clamp(-clip_range, clip_range)
-        return g, x0.half()
-
-    def ddim_vt(x0, guided, sample, *, coef_x0, coef_dir, eps_from_model, eps_from_sample, eps_from_x0=0.0, clip=False,
-                clip_range=1.0):
-        a = x0.float().clamp(-clip_range, clip_range) if clip else x0.float()
-        eps = eps_from_model * guided.float() + eps_from_sample * sample.float() + eps_from_x0 * a
-        return (coef_x0 * a + coef_dir * eps).half()
-    for name, fn in (("axpby", axpby), ("cfg_ddim_v0", cfg_ddim_v0), ("ddim_vt", ddim_vt)):
-        ns.setdefault("saved", {})[name] = getattr(ops, name)
-        setattr(ops, name, fn)
+    """torch stand-ins for the HIP elementwise ops the pipeline / schedulers call (tests/cpu_ops.py)."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import cpu_ops
+    cpu_ops.install()
+    ns["cpu_ops"] = cpu_ops
 
 
 def _restore_ops(ns):
-    from uav import ops
-    for name, fn in ns.get("saved", {}).items():
-        setattr(ops, name, fn)
+    if "cpu_ops" in ns:
+        ns["cpu_ops"].restore()
 
 
 def _cpu_pipeline(unet_sd, vsd, calls=None, vae_cfg=None, propagator=None):
