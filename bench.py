@@ -117,6 +117,23 @@ def cpu_baseline(sample_hw=64, frames=8, max_threads=32):
                       f"FLOP to 5608.7 TFLOP/clip"}
 
 
+def self_launch(n):
+    """Re-exec this script as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same args>`."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -138,13 +155,24 @@ def main():
                     help="clips upscaled CONCURRENTLY per GPU in one step, one HIP stream (and host thread) each: the "
                          "HBM-bound kernels of one clip run beside the MFMA-bound kernels of the other (serving mode); "
                          "per-launch HIP events are switched off because launches overlap")
+    ap.add_argument("--vae-fp16", action="store_true",
+                    help="A/B switch: all-fp16 VAE decoder rows (round-1 behaviour, ~1e-3 rel-L2 vs the fp32 reference decode) "
+                         "instead of the default fp32 residual stream (~6e-4); the mode timed is named in config.workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (RCCL);
+        # rank 0 of the child job prints the JSON line, which passes through unchanged.
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -152,9 +180,8 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)        # RCCL on ROCm; one process per GPU
-    if args.gpus != world and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}: launch with torch.distributed.run --nproc-per-node {args.gpus}",
-              file=sys.stderr)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: RCCL reports {dist.get_world_size()} ranks, expected {args.gpus}")
 
     from uav import _lib, ops
     lib = _lib.load()
@@ -162,6 +189,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X (gfx950)")
 
     pipe = build_pipeline(dev, args.height, args.width)
+    pipe.vae.stream_dtype = torch.float16 if args.vae_fp16 else torch.float32
     pipe.cfg_shared_input = not args.no_cfg_share
     pipe.shard_windows = args.shard_windows
     clip = synthetic_clip(args.frames, args.height, args.width, seed=0 if args.shard_windows else rank, dev=dev)
@@ -261,7 +289,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.shard_windows else "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"configs[{3 if args.shard_windows else 2 if args.propagation else 1}]: {args.frames}-frame {args.height}x{args.width}->{4 * args.height}x{4 * args.width}, "
-                                   f"{args.ddim_steps} DDIM steps, guidance 6, noise_level 120, vae_3d, "
+                                   f"{args.ddim_steps} DDIM steps, guidance 6, noise_level 120, vae_3d ("
+                                   + ("all-fp16 decoder rows" if args.vae_fp16 else "fp32 residual stream, fp16 MFMA operands") + "), "
                                    + (f"RAFT flows (20 iters, {raft_s * 1e3:.0f} ms, outside the timed region like the reference) + "
                                       f"latent propagation at steps {psteps}; " if args.propagation else "no propagation; ")
                                    + ("ONE clip, temporal windows + decode chunks dealt over the ranks, all-gather per DDIM step (RCCL)"

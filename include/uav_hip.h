@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UAV_ABI_VERSION 1
+#define UAV_ABI_VERSION 2
 
 #define UAV_EINVAL   (-1)   /* bad argument (null pointer, size not supported) */
 #define UAV_EALIGN   (-2)   /* pointer / stride alignment requirement violated */
@@ -56,6 +56,7 @@ int  uav_device_check(int dev, char* name_out);
  */
 #define UAV_CONV_GEGLU    1u   /* rows of W interleaved [32 value | 32 gate]; out width n/2 */
 #define UAV_CONV_OUT_F32  2u   /* store fp32 instead of fp16 */
+#define UAV_CONV_RES_F32  128u /* `residual` is fp32 [M][res_stride] (fp32 residual stream of the VAE decoder) */
 
 typedef struct {
     const void*  a1;            /* fp16 source 1, rows of c1 channels */
@@ -66,7 +67,7 @@ typedef struct {
     const float* rowbias;       /* fp32 [n_batches][rowbias_stride] or NULL */
     int32_t      rows_per_batch;
     int32_t      rowbias_stride;
-    const void*  residual;      /* fp16 [M][res_stride] or NULL */
+    const void*  residual;      /* fp16 (fp32 with UAV_CONV_RES_F32) [M][res_stride] or NULL */
     int32_t      res_stride;
     void*        out;           /* fp16 (or fp32) [M][out_stride] */
     int32_t      out_stride;
@@ -90,19 +91,21 @@ int uav_conv_gemm_f16(const uav_conv_params* p, void* stream);
  * Replaces nn.GroupNorm on 5-D tensors (statistics over C/G x T x H x W: resnet.py:267,278,
  * 366,377,467,478,495; unet_video.py:567) and on per-frame 4-D tensors (attention.py:374;
  * unet_blocks.py:740) followed by SiLU (resnet.py:268,284).
- *   x: fp16 rows [n_inst*rows_per_inst][c] read from up to two channel-concatenated sources.
+ *   x: fp16 (or fp32, x_f32 = 1) rows [n_inst*rows_per_inst][c] read from up to two channel-concatenated sources.
  *   stats pass : partial per-channel (sum, sumsq) -> scale/shift tables [n_inst][c] (fp32):
  *                scale = gamma*rstd, shift = beta - mean*rstd*gamma.
  *   apply pass : y = act(x*scale + shift), fp16, written contiguously [rows][c1+c2].
  */
 int64_t uav_groupnorm_workspace_bytes(int32_t n_inst, int32_t c);
-int uav_groupnorm_scale_shift(const void* x1, const void* x2, int32_t c1, int32_t c2,
+int uav_groupnorm_scale_shift(const void* x1, const void* x2,
+                              int32_t x_f32, /* 0: x rows are fp16, 1: fp32 (fp32 residual stream of the VAE decoder) */
+                              int32_t c1, int32_t c2,
                               int32_t c_real, /* real channels (<= c1+c2); padding gets scale=shift=0 */
                               int32_t n_inst, int64_t rows_per_inst, int32_t groups, float eps,
                               const float* gamma, const float* beta,
                               float* scale_out, float* shift_out,
                               void* workspace, int64_t workspace_bytes, void* stream);
-int uav_groupnorm_apply(const void* x1, const void* x2, int32_t c1, int32_t c2,
+int uav_groupnorm_apply(const void* x1, const void* x2, int32_t x_f32, int32_t c1, int32_t c2,
                         int32_t n_inst, int64_t rows_per_inst,
                         const float* scale, const float* shift, int32_t silu,
                         void* y, void* stream);
@@ -177,6 +180,13 @@ int uav_ddim_vt(const void* x0, const void* guided, const void* sample, void* pr
 /* y = a*x + b*z  (add_noise: scheduling_ddim.py:524-545; window blend pipeline:630-634) */
 int uav_axpby_f16(const void* x, const void* z, void* y, int64_t n, float a, float b,
                   void* stream);
+
+/* fp32 rows -> fp16 rows (fp32 residual stream of the VAE decoder feeding a conv operand; x, y 16-B aligned) */
+int uav_cast_f32_f16(const float* x, void* y, int64_t n, void* stream);
+/* SFT fusion of the video VAE (Fuse_sft_block, resnet.py:76-78): out = dec + w*(dec*scale + shift), elementwise;
+ * in_f32 / out_f32 select fp32 instead of fp16 for the three inputs / the output */
+int uav_sft_fuse(const void* dec, const void* scale, const void* shift, void* out, int64_t n, float w,
+                 int32_t in_f32, int32_t out_f32, void* stream);
 
 /* ---- K10: flow-guided propagation step -----------------------------------------------
  * Replaces one recurrence step of Propagation.forward (propagation_module.py:234-254) with

@@ -70,6 +70,35 @@ def prop_inputs(t, h, w, seed=300):
     return x, ff.half().float(), fb.half().float()
 
 
+def prop_inputs_ties(t, h, w, seed=310):
+    """All-half propagation inputs that sit ON the discontinuities of the nearest-neighbour warp: flow components with an
+    exact .5 sub-pixel part (half of the pixels, the rest carry small noise), so x + flow lands on a rounding tie before
+    the fp16 normalise / un-normalise round trip of flow_warp (propagation_module.py:123-132) moves it; wide frames
+    (w = 320) add the fp16 quantisation of large coordinates (spacing .25 above 256)."""
+    g = _g(seed + h + w)
+    x = torch.randn(1, 4, t, h, w, generator=g).half().float()
+    ff = torch.zeros(1, 2, t - 1, h, w); fb = torch.zeros(1, 2, t - 1, h, w)
+    ff[:, 0] = 2.5; ff[:, 1] = 1.5; fb[:, 0] = -2.5; fb[:, 1] = -1.5
+    noisy = (torch.rand(ff.shape, generator=g) < 0.5).float()
+    ff = ff + noisy * 0.03 * torch.randn(ff.shape, generator=g); fb = fb + noisy * 0.03 * torch.randn(fb.shape, generator=g)
+    fb[:, :, :, h // 3: h // 2] += 3.0
+    return x, ff.half().float(), fb.half().float()
+
+
+# reference Propagation run on CPU *half* tensors (the dtype the pipeline hands it, pipeline:651): name -> (inputs fn, t, h, w, interp)
+PROP_HALF_CASES = {
+    "propagation_nearest_half": ("plain", 8, 24, 32, "nearest"),
+    "propagation_bilinear_half": ("plain", 8, 24, 32, "bilinear"),
+    "propagation_nearest_half_ties": ("ties", 5, 24, 40, "nearest"),
+    "propagation_nearest_half_wide": ("ties", 4, 16, 320, "nearest"),
+    "propagation_bilinear_half_wide": ("ties", 3, 16, 320, "bilinear"),
+}
+
+
+def prop_half_inputs(kind, t, h, w):
+    return prop_inputs(t, h, w) if kind == "plain" else prop_inputs_ties(t, h, w)
+
+
 PIPE_CASES = {
     # plumbing case of BASELINE config 1 shape family, scaled to run on CPU in seconds
     "pipe_t8_vae3d": dict(vae="vae3d", t=8, h=16, w=16, steps=3, guidance=6.0, noise_level=120,
@@ -89,3 +118,13 @@ def pipeline_inputs(case, seed=400):
         _, ff, fb = prop_inputs(case["t"], case["h"], case["w"], seed=seed + 1)
         flows = [ff, fb]
     return image, flows
+
+
+# FULL-WIDTH cases (released architecture), generated by `make_golden.py --full` from the reference's own modules
+FULL_CASES = {
+    "unet_full_t8_64": (2, 8, 64, 64),
+    "vae3d_full_t3_48": (1, 3, 48, 48),
+    # BASELINE.json configs[0]: single 8-frame 128x128 -> 512x512 clip, 5 DDIM steps, no propagation
+    "pipe_c1_full": dict(t=8, h=128, w=128, steps=5, guidance=6.0, noise_level=120, clip_seed=41,
+                         prompt="best quality, extremely detailed", negative="blur, worst quality"),
+}

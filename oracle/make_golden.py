@@ -25,7 +25,7 @@ import ref_stubs  # noqa: E402
 import synth  # noqa: E402
 import uav_oracle as O  # noqa: E402
 from golden_cases import (UNET_TINY, VAE3D_TINY, VAEVIDEO_TINY, SCHED, unet_inputs, vae_inputs, prop_inputs,  # noqa: E402
-                          pipeline_inputs, PIPE_CASES)
+                          pipeline_inputs, PIPE_CASES, PROP_HALF_CASES, prop_half_inputs, FULL_CASES)
 
 GOLD = os.path.join(ROOT, "tests", "golden")
 
@@ -60,19 +60,19 @@ class _Tok:
 
 
 class _TextEnc(torch.nn.Module):
-    def __init__(self, tok, dim):
+    def __init__(self, tok, dim, dtype=torch.float32):
         super().__init__()
-        self.tok, self.dim = tok, dim
+        self.tok, self.dim, self._dtype = tok, dim, dtype
         self.dummy = torch.nn.Parameter(torch.zeros(1))
         import types
         self.config = types.SimpleNamespace()
 
     @property
     def dtype(self):
-        return torch.float32
+        return self._dtype
 
     def forward(self, ids, attention_mask=None):
-        return (torch.cat([synth.synth_prompt_embeds(self.tok.prompts[int(r[0])], self.dim) for r in ids]),)
+        return (torch.cat([synth.synth_prompt_embeds(self.tok.prompts[int(r[0])], self.dim) for r in ids]).to(self._dtype),)
 
 
 def main():
@@ -171,6 +171,9 @@ def main():
     make_tile_goldens(ns, pin)
     make_dup_tail_golden(ns, pin)
     make_vae_wlr_golden(ns, pin)
+    make_prop_half_goldens(ns, pin)
+    make_pipe_half_golden(ns, pin)
+    make_fullwidth_goldens(ns, pin)
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
     print("wrote", GOLD)
 
@@ -404,15 +407,149 @@ def make_vae_wlr_golden(ns, pin):
     print("vaevideo_t3_16_wlr05", pin["cases"]["vaevideo_t3_16_wlr05"], flush=True)
 
 
+
+def make_prop_half_goldens(ns, pin):
+    """The reference `Propagation` on CPU *half* tensors — the dtype the pipeline hands it (pipeline:651 casts the
+    flows to the latent dtype): grid built, normalised and un-normalised in fp16 (propagation_module.py:123-132;
+    ATen's grid_sampler rounds the source index to scalar_t before nearbyint — checked against an emulation).  These
+    fixtures pin the engine's DEFAULT coordinate mode (coord_f16), including inputs that sit on .5 rounding ties
+    and wide frames where fp16 coordinates are coarse."""
+    prop = ns.propagation.Propagation(4, learnable=False)
+    for name, (kind, t, h, w, interp) in PROP_HALF_CASES.items():
+        x, ff, fb = prop_half_inputs(kind, t, h, w)
+        with torch.no_grad():
+            ref16 = prop(x.half(), ff.half(), fb.half(), interpolation=interp, mode="fuse", fuse_scale=0.5, alpha1=0.001,
+                         alpha2=0.05)
+            ref32 = prop(x, ff, fb, interpolation=interp, mode="fuse", fuse_scale=0.5, alpha1=0.001, alpha2=0.05)
+        assert ref16.dtype == torch.float16
+        pin["cases"][name] = {"changed_fraction": (ref16.float() != x).float().mean().item(),
+                              "fraction_differing_from_fp32_coordinates": ((ref16.float() - ref32).abs() > 1e-2).float().mean().item()}
+        torch.save(ref16, os.path.join(GOLD, name + ".pt"))
+        print(name, pin["cases"][name], flush=True)
+
+
+def _full_models(ns):
+    import json as _json
+    ucfg = _json.load(open(os.path.join(ref_stubs.REFERENCE_ROOT, "configs", "unet_video_config.json")))
+    vcfg = _json.load(open(os.path.join(ref_stubs.REFERENCE_ROOT, "configs", "vae_3d_config.json")))
+    unet = ns.unet_video.UNetVideoModel.from_config(dict(ucfg)).eval()
+    usd = synth.synth_state_dict(unet.state_dict(), seed=1234)
+    unet.load_state_dict(usd, strict=True)
+    vae = ns.vae.AutoencoderKLVideo.from_config(dict(vcfg)).eval()
+    vsd = synth.synth_state_dict(vae.state_dict(), seed=4321)
+    vae.load_state_dict(vsd, strict=True)
+    return unet, usd, ucfg, vae, vsd, vcfg
+
+
+def make_fullwidth_goldens(ns, pin):
+    """FULL-WIDTH models (the released architecture: 691 M-param UNet, channels 256-1024; 55 M-param VAE), the
+    reference's own modules on CPU:
+      unet_full_t8_64      one UNetVideoModel.forward, B2 x T8 x 64x64, fp32 and the reference's own `.half()` run
+      vae3d_full_t3_48     one 3-frame decode chunk 48x48 -> 192x192 (fp32, like the pipeline's decode, pipeline:668-681)
+      pipe_c1_full         BASELINE configs[0]: 8-frame 128x128 -> 512x512, 5 DDIM steps, guidance 6, no propagation
+    plus the oracle restatement on the same inputs (PINNING.json)."""
+    unet, usd, ucfg, vae, vsd, vcfg = _full_models(ns)
+    c = FULL_CASES
+    # --- UNet forward
+    bsz, t, h, w = c["unet_full_t8_64"]
+    sample, low, ehs, ts, cl = unet_inputs(bsz, t, h, w, ucfg["cross_attention_dim"])
+    with torch.no_grad():
+        t0 = time.time(); ref = unet(sample, torch.tensor(ts), low, encoder_hidden_states=ehs, class_labels=cl).sample; t_ref = time.time() - t0
+        t0 = time.time(); mine = O.unet_forward(usd, ucfg, sample, ts, low, ehs, cl); t_ora = time.time() - t0
+        unet.half()
+        t0 = time.time()
+        ref16 = unet(sample.half(), torch.tensor(ts), low.half(), encoder_hidden_states=ehs.half(), class_labels=cl).sample
+        t_16 = time.time() - t0
+        unet.float()
+    pin["cases"]["unet_full_t8_64"] = {"maxabs_oracle_vs_reference": maxabs(mine, ref), "rel_l2": rel_l2(mine, ref),
+                                       "ref_absmean": ref.abs().mean().item(), "ref_seconds": t_ref, "oracle_seconds": t_ora,
+                                       "ref_fp16_seconds": t_16, "reference_fp16_vs_fp32_rel_l2": rel_l2(ref16, ref)}
+    torch.save({"fp32": ref, "fp16": ref16}, os.path.join(GOLD, "unet_full_t8_64.pt"))
+    print("unet_full_t8_64", pin["cases"]["unet_full_t8_64"], flush=True)
+    # --- VAE decode chunk
+    _, tv, hv, wv = c["vae3d_full_t3_48"]
+    z, img = vae_inputs(1, tv, hv, wv)
+    with torch.no_grad():
+        t0 = time.time(); ref = vae.decode(z, img, 1.0).sample; t_ref = time.time() - t0
+        mine = O.vae_decode(vsd, vcfg, z, img, 1.0)
+    pin["cases"]["vae3d_full_t3_48"] = {"maxabs_oracle_vs_reference": maxabs(mine, ref), "rel_l2": rel_l2(mine, ref),
+                                        "ref_absmean": ref.abs().mean().item(), "ref_seconds": t_ref,
+                                        "saturated_fraction": (ref.abs() >= 1).float().mean().item()}
+    torch.save(ref, os.path.join(GOLD, "vae3d_full_t3_48.pt"))
+    print("vae3d_full_t3_48", pin["cases"]["vae3d_full_t3_48"], flush=True)
+    # --- BASELINE configs[0] end to end
+    pc = c["pipe_c1_full"]
+    tok = _Tok()
+    dim = ucfg["cross_attention_dim"]
+    pipe = ns.pipeline.VideoUpscalePipeline(
+        text_encoder=_TextEnc(tok, dim), tokenizer=tok,
+        low_res_scheduler=ref_stubs.DDPMScheduler(beta_schedule="scaled_linear", beta_start=0.0001, beta_end=0.02),
+        scheduler=ns.scheduling_ddim.DDIMScheduler(**SCHED), vae=vae, unet=unet, propagator=None)
+    clip = synth.synth_clip(1, pc["t"], pc["h"], pc["w"], seed=pc["clip_seed"])
+    gen = torch.Generator().manual_seed(10)
+    t0 = time.time()
+    ref_img, ref_lat = pipe(pc["prompt"], image=clip, generator=gen, num_inference_steps=pc["steps"], guidance_scale=pc["guidance"],
+                            noise_level=pc["noise_level"], negative_prompt=pc["negative"], return_dict=False)
+    t_ref = time.time() - t0
+    gen = torch.Generator().manual_seed(10)
+    lr_noise = torch.randn(clip.shape, generator=gen); lat0 = torch.randn((1, 4) + tuple(clip.shape[2:]), generator=gen)
+    pe = torch.cat([synth.synth_prompt_embeds(pc["negative"], dim), synth.synth_prompt_embeds(pc["prompt"], dim)])
+    with torch.no_grad():
+        t0 = time.time()
+        img, lat = O.pipeline_call(usd, ucfg, vsd, vcfg, clip, pe, num_inference_steps=pc["steps"], guidance_scale=pc["guidance"],
+                                   noise_level=pc["noise_level"], lr_noise=lr_noise, latents=lat0, scheduler_kwargs=SCHED)
+        t_ora = time.time() - t0
+    pin["cases"]["pipe_c1_full"] = {"latents_maxabs_oracle_vs_reference": maxabs(lat, ref_lat), "latents_rel_l2": rel_l2(lat, ref_lat),
+                                    "image_maxabs_oracle_vs_reference": maxabs(img, ref_img),
+                                    "image_saturated_fraction": (ref_img.abs() >= 1).float().mean().item(),
+                                    "ref_seconds": t_ref, "oracle_seconds": t_ora, "threads": torch.get_num_threads(),
+                                    "tflop": 166.0, "ref_tflops_per_s": 166.0 / t_ref}
+    torch.save({"latents": ref_lat.float().clone(), "images_sub4": ref_img[..., ::4, ::4].float().clone(), "images_frame3": ref_img[:, :, 3].half().clone()},
+               os.path.join(GOLD, "pipe_c1_full.pt"))
+    print("pipe_c1_full", pin["cases"]["pipe_c1_full"], flush=True)
+
+
+def make_pipe_half_golden(ns, pin):
+    """The reference pipeline in the precision mix the CLI really runs (inference_upscale_a_video.py:101-118): UNet
+    `.half()`, text-encoder dtype fp16 -> both randn draws, the latents, CFG, DDIM and the flow-guided propagation
+    (flows cast to the latent dtype, pipeline:651) all in fp16, VAE decode in fp32 (pipeline:668-681) — on CPU half
+    tensors, tiny seeded models, T = 10 (two windows) with propagation at step 1 and the video VAE."""
+    case = PIPE_CASES["pipe_t10_vaevideo_prop"]
+    unet = ns.unet_video.UNetVideoModel.from_config(dict(UNET_TINY)).eval()
+    usd = synth.synth_state_dict(unet.state_dict(), seed=1234)
+    unet.load_state_dict(usd, strict=True)
+    unet.half()
+    vae = ns.vae.AutoencoderKLVideo.from_config(dict(VAEVIDEO_TINY)).eval()
+    vae.load_state_dict(synth.synth_state_dict(vae.state_dict(), seed=4321), strict=True)
+    prop = ns.propagation.Propagation(4, learnable=False)
+    tok = _Tok()
+    pipe = ns.pipeline.VideoUpscalePipeline(
+        text_encoder=_TextEnc(tok, UNET_TINY["cross_attention_dim"], dtype=torch.float16), tokenizer=tok,
+        low_res_scheduler=ref_stubs.DDPMScheduler(beta_schedule="scaled_linear", beta_start=0.0001, beta_end=0.02),
+        scheduler=ns.scheduling_ddim.DDIMScheduler(**SCHED), vae=vae, unet=unet, propagator=prop)
+    image, flows = pipeline_inputs(case)
+    gen = torch.Generator().manual_seed(10)
+    ref_img, ref_lat = pipe(case["prompt"], image=image, flows_bi=flows, generator=gen, num_inference_steps=case["steps"],
+                            guidance_scale=case["guidance"], noise_level=case["noise_level"], negative_prompt=case["negative"],
+                            propagation_steps=list(case["propagation_steps"]), return_dict=False)
+    fp32 = torch.load(os.path.join(GOLD, "pipe_t10_vaevideo_prop.pt"))
+    pin["cases"]["pipe_t10_vaevideo_prop_refhalf"] = {
+        "latents_dtype": str(ref_lat.dtype), "image_dtype": str(ref_img.dtype),
+        "latents_rel_l2_vs_reference_fp32_run": rel_l2(ref_lat, fp32["latents"]),
+        "image_rel_l2_vs_reference_fp32_run": rel_l2(ref_img, fp32["images"])}
+    torch.save({"latents": ref_lat.half(), "images": ref_img.half()}, os.path.join(GOLD, "pipe_t10_vaevideo_prop_refhalf.pt"))
+    print("pipe_t10_vaevideo_prop_refhalf", pin["cases"]["pipe_t10_vaevideo_prop_refhalf"], flush=True)
+
+
 def only(section):
     """`python oracle/make_golden.py --raft | --unet`: regenerate one section's fixtures and PINNING.json entries."""
     torch.set_num_threads(8)
     ns = ref_stubs.import_reference()
     pin = json.load(open(os.path.join(GOLD, "PINNING.json")))
     {"raft": make_raft_goldens, "unet": make_unet_goldens, "tiles": make_tile_goldens, "pipe14": make_dup_tail_golden,
-     "vaewlr": make_vae_wlr_golden}[section](ns, pin)
+     "vaewlr": make_vae_wlr_golden, "prophalf": make_prop_half_goldens, "pipehalf": make_pipe_half_golden, "full": make_fullwidth_goldens}[section](ns, pin)
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
-    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else only("tiles") if "--tiles" in sys.argv else only("pipe14") if "--pipe14" in sys.argv else only("vaewlr") if "--vaewlr" in sys.argv else main()
+    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else only("tiles") if "--tiles" in sys.argv else only("pipe14") if "--pipe14" in sys.argv else only("vaewlr") if "--vaewlr" in sys.argv else only("pipehalf") if "--pipehalf" in sys.argv else only("prophalf") if "--prophalf" in sys.argv else only("full") if "--full" in sys.argv else main()

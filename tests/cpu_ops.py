@@ -208,7 +208,18 @@ def propagate_step(feat_prev, feat_cur, flow_prop, flow_check, out, *, c, h, w, 
     return out
 
 
-_OPS = ("propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "temporal_attention", "linear_small",
+def cast_f16(x):
+    return x if x.dtype == HALF else _h(x)
+
+
+def sft_fuse(dec, scale, shift, w, out_f32=False):
+    assert dec.dtype == scale.dtype == shift.dtype
+    d = dec.float()
+    y = d + w * (d * scale.float() + shift.float())
+    return y if out_f32 else _h(y)
+
+
+_OPS = ("cast_f16", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "temporal_attention", "linear_small",
         "timestep_embedding", "pack_nhwc", "unpack_ncthw", "axpby", "cfg_ddim_v0", "ddim_vt")
 
 

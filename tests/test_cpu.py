@@ -180,7 +180,7 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/uav_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.uav_version() == 1
+    assert lib.uav_version() == 2
 
 
 # ---------------------------------------------------------------------------------------------
@@ -337,12 +337,14 @@ def test_cabi_rejects_bad_arguments_without_touching_the_gpu():
     assert conv(t_len=3) == ESHAPE                # n_img % t_len
     assert conv(flags=1, residual=P, res_stride=128) == ESHAPE   # GEGLU excludes residual
     assert conv(rowbias=P, rows_per_batch=0) == ESHAPE
+    assert conv(flags=128) == EINVAL              # fp32-residual flag without a residual
     assert lib.uav_conv_gemm_f16(None, None) == EINVAL
+    assert lib.uav_cast_f32_f16(None, P, 8, None) == EINVAL and lib.uav_sft_fuse(P, P, None, P, 8, 1.0, 0, 0, None) == EINVAL
     # GroupNorm
-    assert lib.uav_groupnorm_scale_shift(None, None, 64, 0, 64, 1, 16, 32, 1e-5, None, None, P, P, P, 1 << 20, None) == EINVAL
-    assert lib.uav_groupnorm_scale_shift(P, None, 60, 0, 60, 1, 16, 30, 1e-5, None, None, P, P, P, 1 << 20, None) == ESHAPE
-    assert lib.uav_groupnorm_scale_shift(P, None, 64, 0, 64, 1, 16, 7, 1e-5, None, None, P, P, P, 1 << 20, None) == ESHAPE
-    assert lib.uav_groupnorm_scale_shift(P, None, 64, 0, 64, 1, 16, 32, 1e-5, None, None, P, P, P, 8, None) == EINVAL    # workspace too small
+    assert lib.uav_groupnorm_scale_shift(None, None, 0, 64, 0, 64, 1, 16, 32, 1e-5, None, None, P, P, P, 1 << 20, None) == EINVAL
+    assert lib.uav_groupnorm_scale_shift(P, None, 0, 60, 0, 60, 1, 16, 30, 1e-5, None, None, P, P, P, 1 << 20, None) == ESHAPE
+    assert lib.uav_groupnorm_scale_shift(P, None, 1, 64, 0, 64, 1, 16, 7, 1e-5, None, None, P, P, P, 1 << 20, None) == ESHAPE
+    assert lib.uav_groupnorm_scale_shift(P, None, 0, 64, 0, 64, 1, 16, 32, 1e-5, None, None, P, P, P, 8, None) == EINVAL    # workspace too small
     # attention: null / shape / alignment
     assert lib.uav_attention_f16(None, 64, P, 64, P, 64, P, 64, 1, 8, 8, 1, 1, 64, 0.125, P, None) == EINVAL
     assert lib.uav_attention_f16(P, 64, P, 64, P, 64, P, 64, 3, 8, 8, 2, 1, 64, 0.125, P, None) == ESHAPE        # bq % q_per_kv

@@ -341,3 +341,61 @@ def test_propagate_step_fp32_coords(ops, dev, nearest):
                        nearest=nearest, coord_f16=False, fuse_scale=0.5, alpha1=0.01, alpha2=0.5)
     bad = ((out.float() - ref[0]).abs() > 2e-2).float().mean().item()
     assert bad < 2e-3, f"{bad} of pixels differ"          # threshold-boundary pixels may flip the mask
+
+
+# ------------------------------------------------------------------------------------------------
+# fp32 residual stream of the VAE decoder (round 2): fp32 conv outputs / fp32 residual, GroupNorm on fp32 rows
+@pytest.mark.parametrize("cout,h,w,tile", [(256, 40, 36, "128 or 256"), (128, 12, 10, "128, M tail -> generic path"),
+                                           (512, 48, 48, "256x256 kernel")])
+def test_conv_f32_stream_epilogue(ops, dev, cout, h, w, tile):
+    """out_f32 with an fp32 residual: ((conv + bias) + residual) * scale, stored fp32.  Tolerance 1e-4 (fp32 output,
+    fp16-representable operands, fp32 accumulation; only the summation order differs from the torch reference)."""
+    g = torch.Generator().manual_seed(cout + h)
+    bsz, t_len, cin = 2, 3, 128
+    x5 = h16(bsz, cin, t_len, h, w, dev=dev, gen=g)
+    wt = h16(cout, cin, 1, 3, 3, dev=dev, scale=(9 * cin) ** -0.5, gen=g)
+    bias = torch.randn(cout, generator=g).to(dev)
+    res5 = torch.randn(bsz, cout, t_len, h, w, generator=g).to(dev)                 # NOT fp16-representable on purpose
+    scale = 1.0 / 1.3
+    ref = (ref_conv(x5, wt, bias, (1, 3, 3), 1, False) + res5) * scale
+    rows = x5.permute(0, 2, 3, 4, 1).reshape(-1, cin).contiguous().half()
+    rr = res5.permute(0, 2, 3, 4, 1).reshape(-1, cout).contiguous()
+    cw = ops.pack_conv(wt, bias, device=dev)
+    y = ops.conv_gemm(rows, cw, n_img=bsz * t_len, t_len=t_len, hi=h, wi=w, residual=rr, out_scale=scale, out_f32=True)
+    assert y.dtype == torch.float32
+    y5 = y.reshape(bsz, t_len, h, w, cout).permute(0, 4, 1, 2, 3)
+    assert rel_l2(y5, ref) < 1e-4
+    y0 = ops.conv_gemm(rows, cw, n_img=bsz * t_len, t_len=t_len, hi=h, wi=w, out_f32=True)          # no residual
+    assert rel_l2(y0.reshape(bsz, t_len, h, w, cout).permute(0, 4, 1, 2, 3), ref_conv(x5, wt, bias, (1, 3, 3), 1, False)) < 1e-4
+    yh = ops.conv_gemm(rows, cw, n_img=bsz * t_len, t_len=t_len, hi=h, wi=w, residual=rr, out_scale=scale)   # fp32 res, fp16 out
+    assert yh.dtype == torch.float16 and rel_l2(yh.float().reshape(bsz, t_len, h, w, cout).permute(0, 4, 1, 2, 3), ref) < 2e-3
+
+
+def test_groupnorm_on_fp32_rows(ops, dev):
+    g = torch.Generator().manual_seed(23)
+    n_inst, rows_per, c, groups = 3, 700, 256, 32
+    x = (torch.randn(n_inst * rows_per, c, generator=g) * 2.0 + 0.7).to(dev)       # fp32, not fp16-representable
+    gamma = (1 + 0.1 * torch.randn(c, generator=g)).to(dev); beta = (0.1 * torch.randn(c, generator=g)).to(dev)
+    y = ops.groupnorm(x, gamma, beta, n_inst=n_inst, rows_per_inst=rows_per, groups=groups, eps=1e-6, silu=True)
+    xr = x.reshape(n_inst, rows_per, groups, c // groups).double()
+    mu = xr.mean(dim=(1, 3), keepdim=True); var = xr.var(dim=(1, 3), unbiased=False, keepdim=True)
+    ref = F.silu((((xr - mu) / (var + 1e-6).sqrt()).float().reshape(-1, c)) * gamma + beta)
+    assert y.dtype == torch.float16 and rel_l2(y, ref) < 1e-3                      # one fp16 rounding of the output
+    # two fp32 sources (channel concat)
+    x2 = torch.randn(n_inst * rows_per, 64, generator=g).to(dev)
+    g2 = torch.ones(c + 64, device=dev); b2 = torch.zeros(c + 64, device=dev)
+    y2 = ops.groupnorm(x, g2, b2, n_inst=n_inst, rows_per_inst=rows_per, groups=32, eps=1e-6, silu=False, x2=x2)
+    xc = torch.cat([x, x2], -1).reshape(n_inst, rows_per, 32, (c + 64) // 32).double()
+    mu = xc.mean(dim=(1, 3), keepdim=True); var = xc.var(dim=(1, 3), unbiased=False, keepdim=True)
+    assert rel_l2(y2, ((xc - mu) / (var + 1e-6).sqrt()).float().reshape(-1, c + 64)) < 1e-3
+
+
+def test_cast_and_sft_fuse(ops, dev):
+    g = torch.Generator().manual_seed(29)
+    x = torch.randn(1003, 24, generator=g).to(dev)
+    assert torch.equal(ops.cast_f16(x), x.half())
+    assert ops.cast_f16(x.half()).dtype == torch.float16
+    dec, sc, sh = [torch.randn(777, 64, generator=g).to(dev) for _ in range(3)]
+    ref = dec + 0.6 * (dec * sc + sh)
+    assert rel_l2(ops.sft_fuse(dec, sc, sh, 0.6, out_f32=True), ref) < 1e-6
+    assert rel_l2(ops.sft_fuse(dec.half(), sc.half(), sh.half(), 0.6), dec.half().float() + 0.6 * (dec.half().float() * sc.half().float() + sh.half().float())) < 1e-3

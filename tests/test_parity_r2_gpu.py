@@ -1,0 +1,275 @@
+"""Round-2 parity evidence on the GPU: FULL-WIDTH models and a BASELINE config end to end
+against fixtures produced by the REFERENCE's own modules (`oracle/make_golden.py --full`, run in the build container
+from /root/reference), the propagation kernel's DEFAULT fp16-coordinate mode against the reference run on half tensors,
+the error-vs-DDIM-step curve over 30 steps, and the d = 512 VAE attention at config 2's L = 102 400.
+
+Tolerances.  BASELINE.json: <= 1e-3 rel-L2 "vs reference".  The reference itself runs the UNet as `.half()`
+(inference_upscale_a_video.py:113-118); its own fp16 result is `reference_fp16_vs_fp32_rel_l2` away from its fp32 run
+(PINNING.json, measured per fixture with the reference module on CPU half tensors).  Bars asserted here:
+  UNet forward           no further from the reference's fp32 run than the reference's own fp16 run
+  VAE decode (fp32 ref)  <= 1e-3 in the default (fp32 residual stream) mode
+  pipeline latents       reported against the measured per-step growth; asserted <= 1e-2 after 5 steps
+Every measured number is appended to gpurun_out/parity.jsonl (committed under profiles/).
+"""
+import json
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+GOLD = os.path.join(ROOT, "tests", "golden")
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a = a.float().cpu(); b = b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+def report(name, **vals):
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity.jsonl"), "a") as fh:
+            fh.write(json.dumps(dict(case=name, **vals)) + "\n")
+
+
+def pinning(name):
+    return json.load(open(os.path.join(GOLD, "PINNING.json")))["cases"][name]
+
+
+# ------------------------------------------------------------------------------------------------
+# propagation: the production default (fp16 coordinates for fp16 latents) against the reference on half tensors
+@pytest.mark.parametrize("name", ["propagation_nearest_half", "propagation_bilinear_half", "propagation_nearest_half_ties",
+                                  "propagation_nearest_half_wide", "propagation_bilinear_half_wide"])
+def test_propagation_default_mode_vs_reference_half(dev, name):
+    import golden_cases as GC
+    from models_video.propagation_module import Propagation
+    kind, t, h, w, interp = GC.PROP_HALF_CASES[name]
+    x, ff, fb = GC.prop_half_inputs(kind, t, h, w)
+    prop = Propagation(4, learnable=False)
+    assert prop.coord_f16 is None                     # default: follow the latent dtype, like the reference
+    out = prop(x.half().to(dev), ff.half().to(dev), fb.half().to(dev), interpolation=interp, mode="fuse", fuse_scale=0.5,
+               alpha1=0.001, alpha2=0.05)
+    gold = torch.load(os.path.join(GOLD, name + ".pt"))
+    assert out.dtype == torch.float16 and out.shape == gold.shape
+    diff = (out.float().cpu() - gold.float()).abs()
+    exact = (diff == 0).float().mean().item()
+    bad = (diff > 1e-2).float().mean().item()
+    # the fp32-coordinate mode must NOT pass on the tie cases (that is what makes this test discriminating)
+    prop.coord_f16 = False
+    out32 = prop(x.half().to(dev), ff.half().to(dev), fb.half().to(dev), interpolation=interp, mode="fuse", fuse_scale=0.5,
+                 alpha1=0.001, alpha2=0.05)
+    bad32 = ((out32.float().cpu() - gold.float()).abs() > 1e-2).float().mean().item()
+    report(name, fraction_bit_exact=exact, fraction_off_by_1e_2=bad, fp32_coordinate_mode_fraction_off=bad32,
+           reference_half_vs_fp32_coordinates=pinning(name)["fraction_differing_from_fp32_coordinates"])
+    if interp == "nearest":
+        assert bad == 0.0, f"{name}: {bad} of the pixels picked another source pixel than the reference"
+        assert exact > 0.999
+    else:
+        assert bad < 2e-3                              # bilinear: weights replayed op by op; last-bit differences only
+    if "ties" in name or "wide" in name:
+        assert bad32 > 0.05
+
+
+def test_pipeline_default_precision_mix_vs_reference_half(dev):
+    """The whole pipeline in the CLI's real precision mix — fp16 text-encoder dtype (both randn draws in fp16), fp16
+    UNet, fp16 propagation with the DEFAULT coordinate mode, fp32 VAE output — against the reference pipeline run the
+    same way on CPU half tensors (tests/golden/pipe_t10_vaevideo_prop_refhalf.pt)."""
+    import golden_cases as GC
+    import synth
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
+    from models_video.propagation_module import Propagation
+    from models_video.scheduling_ddim import DDIMScheduler, DDPMScheduler
+    from models_video.unet_video import UNetVideoModel
+    from uav.standin_text import StandInTextEncoder, StandInTokenizer
+    case = GC.PIPE_CASES["pipe_t10_vaevideo_prop"]
+    unet = UNetVideoModel.from_config(dict(GC.UNET_TINY))
+    unet.load_state_dict(synth.synth_state_dict(unet.state_dict(), seed=1234), strict=True)
+    vae = AutoencoderKLVideo.from_config(dict(GC.VAEVIDEO_TINY))
+    vae.load_state_dict(synth.synth_state_dict(vae.state_dict(), seed=4321), strict=True)
+    tok = StandInTokenizer()
+    prop = Propagation(4, learnable=False)             # default coordinate mode
+    pipe = VideoUpscalePipeline(text_encoder=StandInTextEncoder(tok, GC.UNET_TINY["cross_attention_dim"], dtype=torch.float16),
+                                tokenizer=tok, low_res_scheduler=DDPMScheduler(), scheduler=DDIMScheduler(**GC.SCHED),
+                                vae=vae.to(dev).eval(), unet=unet.half().to(dev).eval(), propagator=prop).to(dev)
+    image, flows = GC.pipeline_inputs(case)
+    out, lat = pipe(case["prompt"], image=image.to(dev), flows_bi=[f.to(dev) for f in flows], generator=torch.Generator().manual_seed(10),
+                    num_inference_steps=case["steps"], guidance_scale=case["guidance"], noise_level=case["noise_level"],
+                    negative_prompt=case["negative"], propagation_steps=list(case["propagation_steps"]), return_dict=False)
+    gold = torch.load(os.path.join(GOLD, "pipe_t10_vaevideo_prop_refhalf.pt"))
+    e_lat = rel_l2(lat, gold["latents"])
+    unsat = gold["images"].float().abs() < 0.999
+    e_img = rel_l2(out.float().cpu()[unsat], gold["images"].float()[unsat])
+    report("pipe_t10_vaevideo_prop_refhalf", latents_rel_l2=e_lat, image_rel_l2_unsaturated=e_img)
+    assert e_lat < 1e-2, e_lat                         # two fp16 evaluations of the same 3 steps (same draws, same warps)
+    assert e_img < 3e-2, e_img
+
+
+# ------------------------------------------------------------------------------------------------
+# FULL-WIDTH models (released architecture) against the reference's own outputs
+@pytest.fixture(scope="module")
+def full(dev):
+    import golden_cases as GC
+    import synth
+    from uav import configs
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from models_video.unet_video import UNetVideoModel
+    unet = UNetVideoModel.from_config(dict(configs.UNET_VIDEO))
+    unet.load_state_dict(synth.synth_state_dict(unet.state_dict(), seed=1234), strict=True)
+    unet = unet.half().to(dev).eval()
+    vae = AutoencoderKLVideo.from_config(dict(configs.VAE_3D))
+    vae.load_state_dict(synth.synth_state_dict(vae.state_dict(), seed=4321), strict=True)
+    vae = vae.to(dev).eval()
+    return dict(GC=GC, synth=synth, configs=configs, unet=unet, vae=vae)
+
+
+def test_unet_full_width_forward_vs_reference(full, dev):
+    """691 M-parameter UNetVideoModel (channels 256-1024, K up to 2048*9), B2 x T8 x 64x64: one forward against the
+    reference module's fp32 output and against the reference's own `.half()` run."""
+    GC = full["GC"]
+    bsz, t, h, w = GC.FULL_CASES["unet_full_t8_64"]
+    sample, low, ehs, ts, cl = GC.unet_inputs(bsz, t, h, w, full["configs"].UNET_VIDEO["cross_attention_dim"])
+    with torch.no_grad():
+        out = full["unet"](sample.half().to(dev), ts, low.half().to(dev), encoder_hidden_states=ehs.half().to(dev), class_labels=cl).sample
+    gold = torch.load(os.path.join(GOLD, "unet_full_t8_64.pt"))
+    ref_noise = pinning("unet_full_t8_64")["reference_fp16_vs_fp32_rel_l2"]
+    e32, e16 = rel_l2(out, gold["fp32"]), rel_l2(out, gold["fp16"])
+    report("unet_full_t8_64", rel_l2_vs_reference_fp32=e32, rel_l2_vs_reference_fp16_run=e16, reference_fp16_vs_fp32=ref_noise)
+    assert out.shape == gold["fp32"].shape
+    assert e32 <= ref_noise, (e32, ref_noise)          # no further from the fp32 reference than the reference's fp16 path
+    assert e16 <= 1.5 * ref_noise, (e16, ref_noise)
+
+
+@pytest.mark.parametrize("mode", ["fp32_stream", "fp16_stream"])
+def test_vae_full_width_decode_vs_reference(full, dev, mode):
+    """55 M-parameter vae_3d decoder (channels 512/512/256/128), one 3-frame chunk 48x48 -> 192x192 against the
+    reference's fp32 decode.  `fp32_stream` (default): conv outputs, residual stream and GroupNorm inputs in fp32,
+    fp16 MFMA operands; `fp16_stream`: everything stored in fp16 (round-1 behaviour)."""
+    GC = full["GC"]
+    _, t, h, w = GC.FULL_CASES["vae3d_full_t3_48"]
+    z, img = GC.vae_inputs(1, t, h, w)
+    vae = full["vae"]
+    vae.stream_dtype = torch.float32 if mode == "fp32_stream" else torch.float16
+    try:
+        with torch.no_grad():
+            out = vae.decode(z.to(dev), img.to(dev), 1.0).sample
+    finally:
+        vae.stream_dtype = torch.float32
+    gold = torch.load(os.path.join(GOLD, "vae3d_full_t3_48.pt"))
+    e = rel_l2(out, gold)
+    report("vae3d_full_t3_48_" + mode, rel_l2_vs_reference_fp32=e, ref_absmean=pinning("vae3d_full_t3_48")["ref_absmean"])
+    assert out.shape == gold.shape and out.dtype == torch.float32
+    assert e < (1e-3 if mode == "fp32_stream" else 3e-3), e
+
+
+def test_baseline_config0_end_to_end_vs_reference(full, dev):
+    """BASELINE.json configs[0]: single 8-frame 128x128 -> 512x512 clip, 5 DDIM steps, guidance 6, no propagation,
+    full-width UNet + vae_3d, against the reference pipeline's own output (166 TFLOP on CPU, generated in the build
+    container; latents in full, image sub-sampled 4x + one full frame)."""
+    GC = full["GC"]
+    from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
+    from models_video.scheduling_ddim import DDIMScheduler, DDPMScheduler
+    from uav.standin_text import StandInTextEncoder, StandInTokenizer
+    pc = GC.FULL_CASES["pipe_c1_full"]
+    tok = StandInTokenizer()
+    pipe = VideoUpscalePipeline(text_encoder=StandInTextEncoder(tok, full["configs"].UNET_VIDEO["cross_attention_dim"], dtype=torch.float32),
+                                tokenizer=tok, low_res_scheduler=DDPMScheduler(), scheduler=DDIMScheduler(**GC.SCHED),
+                                vae=full["vae"], unet=full["unet"], propagator=None).to(dev)
+    clip = full["synth"].synth_clip(1, pc["t"], pc["h"], pc["w"], seed=pc["clip_seed"])
+    pipe.latents_trace = []
+    out, lat = pipe(pc["prompt"], image=clip.to(dev), generator=torch.Generator().manual_seed(10), num_inference_steps=pc["steps"],
+                    guidance_scale=pc["guidance"], noise_level=pc["noise_level"], negative_prompt=pc["negative"], return_dict=False)
+    gold = torch.load(os.path.join(GOLD, "pipe_c1_full.pt"))
+    e_lat = rel_l2(lat, gold["latents"])
+    sub = out.float().cpu()[..., ::4, ::4]
+    unsat = gold["images_sub4"].abs() < 0.999
+    e_img = rel_l2(sub[unsat], gold["images_sub4"][unsat])
+    f3 = gold["images_frame3"].float()
+    unsat3 = f3.abs() < 0.999
+    e_f3 = rel_l2(out.float().cpu()[:, :, 3][unsat3], f3[unsat3])
+    report("pipe_c1_full", latents_rel_l2=e_lat, image_sub4_rel_l2_unsaturated=e_img, image_frame3_rel_l2_unsaturated=e_f3,
+           saturated_fraction=1.0 - unsat.float().mean().item())
+    assert out.shape == (1, 3, pc["t"], 4 * pc["h"], 4 * pc["w"])
+    assert e_lat < 1e-2, e_lat
+    assert e_img < 3e-2 and e_f3 < 3e-2, (e_img, e_f3)
+
+
+# ------------------------------------------------------------------------------------------------
+def test_error_vs_ddim_step_curve_30_steps(dev):
+    """1/4-width models, 30 DDIM steps (the step count of BASELINE configs[1]), guidance 6: engine latents against the
+    fp32 oracle after EVERY step -> gpurun_out/parity_curve.jsonl (how the per-forward fp16 error accumulates)."""
+    import golden_cases as GC
+    import synth
+    import uav_oracle as O
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
+    from models_video.scheduling_ddim import DDIMScheduler, DDPMScheduler
+    from models_video.unet_video import UNetVideoModel
+    from uav.standin_text import StandInTextEncoder, StandInTokenizer
+    unet = UNetVideoModel.from_config(dict(GC.UNET_TINY))
+    usd = synth.synth_state_dict(unet.state_dict(), seed=1234)
+    unet.load_state_dict(usd, strict=True)
+    vae = AutoencoderKLVideo.from_config(dict(GC.VAE3D_TINY))
+    vsd = synth.synth_state_dict(vae.state_dict(), seed=4321)
+    vae.load_state_dict(vsd, strict=True)
+    t, h, w, steps = 8, 16, 16, 30
+    tok = StandInTokenizer()
+    dim = GC.UNET_TINY["cross_attention_dim"]
+    pipe = VideoUpscalePipeline(text_encoder=StandInTextEncoder(tok, dim, dtype=torch.float32), tokenizer=tok,
+                                low_res_scheduler=DDPMScheduler(), scheduler=DDIMScheduler(**GC.SCHED), vae=vae.to(dev).eval(),
+                                unet=unet.to(dev).eval(), propagator=None).to(dev)
+    clip = synth.synth_clip(1, t, h, w, seed=77)
+    pipe.latents_trace = []
+    out, lat = pipe("p", image=clip.to(dev), generator=torch.Generator().manual_seed(10), num_inference_steps=steps,
+                    guidance_scale=6.0, noise_level=120, negative_prompt="n", return_dict=False)
+    gen = torch.Generator().manual_seed(10)
+    lr_noise = torch.randn(clip.shape, generator=gen); lat0 = torch.randn((1, 4, t, h, w), generator=gen)
+    pe = torch.cat([synth.synth_prompt_embeds("n", dim), synth.synth_prompt_embeds("p", dim)])
+    with torch.no_grad():
+        oimg, olat, otrace = O.pipeline_call(usd, GC.UNET_TINY, vsd, GC.VAE3D_TINY, clip, pe, num_inference_steps=steps,
+                                             guidance_scale=6.0, noise_level=120, lr_noise=lr_noise, latents=lat0,
+                                             scheduler_kwargs=GC.SCHED, return_trace=True)
+    curve = [rel_l2(a, b) for a, b in zip(pipe.latents_trace, otrace)]
+    assert len(curve) == steps
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity_curve.jsonl"), "a") as fh:
+            fh.write(json.dumps({"case": "quarter_width_t8_16x16_30steps_guidance6", "latents_rel_l2_per_step": curve}) + "\n")
+    unsat = oimg.abs() < 0.999
+    e_img = rel_l2(out.float().cpu()[unsat], oimg[unsat])
+    report("curve_30_steps", latents_rel_l2_step1=curve[0], step5=curve[4], step15=curve[14], step30=curve[-1], image_rel_l2_unsaturated=e_img)
+    assert curve[-1] < 5e-2, curve                     # no blow-up: the error stays the size of a few fp16 forwards
+    assert max(curve) < 5e-2
+
+
+# ------------------------------------------------------------------------------------------------
+def test_attention_d512_at_config2_length(dev):
+    """VAE mid-block attention at BASELINE config 2's real size: ONE frame, L = 320*320 = 102 400 keys, d = 512.
+    Sampled query rows against a dense fp32 softmax over all 102 400 keys; inputs with the statistics the decoder
+    produces (q, k from a GroupNorm'ed tensor through a linear: unit variance, scores ~ N(0,1) after the d^-1/2 scale,
+    plus a few strongly matching q/k pairs so that the online-softmax rescale path is exercised)."""
+    from uav import ops
+    lq = lk = 102400
+    d = 512
+    gd = torch.Generator(device=dev).manual_seed(17)
+    q = torch.randn(lq, d, generator=gd, device=dev).half()
+    k = torch.randn(lk, d, generator=gd, device=dev).half()
+    v = torch.randn(lk, d, generator=gd, device=dev).half()
+    sel = torch.cat([torch.tensor([0, 1, 63, 64, 255, 256, lq - 1]), torch.randint(0, lq, (89,))])
+    for i, r in enumerate(sel[:8].tolist()):           # spikes: key (r*7919 % lk) is a scaled copy of query r
+        k[(r * 7919) % lk] = (q[r].float() * (0.35 + 0.05 * i)).half()
+    out = ops.attention(q, k, v, bq=1, lq=lq, lk=lk, heads=1, head_dim=d)
+    sel = sel.to(dev)
+    s = (q[sel].float() @ k.float().t()) * d ** -0.5
+    ref = torch.softmax(s, dim=-1) @ v.float()
+    e = rel_l2(out[sel], ref)
+    vc = torch.full((lk, d), 0.75, device=dev).half()
+    oc = ops.attention(q, k, vc, bq=1, lq=lq, lk=lk, heads=1, head_dim=d)
+    dev_const = (oc.float() - 0.75).abs().max().item()
+    report("attention_d512_L102400", sampled_rows=int(sel.numel()), rel_l2_vs_dense_fp32_softmax=e, const_v_max_dev=dev_const)
+    assert e < 3e-3, e
+    assert dev_const < 2e-3

@@ -366,11 +366,8 @@ __global__ __launch_bounds__(512, 2) void attn512_kernel(AttnArgs p) {
 }
 
 int launch_attn512(const AttnArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn512_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM5);
-        attr_set = true;
-    }
+    static UavDynLds lds;
+    if (int rc = uav_set_dyn_lds(lds, (const void*)attn512_kernel, SMEM5)) return rc;
     dim3 grid((a.lq + 127) / 128, 1, a.bq);
     hipLaunchKernelGGL(attn512_kernel, grid, dim3(512), SMEM5, s, a);
     return uav_launch_status();
@@ -379,11 +376,9 @@ int launch_attn512(const AttnArgs& a, hipStream_t s) {
 template <int D>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
     using C = AttnCfg<D>;
-    static bool attr_set = false;
-    if (!attr_set && C::SMEM > 65536) {
-        (void)hipFuncSetAttribute((const void*)attn_kernel<D>, hipFuncAttributeMaxDynamicSharedMemorySize, C::SMEM);
-        attr_set = true;
-    }
+    static UavDynLds lds;
+    if (C::SMEM > 65536)
+        if (int rc = uav_set_dyn_lds(lds, (const void*)attn_kernel<D>, C::SMEM)) return rc;
     dim3 grid((a.lq + 127) / 128, a.heads, a.bq);
     hipLaunchKernelGGL(attn_kernel<D>, grid, dim3(256), C::SMEM, s, a);
     return uav_launch_status();

@@ -25,6 +25,7 @@
 // launch = 2*M*N*K_logical.
 #include "uav_common.h"
 #include <stdlib.h>
+#include <mutex>
 
 namespace {
 
@@ -145,6 +146,43 @@ UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], 
     }
 }
 
+// fp32-output fast path (VAE decoder in fp32-stream mode: conv outputs, residual stream and GroupNorm inputs stay fp32,
+// only the MFMA operands are fp16).  A lane owns pixel m and, per register quad g, 4 consecutive channels: one float4
+// (16-B) store per quad straight from the accumulators, one float4 load for an fp32 residual; no half-wave exchange.
+// Same arithmetic order as the fp16 paths: ((acc + bias) + residual) * out_scale.
+template <int NI, int MI, bool RES>
+UAV_DEVINL void conv_epilogue_f32_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32) {
+    const float osc = p.out_scale;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        float4_t bq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bq[g] = *(const float4_t*)(p.bias + nw0 + ni * 32 + 8 * g + 4 * hi32);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const long long m = mw0 + mi * 32 + l32;
+            float* orow = (float*)p.out + m * p.out_stride + nw0 + ni * 32 + 4 * hi32;
+            const float* rrow = RES ? (const float*)p.residual + m * p.res_stride + nw0 + ni * 32 + 4 * hi32 : nullptr;
+            float4_t R[4];
+            if (RES) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) R[g] = *(const float4_t*)(rrow + 8 * g);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                float4_t o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v = acc[ni][mi][4 * g + j] + bq[g][j];
+                    if (RES) v += R[g][j];
+                    o[j] = v * osc;
+                }
+                *(float4_t*)(orow + 8 * g) = o;
+            }
+        }
+    }
+}
+
 // GEGLU fast path (same preconditions; no residual / rowbias by contract): value/gate tile pairs (2b, 2b+1).
 template <int NI, int MI, bool BIAS>
 UAV_DEVINL void conv_epilogue_geglu_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32) {
@@ -192,8 +230,15 @@ template <int NI, int MI>
 UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32) {
     const bool geglu = p.flags & UAV_CONV_GEGLU;
     const bool of32 = p.flags & UAV_CONV_OUT_F32;
+    const bool rf32 = p.flags & UAV_CONV_RES_F32;
+    if (of32 && !geglu && p.bias && !p.rowbias && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n && !(p.out_stride & 3) &&
+        (!p.residual || (rf32 && !(p.res_stride & 3)))) {
+        if (p.residual) conv_epilogue_f32_fast<NI, MI, true>(p, acc, mw0, nw0, l32, hi32);
+        else conv_epilogue_f32_fast<NI, MI, false>(p, acc, mw0, nw0, l32, hi32);
+        return;
+    }
     // wave-uniform fast-path test
-    if (!of32 && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n && !(p.out_stride & 7) &&
+    if (!of32 && !rf32 && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n && !(p.out_stride & 7) &&
         (!p.residual || !(p.res_stride & 7))) {
         if (geglu) {
             if (p.bias) conv_epilogue_geglu_fast<NI, MI, true>(p, acc, mw0, nw0, l32, hi32);
@@ -268,7 +313,7 @@ UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long 
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
                 const int nq = nw0 + ni * 32 + 16 * gp;               // first channel of this quad pair (wave-uniform)
-                const bool wide = !of32 && (nq + 16 <= p.n) && !(p.out_stride & 7) && !(p.res_stride & 7);
+                const bool wide = !of32 && !rf32 && (nq + 16 <= p.n) && !(p.out_stride & 7) && !(p.res_stride & 7);
                 if (wide) {
                     const int nl = nq + 8 * hi32;                     // the 8 channels this lane loads / stores
                     uint32_t R[4] = {0, 0, 0, 0};
@@ -330,9 +375,15 @@ UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long 
                             for (int j = 0; j < 4; ++j) v[j] += b[j];
                         }
                         if (p.residual) {
-                            half4_t r = *(const half4_t*)(p.residual + ((long long)m * p.res_stride + n) * 2);
+                            if (rf32) {
+                                float4_t r = *(const float4_t*)(p.residual + ((long long)m * p.res_stride + n) * 4);
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                                for (int j = 0; j < 4; ++j) v[j] += r[j];
+                            } else {
+                                half4_t r = *(const half4_t*)(p.residual + ((long long)m * p.res_stride + n) * 2);
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) v[j] += (float)r[j];
+                            }
                         }
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] *= p.out_scale;
@@ -790,6 +841,7 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     if (q->rowbias && (q->rows_per_batch <= 0 || (q->rowbias_stride % 4))) return UAV_ESHAPE;
     if ((q->flags & UAV_CONV_GEGLU) && ((q->flags & UAV_CONV_OUT_F32) || q->residual || q->rowbias || (q->n % 64)))
         return UAV_ESHAPE;
+    if ((q->flags & UAV_CONV_RES_F32) && !q->residual) return UAV_EINVAL;
     if (q->upsample && (q->stride != 1 || q->ho != 2 * q->hi || q->wo != 2 * q->wi)) return UAV_ESHAPE;
     if (q->t_len <= 0 || q->n_img % q->t_len) return UAV_ESHAPE;
     if (q->ho >= 65536 || q->wo >= 65536) return UAV_ESHAPE;
@@ -806,12 +858,18 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     a.zero_page = (const char*)q->zero_page;
     a.M = (long long)q->n_img * q->ho * q->wo;
     if (a.M <= 0 || a.M >= (1ll << 31)) return UAV_ESHAPE;
-    static int korder = -1;
-    if (korder < 0) { const char* e = getenv("UAV_CONV_KORDER"); korder = e ? atoi(e) : 1; }
-    a.korder = korder;
-    static int tile_order = -1;
-    if (tile_order < 0) { const char* e = getenv("UAV_CONV_TILE_ORDER"); tile_order = e ? atoi(e) : 1; }
-    a.tile_order = tile_order;
+    // One-time setup.  Environment switches (development A/B only) are read once through a thread-safe magic static;
+    // the dynamic-LDS attribute of the 256x256 kernels and the CU count are PER DEVICE (std::call_once per device index),
+    // so a second GPU, or a second host thread driving the library (bench --clips-per-step), never launches before the
+    // attribute is in place.
+    struct ConvEnv { int korder, tile_order, force_tile, dbg, persist; };
+    static const ConvEnv env = [] {
+        auto geti = [](const char* k, int d) { const char* e = getenv(k); return e ? atoi(e) : d; };
+        return ConvEnv{geti("UAV_CONV_KORDER", 1), geti("UAV_CONV_TILE_ORDER", 1), geti("UAV_CONV_TILE", 0),
+                       geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0)};
+    }();
+    a.korder = env.korder;
+    a.tile_order = env.tile_order;
     const long long mtiles = (a.M + BM - 1) / BM;
     const long long grid = mtiles * (q->n_pad / BN);
     if (grid >= (1ll << 31)) return UAV_ESHAPE;
@@ -819,27 +877,26 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     // tile selection: the 256x256 kernel needs n_pad % 256 == 0 and enough tiles to fill 256 CUs
     const long long mtiles256 = (a.M + LM - 1) / LM;
     const long long grid256 = mtiles256 * (q->n_pad / LN);
-    static int force_tile = -1;
-    if (force_tile < 0) { const char* e = getenv("UAV_CONV_TILE"); force_tile = e ? atoi(e) : 0; }
+    const int force_tile = env.force_tile;
     const bool big = !small && (q->n_pad % LN == 0) && (force_tile >= 256 || (force_tile != 128 && grid256 >= 224));
     if (big) {
-        static int dbg = -1, persist = 0;
-        static long long ncu = 256;
+        constexpr int MAXDEV = 64;
+        static std::once_flag dev_once[MAXDEV];
+        static long long dev_ncu[MAXDEV];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return UAV_EINVAL;
+        std::call_once(dev_once[dev], [dev] {
+            const void* fns[] = {(const void*)conv_gemm256_kernel<0>, (const void*)conv_gemm256_kernel<1>,
+                                 (const void*)conv_gemm256_kernel<2>, (const void*)conv_gemm256_kernel<3>,
+                                 (const void*)conv_gemm256_kernel<4>, (const void*)conv_gemm256_kernel<5>,
+                                 (const void*)conv_gemm256_kernel<6>, (const void*)conv_gemm256_kernel<0, 1>};
+            for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
+            hipDeviceProp_t prop;
+            dev_ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+        });
+        const long long ncu = dev_ncu[dev];
+        const int dbg = env.dbg, persist = env.persist;
         a.ntiles = (unsigned)grid256;
-        if (dbg < 0) {
-            const char* e = getenv("UAV_CONV_DBG"); dbg = e ? atoi(e) : 0;
-            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
-            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
-            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
-            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
-            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
-            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
-            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
-            (void)hipFuncSetAttribute((const void*)conv_gemm256_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
-            const char* pe = getenv("UAV_CONV_PERSIST"); persist = pe ? atoi(pe) : 0;      // force for whole-model A/B runs
-            int dev = 0; hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) ncu = prop.multiProcessorCount;
-        }
         if (dbg == 1) hipLaunchKernelGGL(conv_gemm256_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 2) hipLaunchKernelGGL(conv_gemm256_kernel<2>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 4) hipLaunchKernelGGL(conv_gemm256_kernel<4>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);

@@ -152,6 +152,29 @@ __global__ __launch_bounds__(256) void axpby_kernel(const half_t* __restrict__ x
     y[i] = (half_t)(a * (float)x[i] + b * (float)z[i]);
 }
 
+// fp32 rows -> fp16 rows (the VAE decoder's fp32 residual stream feeding a conv operand directly, i.e. the
+// nearest-2x upsampler conv), 8 elements per thread.
+__global__ __launch_bounds__(256) void cast_f32_f16_kernel(const float* __restrict__ x, half_t* __restrict__ y, long long n) {
+    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i + 8 <= n) {
+        const float4_t a = *(const float4_t*)(x + i), b = *(const float4_t*)(x + i + 4);
+        half8_t o = {(half_t)a[0], (half_t)a[1], (half_t)a[2], (half_t)a[3], (half_t)b[0], (half_t)b[1], (half_t)b[2], (half_t)b[3]};
+        *(half8_t*)(y + i) = o;
+    } else {
+        for (long long j = i; j < n; ++j) y[j] = (half_t)x[j];
+    }
+}
+
+// SFT fusion of the video VAE (Fuse_sft_block, resnet.py:76-78): out = dec + w*(dec*scale + shift) = dec*(1 + w*scale) + w*shift
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void sft_fuse_kernel(const TI* __restrict__ dec, const TI* __restrict__ scale,
+                                                       const TI* __restrict__ shift, TO* __restrict__ out, long long n, float w) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float d = (float)dec[i];
+    out[i] = (TO)(d + w * (d * (float)scale[i] + (float)shift[i]));
+}
+
 // ---------------------------------------------------------------------------------------------
 // Propagation step.  R = rounding policy: fp16 replay of the reference's GPU arithmetic
 // (flow_warp builds the grid in the latent dtype, propagation_module.py:123-132; ATen's
@@ -318,6 +341,30 @@ extern "C" int uav_axpby_f16(const void* x, const void* z, void* y, int64_t n, f
     if (!x || !z || !y || n <= 0) return UAV_EINVAL;
     hipLaunchKernelGGL(axpby_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x,
                        (const half_t*)z, (half_t*)y, (long long)n, a, b);
+    return uav_launch_status();
+}
+
+extern "C" int uav_cast_f32_f16(const float* x, void* y, int64_t n, void* stream) {
+    if (!x || !y || n <= 0) return UAV_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return UAV_EALIGN;
+    hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(nblk((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, (half_t*)y,
+                       (long long)n);
+    return uav_launch_status();
+}
+
+extern "C" int uav_sft_fuse(const void* dec, const void* scale, const void* shift, void* out, int64_t n, float w,
+                            int32_t in_f32, int32_t out_f32, void* stream) {
+    if (!dec || !scale || !shift || !out || n <= 0) return UAV_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(nblk(n, 256)), blk(256);
+    if (in_f32 && out_f32)
+        hipLaunchKernelGGL((sft_fuse_kernel<float, float>), grid, blk, 0, s, (const float*)dec, (const float*)scale, (const float*)shift, (float*)out, (long long)n, w);
+    else if (in_f32)
+        hipLaunchKernelGGL((sft_fuse_kernel<float, half_t>), grid, blk, 0, s, (const float*)dec, (const float*)scale, (const float*)shift, (half_t*)out, (long long)n, w);
+    else if (out_f32)
+        hipLaunchKernelGGL((sft_fuse_kernel<half_t, float>), grid, blk, 0, s, (const half_t*)dec, (const half_t*)scale, (const half_t*)shift, (float*)out, (long long)n, w);
+    else
+        hipLaunchKernelGGL((sft_fuse_kernel<half_t, half_t>), grid, blk, 0, s, (const half_t*)dec, (const half_t*)scale, (const half_t*)shift, (half_t*)out, (long long)n, w);
     return uav_launch_status();
 }
 

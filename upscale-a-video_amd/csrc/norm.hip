@@ -23,13 +23,26 @@ struct GnSrc {
     const char* x1; const char* x2; int c1, c2;
 };
 
-UAV_DEVINL const char* gn_vec_ptr(const GnSrc& s, long long row, int v) {
-    // v = vector index (8 channels) inside the concatenated row
+// 8 consecutive channels (vector index v inside the concatenated row) as fp32.  F32 = the rows are fp32 (fp32
+// residual stream of the VAE decoder: conv outputs are normalised without an intermediate fp16 rounding).
+template <bool F32>
+UAV_DEVINL void gn_load8(const GnSrc& s, long long row, int v, float (&f)[8]) {
     const int v1 = s.c1 >> 3;
-    return v < v1 ? s.x1 + (row * s.c1 + (long long)v * 8) * 2
-                  : s.x2 + (row * s.c2 + (long long)(v - v1) * 8) * 2;
+    const bool first = v < v1;
+    const char* base = first ? s.x1 : s.x2;
+    const long long e = first ? row * s.c1 + (long long)v * 8 : row * s.c2 + (long long)(v - v1) * 8;
+    if (F32) {
+        const float4_t a = *(const float4_t*)(base + e * 4), b = *(const float4_t*)(base + e * 4 + 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { f[j] = a[j]; f[4 + j] = b[j]; }
+    } else {
+        const half8_t x = *(const half8_t*)(base + e * 2);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (float)x[j];
+    }
 }
 
+template <bool F32>
 __global__ __launch_bounds__(256) void gn_partial_kernel(GnSrc s, long long rows_per_inst, int chunks,
                                                          float* __restrict__ ws) {
     __shared__ float red[256 * 16];
@@ -48,17 +61,20 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnSrc s, long long rows
     if (active) {
         constexpr int U = 8;                                // independent 16-B loads in flight per thread
         for (long long r = r0 + ro; r < r1; r += (long long)rpp * U) {
-            half8_t x[U];
+            float x[U][8];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const long long rr = r + (long long)u * rpp;
-                half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-                x[u] = rr < r1 ? *(const half8_t*)gn_vec_ptr(s, inst * rows_per_inst + rr, v) : z;
+                if (rr < r1) gn_load8<F32>(s, inst * rows_per_inst + rr, v, x[u]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) x[u][j] = 0.f;
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { float f = (float)x[u][j]; sm[j] += f; sq[j] += f * f; }
+                for (int j = 0; j < 8; ++j) { float f = x[u][j]; sm[j] += f; sq[j] += f * f; }
         }
     }
 #pragma unroll
@@ -115,6 +131,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
         for (int ch = c_real + tid; ch < c; ch += 256) { scale[(long long)inst * c + ch] = 0.f; shift[(long long)inst * c + ch] = 0.f; }
 }
 
+template <bool F32>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc s, long long rows_per_inst, int chunks,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
                                                        int silu, char* __restrict__ y) {
@@ -132,11 +149,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc s, long long rows_p
     for (int j = 0; j < 8; ++j) { sc[j] = scale[(long long)inst * c + v * 8 + j]; sh[j] = shift[(long long)inst * c + v * 8 + j]; }
     for (long long r = r0 + ro; r < r1; r += rpp) {
         const long long row = inst * rows_per_inst + r;
-        half8_t x = *(const half8_t*)gn_vec_ptr(s, row, v);
+        float x[8];
+        gn_load8<F32>(s, row, v, x);
         half8_t o;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float f = (float)x[j] * sc[j] + sh[j];
+            float f = x[j] * sc[j] + sh[j];
             if (silu) f = uav_silu(f);
             o[j] = (half_t)f;
         }
@@ -208,7 +226,7 @@ extern "C" int64_t uav_groupnorm_workspace_bytes(int32_t n_inst, int32_t c) {
     return (int64_t)n_inst * GN_MAX_CHUNKS * c * 2 * 4;
 }
 
-extern "C" int uav_groupnorm_scale_shift(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t c_real,
+extern "C" int uav_groupnorm_scale_shift(const void* x1, const void* x2, int32_t x_f32, int32_t c1, int32_t c2, int32_t c_real,
                                          int32_t n_inst, int64_t rows_per_inst, int32_t groups, float eps,
                                          const float* gamma, const float* beta, float* scale_out, float* shift_out,
                                          void* workspace, int64_t workspace_bytes, void* stream) {
@@ -221,14 +239,18 @@ extern "C" int uav_groupnorm_scale_shift(const void* x1, const void* x2, int32_t
     if (workspace_bytes < (int64_t)n_inst * chunks * c * 2 * 4) return UAV_EINVAL;
     GnSrc s{(const char*)x1, (const char*)x2, c1, c2};
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, n_inst), dim3(256), 0, st, s, (long long)rows_per_inst, chunks,
-                       (float*)workspace);
+    if (x_f32)
+        hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(chunks, n_inst), dim3(256), 0, st, s, (long long)rows_per_inst, chunks,
+                           (float*)workspace);
+    else
+        hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(chunks, n_inst), dim3(256), 0, st, s, (long long)rows_per_inst, chunks,
+                           (float*)workspace);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n_inst), dim3(256), 0, st, (const float*)workspace, chunks, c, c_real,
                        groups, (long long)rows_per_inst, eps, gamma, beta, scale_out, shift_out);
     return uav_launch_status();
 }
 
-extern "C" int uav_groupnorm_apply(const void* x1, const void* x2, int32_t c1, int32_t c2, int32_t n_inst,
+extern "C" int uav_groupnorm_apply(const void* x1, const void* x2, int32_t x_f32, int32_t c1, int32_t c2, int32_t n_inst,
                                    int64_t rows_per_inst, const float* scale, const float* shift, int32_t silu, void* y,
                                    void* stream) {
     if (!x1 || !scale || !shift || !y) return UAV_EINVAL;
@@ -241,8 +263,12 @@ extern "C" int uav_groupnorm_apply(const void* x1, const void* x2, int32_t c1, i
     if (chunks > want) chunks = want;
     if (chunks < 1) chunks = 1;
     GnSrc s{(const char*)x1, (const char*)x2, c1, c2};
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)chunks, n_inst), dim3(256), 0, (hipStream_t)stream, s,
-                       (long long)rows_per_inst, (int)chunks, scale, shift, silu, (char*)y);
+    if (x_f32)
+        hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((unsigned)chunks, n_inst), dim3(256), 0, (hipStream_t)stream, s,
+                           (long long)rows_per_inst, (int)chunks, scale, shift, silu, (char*)y);
+    else
+        hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)chunks, n_inst), dim3(256), 0, (hipStream_t)stream, s,
+                           (long long)rows_per_inst, (int)chunks, scale, shift, silu, (char*)y);
     return uav_launch_status();
 }
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
 #include "../../include/uav_hip.h"
 
 typedef _Float16 half_t;
@@ -20,6 +21,16 @@ typedef uint32_t uint2_t __attribute__((ext_vector_type(2)));
 static inline int uav_launch_status() {
     hipError_t e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
+}
+
+// Per-device one-time raise of a kernel's dynamic-LDS limit (the attribute is per device; a function-local `static bool`
+// would cover only the device that happened to be current at the first call and races between host threads).
+struct UavDynLds { std::once_flag once[64]; };
+static inline int uav_set_dyn_lds(UavDynLds& st, const void* fn, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return UAV_EINVAL;
+    std::call_once(st.once[dev], [fn, bytes] { (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
+    return 0;
 }
 
 UAV_DEVINL float uav_silu(float x) { return x / (1.0f + __expf(-x)); }

@@ -65,7 +65,8 @@ class BasicEncoder(E.EngineModule):
                 w = w * s[:, None, None, None]
                 b = (b - bn.running_mean.detach().float()) * s + bn.bias.detach().float()
             return ops.pack_conv_f32(w, b, device=dev)
-        return self._cache().get(("c", key), build)
+        return self._cache().get(("c", key), build, (conv.weight, conv.bias) + ((bn.weight, bn.bias, bn.running_mean, bn.running_var)
+                                                                           if isinstance(bn, nn.BatchNorm2d) else ()))
 
     def _conv_norm(self, key, x, conv, norm, n, h, w, relu):
         s, p = conv.stride[0], conv.padding
@@ -128,14 +129,15 @@ class BasicUpdateBlock(E.EngineModule):
 
     def pk(self, key, conv, cin_pad_to=None):
         return self._cache().get(("c", key), lambda: ops.pack_conv_f32(conv.weight, conv.bias, device=E._dev(conv.weight),
-                                                                      cin_pad_to=cin_pad_to))
+                                                                      cin_pad_to=cin_pad_to), (conv.weight, conv.bias))
 
     def pk_zr(self, sfx):
         def build():
             z, r = getattr(self.gru, "convz" + sfx), getattr(self.gru, "convr" + sfx)
             return ops.pack_conv_f32(torch.cat([z.weight.detach(), r.weight.detach()], 0),
                                      torch.cat([z.bias.detach(), r.bias.detach()], 0), device=E._dev(z.weight))
-        return self._cache().get(("zr", sfx), build)
+        z, r = getattr(self.gru, "convz" + sfx), getattr(self.gru, "convr" + sfx)
+        return self._cache().get(("zr", sfx), build, (z.weight, z.bias, r.weight, r.bias))
 
 
 class RAFT(E.EngineModule):
@@ -218,6 +220,7 @@ class RAFT(E.EngineModule):
         up = ops.convex_upsample_f32(flow, mask, P, h, w)                                # (P,2,H,W)
         return up[:t - 1].contiguous(), up[t - 1:].contiguous()
 
+    @E.guarded
     def forward(self, image1, image2, iters=12, flow_init=None, test_mode=True):
         """Reference signature: batched pairs (N,3,H,W) -> (low-res flow is not exposed here, flow_up)."""
         if flow_init is not None or not test_mode:

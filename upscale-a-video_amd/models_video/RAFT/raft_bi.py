@@ -7,6 +7,7 @@ of 8 (they are identities otherwise and skipped).
 import torch
 import torch.nn as nn
 
+from uav import engine as E
 from uav import ops
 
 from .raft import RAFT
@@ -38,6 +39,7 @@ class RAFT_bi(nn.Module):
             p.requires_grad = False
         self.eval()
 
+    @E.guarded
     def forward(self, gt_local_frames, iters=20):
         b, c, t, h, w = gt_local_frames.size()
         h8, w8 = -(-h // 8) * 8, -(-w // 8) * 8

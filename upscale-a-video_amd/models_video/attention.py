@@ -134,7 +134,8 @@ class TemporalAttention(CrossAttention):
                 ang = torch.arange(t_len, device=dev, dtype=torch.float32)[:, None] * fr[None, :]
                 return bias, ang.cos().contiguous(), ang.sin().contiguous(), 2 * fr.numel()
             return bias, None, None, 0
-        return self._cache().get(("ttab", t_len), build)
+        return self._cache().get(("ttab", t_len), build, (self.time_rel_pos_bias.relative_attention_bias.weight,
+                                                          None if self.rotary_emb is None else self.rotary_emb.freqs))
 
     def run_temporal(self, x, residual, g: E.Geom):
         c = self.heads * self.dim_head
@@ -195,10 +196,11 @@ class BasicTransformerBlock(E.EngineModule):
         `ehs_rows` (so its storage cannot be recycled) and is keyed on identity + version."""
         c = self._cache()
         hit = c.store.get(("textkv", tag))
-        if hit is not None and hit[0] is ehs_rows and hit[1] == ehs_rows._version:
+        wstamp = E._stamp((attn.to_k.weight, attn.to_v.weight))      # in-place weight edits invalidate the projection too
+        if hit is not None and hit[0] is ehs_rows and hit[1] == ehs_rows._version and hit[3] == wstamp:
             return hit[2]
         kv = attn.project_text(ehs_rows)
-        c.store[("textkv", tag)] = (ehs_rows, ehs_rows._version, kv)
+        c.store[("textkv", tag)] = (ehs_rows, ehs_rows._version, kv, wstamp)
         return kv
 
     def run(self, x, g: E.Geom, ehs_rows, n_text):

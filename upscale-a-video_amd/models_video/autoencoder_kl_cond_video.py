@@ -43,7 +43,14 @@ class AutoencoderKLVideo(ModelMixin, ConfigMixin, E.EngineModule):
         self.post_quant_conv = InflatedConv3d(latent_channels, latent_channels, 1)
         self.use_slicing = False
         self.use_tiling = False
+        # Decoder stream precision.  None (default): follow the parameter dtype like the reference does — an fp32 VAE (what
+        # the CLI builds, inference_upscale_a_video.py:104-111, decoded in fp32 at pipeline:668-681) keeps conv outputs,
+        # the residual stream and GroupNorm inputs in fp32 with fp16 MFMA operands (10-bit mantissa operands + fp32
+        # accumulation: the arithmetic cuDNN's default TF32 convolutions give the reference on its own GPUs); `.half()`
+        # selects the all-fp16 rows of round 1 (faster, ~2x the error).  torch.float32 / torch.float16 force a mode.
+        self.stream_dtype = None
 
+    @E.guarded
     def encode(self, x, return_dict: bool = True):
         rows, g = E.to_rows(x, c_pad=8)
         h, g2 = self.encoder.run(rows, g)                                     # fp32 rows [..][2*latent]
@@ -52,6 +59,7 @@ class AutoencoderKLVideo(ModelMixin, ConfigMixin, E.EngineModule):
         post = DiagonalGaussianDistribution(m)
         return AutoencoderKLOutput(latent_dist=post) if return_dict else (post,)
 
+    @E.guarded
     def decode_rows(self, z, img=None, w_lr=1.0, latent_scale=1.0):
         """z (B,4,T,H,W) -> fp32 output rows [B*T*4H*4W][4] (3 real channels) + geometry."""
         zr, g = E.to_rows(z, c_pad=8, scale=latent_scale)
@@ -61,7 +69,8 @@ class AutoencoderKLVideo(ModelMixin, ConfigMixin, E.EngineModule):
         ir = None
         if img is not None and self.decoder.condition_img:
             ir, _ = E.to_rows(img, c_pad=8)
-        return self.decoder.run(zq, g, ir, w_lr)
+        sd = self.stream_dtype if self.stream_dtype is not None else self.decoder.conv_in.weight.dtype
+        return self.decoder.run(zq, g, ir, w_lr, stream_f32=sd == torch.float32)
 
     def decode(self, z, img=None, w_lr=1, return_dict: bool = True, clamp=None):
         y, g2 = self.decode_rows(z, img, float(w_lr))

@@ -27,6 +27,7 @@ from typing import List, Optional, Union
 import torch
 
 from uav import dist as D
+from uav import engine as E
 from uav import ops
 
 from ._compat import BaseOutput, ConfigMixin
@@ -76,6 +77,7 @@ class VideoUpscalePipeline(ConfigMixin):
         # one LONG clip over several GPUs (BASELINE config 4): deal the temporal windows of each DDIM step and the decode
         # chunks over the ranks of the default process group; results are bit-identical to the single-GPU call
         self.shard_windows = False
+        self.latents_trace = None          # test hook: set to a list to collect the latents after every DDIM step
         self.cache_prompt_embeds = True
         self._prompt_cache = {}
 
@@ -173,15 +175,21 @@ class VideoUpscalePipeline(ConfigMixin):
             return self._encode_prompt(prompt, device, num_images_per_prompt, do_cfg, negative_prompt,
                                        prompt_embeds=prompt_embeds, negative_prompt_embeds=negative_prompt_embeds)
         stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
-        key = (prompt, negative_prompt, bool(do_cfg), int(num_images_per_prompt), str(dev), stream,
-               id(self.text_encoder), id(self.tokenizer))
+        key = (prompt, negative_prompt, bool(do_cfg), int(num_images_per_prompt), str(dev), stream)
         hit = self._prompt_cache.get(key)
+        # an entry is valid only for the encoder / tokenizer OBJECTS that made it (held weakly: `id()` alone can be
+        # recycled after garbage collection) and for the encoder's current parameter values
+        enc_stamp = E._stamp(list(self.text_encoder.parameters())[:4]) if hasattr(self.text_encoder, "parameters") else ()
+        if hit is not None and (hit[1]() is not self.text_encoder or hit[2]() is not self.tokenizer or hit[3] != enc_stamp):
+            hit = None
         if hit is None:
-            hit = self._encode_prompt(prompt, device, num_images_per_prompt, do_cfg, negative_prompt)
+            import weakref
+            emb = self._encode_prompt(prompt, device, num_images_per_prompt, do_cfg, negative_prompt)
             if len(self._prompt_cache) >= 8:
                 self._prompt_cache.clear()
+            hit = (emb, weakref.ref(self.text_encoder), weakref.ref(self.tokenizer), enc_stamp)
             self._prompt_cache[key] = hit
-        return hit
+        return hit[0]
 
     def check_inputs(self, prompt, image, noise_level, negative_prompt=None, prompt_embeds=None,
                      negative_prompt_embeds=None):
@@ -246,6 +254,12 @@ class VideoUpscalePipeline(ConfigMixin):
         if batch_size != 1 or num_images_per_prompt != 1:
             raise NotImplementedError("the CLI upscales one clip per call")
         device = self._execution_device
+        if device.type == "cuda" and device.index is not None and device.index != torch.cuda.current_device():
+            # launches go to the current device's stream (uav/ops.py:_stream): make the pipeline's GPU current
+            with torch.cuda.device(device):
+                return self.__call__(prompt, image, flows_bi, num_inference_steps, guidance_scale, noise_level, denoise_level,
+                                     negative_prompt, num_images_per_prompt, eta, generator, latents, prompt_embeds,
+                                     negative_prompt_embeds, propagation_steps, w_lr, return_dict, progress)
         do_cfg = guidance_scale > 1.0
 
         prompt_embeds = self._cached_prompt_embeds(prompt, device, num_images_per_prompt, do_cfg, negative_prompt,
@@ -320,6 +334,8 @@ class VideoUpscalePipeline(ConfigMixin):
                 x0 = self.propagator(x0, flows_f, flows_b, interpolation="nearest", mode="fuse", fuse_scale=0.5,
                                      alpha1=0.001, alpha2=0.05).contiguous()
             latents = self.scheduler.step_vt(x0, guided, t, latents).prev_sample
+            if self.latents_trace is not None:        # test hook: per-step latents (error-vs-step curves)
+                self.latents_trace.append(latents.clone())
 
         latents_out = latents.float()
         # 11. decode in chunks of 3 frames on the GLOBAL frame index (:685-702)

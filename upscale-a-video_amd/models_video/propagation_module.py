@@ -14,6 +14,7 @@ nearest-neighbour index is discontinuous in the coordinates.
 import torch
 import torch.nn as nn
 
+from uav import engine as E
 from uav import ops
 
 
@@ -31,6 +32,7 @@ class Propagation(nn.Module):
         self.module = ["backward_prop", "forward_prop"]
         self.coord_f16 = None          # None: follow the latent dtype like the reference; True/False to force
 
+    @E.guarded
     def forward(self, x, flows_forward, flows_backward, interpolation="bilinear", mode="fuse", fuse_scale=0.5,
                 alpha1=0.01, alpha2=0.5):
         b, c, t, h, w = x.shape

@@ -57,10 +57,11 @@ class InflatedConv3d(nn.Conv2d, E.EngineModule):
 class Conv3dK11(nn.Conv3d, E.EngineModule):
     """nn.Conv3d container (temporal (k,1,1) and 3x3x3 kernels) executed by the implicit GEMM."""
 
-    def run(self, x, g: E.Geom, *, residual=None, out_scale=1.0, rowbias=None):
+    def run(self, x, g: E.Geom, *, residual=None, out_scale=1.0, rowbias=None, out_f32=False):
         cw = E.packed_conv(self, "w", self)
         return ops.conv_gemm(x, cw, n_img=g.n_img, t_len=g.t, hi=g.h, wi=g.w, stride=1, pad=tuple(self.padding),
-                             residual=residual, out_scale=out_scale, rowbias=rowbias, rows_per_batch=g.rows_per_batch)
+                             residual=residual, out_scale=out_scale, rowbias=rowbias, rows_per_batch=g.rows_per_batch,
+                             out_f32=out_f32)
 
 
 class Upsample3D(E.EngineModule):
@@ -81,8 +82,10 @@ class Upsample3D(E.EngineModule):
 
     def run(self, x, g: E.Geom, output_size=None):
         conv = self.conv if self.name == "conv" else self.Conv2d_0
+        s32 = x.dtype == torch.float32           # fp32 residual stream (VAE decoder): x is also this conv's operand
+        x = ops.cast_f16(x)
         if output_size is None or tuple(output_size[-2:]) == (2 * g.h, 2 * g.w):
-            return conv.run(x, g, upsample=True), g.with_hw(2 * g.h, 2 * g.w)
+            return conv.run(x, g, upsample=True, out_f32=s32), g.with_hw(2 * g.h, 2 * g.w)
         # Forced size (reference resnet.py:147-150, used when H, W are not multiples of 2^num_upsamplers,
         # unet_video.py:443-445,541-542): F.interpolate(size=..., mode="nearest"), i.e. src = floor(dst * in / out)
         # in fp32.  Rare path (odd intermediate sizes): the resized rows are materialised by an index gather and
@@ -90,7 +93,7 @@ class Upsample3D(E.EngineModule):
         ho, wo = int(output_size[-2]), int(output_size[-1])
         idx = self._nearest_rows(g, ho, wo, x.device)
         g2 = g.with_hw(ho, wo)
-        return conv.run(x.index_select(0, idx), g2), g2
+        return conv.run(x.index_select(0, idx), g2, out_f32=s32), g2
 
     def _nearest_rows(self, g, ho, wo, device):
         key = (g.n_img, g.h, g.w, ho, wo, str(device))
@@ -160,20 +163,31 @@ class _ResnetBase(E.EngineModule):
         self.use_in_shortcut = in_channels != out_channels if use_in_shortcut is None else use_in_shortcut
         self.conv_shortcut = make_shortcut(in_channels, out_channels) if self.use_in_shortcut else None
 
-    def run(self, x, g: E.Geom, temb=None, x2=None, c_real=None):
-        """x (and optional channel-concatenated x2): rows of in_channels; temb: fp32 [B][temb_ch]."""
+    def run(self, x, g: E.Geom, temb=None, x2=None, c_real=None, stream_f32=None):
+        """x (and optional channel-concatenated x2): rows of in_channels; temb: fp32 [B][temb_ch].
+
+        Stream dtype: with fp32 rows in (or `stream_f32=True`) the block keeps its conv outputs, the residual sum and
+        the GroupNorm inputs in fp32 — only the MFMA operands (GroupNorm outputs) are fp16, i.e. ONE fp16 rounding per
+        conv instead of three (conv out, residual sum, norm out).  The VAE decoder runs this way by default because
+        the reference decodes in fp32 (pipeline_upscale_a_video.py:668-681); the UNet keeps fp16 rows like the
+        reference's `.half()` UNet."""
+        s32 = (x.dtype == torch.float32) if stream_f32 is None else bool(stream_f32)
         h = E.group_norm(self, "norm1", self.norm1, x, n_inst=g.b, rows_per_inst=g.rows_per_batch, silu=True, x2=x2,
                          c_real=c_real)
         rb = _temb_rows(self, temb) if (temb is not None and self.time_emb_proj is not None) else None
-        h = self.conv1.run(h, g, rowbias=rb)
+        h = self.conv1.run(h, g, rowbias=rb, out_f32=s32)
         h = E.group_norm(self, "norm2", self.norm2, h, n_inst=g.b, rows_per_inst=g.rows_per_batch, silu=True)
         if self.conv_shortcut is not None:
-            res = self.conv_shortcut.run(x, g, x2=x2) if x2 is not None else self.conv_shortcut.run(x, g)
+            xs = ops.cast_f16(x)                  # the shortcut conv reads the stream as an MFMA operand
+            res = self.conv_shortcut.run(xs, g, x2=ops.cast_f16(x2), out_f32=s32) if x2 is not None else \
+                self.conv_shortcut.run(xs, g, out_f32=s32)
         else:
             if x2 is not None:
                 raise ops._lib.UavError("concatenated input needs a shortcut conv")
+            if s32 and x.dtype != torch.float32:
+                raise ops._lib.UavError("fp32 stream requested for an fp16 identity shortcut")
             res = x
-        return self.conv2.run(h, g, residual=res, out_scale=1.0 / self.output_scale_factor)
+        return self.conv2.run(h, g, residual=res, out_scale=1.0 / self.output_scale_factor, out_f32=s32)
 
     def forward(self, input_tensor, temb=None):
         cin = self.in_channels
@@ -223,10 +237,11 @@ class ResnetBlock3D_plus(ResnetBlock3D):
         self.conv_3d = Conv3dK11(self.out_channels, self.out_channels, kernel_size=(3, 3, 3), stride=(1, 1, 1),
                                  padding=(1, 1, 1))
 
-    def run(self, x, g: E.Geom, temb=None, x2=None, c_real=None):
-        out = super().run(x, g, temb, x2=x2, c_real=c_real)
+    def run(self, x, g: E.Geom, temb=None, x2=None, c_real=None, stream_f32=None):
+        out = super().run(x, g, temb, x2=x2, c_real=c_real, stream_f32=stream_f32)
         h = E.group_norm(self, "norm_3d", self.norm_3d, out, n_inst=g.b, rows_per_inst=g.rows_per_batch, silu=True)
-        return self.conv_3d.run(h, g, residual=out, out_scale=1.0 / self.output_scale_factor)
+        return self.conv_3d.run(h, g, residual=out, out_scale=1.0 / self.output_scale_factor,
+                                out_f32=out.dtype == torch.float32)
 
 
 class Fuse_sft_block(E.EngineModule):
@@ -242,9 +257,9 @@ class Fuse_sft_block(E.EngineModule):
         self.shift = InflatedConv3d(dec_ch, dec_ch, 3, 1, 1)
 
     def run(self, enc, dec, g: E.Geom, w=1.0):
+        s32 = dec.dtype == torch.float32
         e = self.shared[0].run(enc, g, None, x2=dec)
-        e = self.shared[1].run(e, g, None)
-        scale = self.scale.run(e, g)
-        shift = self.shift.run(e, g)
-        # dec + w*(dec*scale + shift): elementwise, done with torch ops on the (small, low-res) tensors
-        return (dec.float() * (1.0 + w * scale.float()) + w * shift.float()).half()
+        e = ops.cast_f16(self.shared[1].run(e, g, None))
+        scale = self.scale.run(e, g, out_f32=s32)
+        shift = self.shift.run(e, g, out_f32=s32)
+        return ops.sft_fuse(dec, scale, shift, w, out_f32=s32)          # dec + w*(dec*scale + shift)

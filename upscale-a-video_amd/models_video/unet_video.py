@@ -194,6 +194,7 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
             emb = emb + ce                                                       # broadcast (1|B, D)
         return emb.contiguous()
 
+    @E.guarded
     def forward(self, sample, timestep, low_res, encoder_hidden_states=None, class_labels=20, attention_mask=None,
                 return_dict: bool = True, cfg_shared_input: bool = False):
         if attention_mask is not None:
@@ -202,7 +203,9 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
             raise ValueError(f"expected {self.config.in_channels} input channels, got {sample.shape[1]}+{low_res.shape[1]}")
         dev = sample.device
         if self.config.center_input_sample:
+            # the reference centres the CONCATENATED [sample, low_res] tensor (unet_video.py:440-454)
             sample = 2 * sample - 1.0
+            low_res = 2 * low_res - 1.0
         x, g = E.to_rows(sample, c_pad=8, x5b=low_res)                           # cat on C (4+3 -> 8 padded)
         bsz = sample.shape[0]
         emb = self._embedding(timestep, class_labels, bsz, dev)

@@ -122,13 +122,14 @@ class Decoder(E.EngineModule):
         self.conv_out = InflatedConv3d(block_out_channels[0], out_channels, 3, padding=1)
         self.gradient_checkpointing = False
 
-    def run(self, z, g, img=None, w_lr=1.0):
-        """z: latent rows [..][8] (after post_quant_conv); img: LR frame rows [..][8] (3 real channels)."""
-        x = self.conv_in.run(z, g)
+    def run(self, z, g, img=None, w_lr=1.0, stream_f32=False):
+        """z: latent rows [..][8] (after post_quant_conv); img: LR frame rows [..][8] (3 real channels).
+        stream_f32: conv outputs / residual stream / GroupNorm inputs in fp32 (see _ResnetBase.run)."""
+        x = self.conv_in.run(z, g, out_f32=stream_f32)
         if self.condition_img:
             if img is None:
                 raise AssertionError("input img condition when condition_img is True.")
-            c = self.condition_in[0].run(img, g, None, c_real=3)
+            c = self.condition_in[0].run(img, g, None, c_real=3, stream_f32=stream_f32)
             c = self.condition_in[1].run(c, g, None)
             x = self.condition_fuse.run(c, x, g, w=w_lr)
         x = self.mid_block.run(x, g)

@@ -36,6 +36,7 @@ class ConvParams(C.Structure):
 CONV_GEGLU = 1
 CONV_OUT_F32 = 2
 CONV_PERSISTENT = 64
+CONV_RES_F32 = 128
 CONV_RELU, CONV_SIGMOID, CONV_TANH = 4, 8, 16
 
 # name -> (restype, argtypes); the complete export list of include/uav_hip.h
@@ -44,8 +45,8 @@ SIGNATURES = {
     "uav_device_check": (C.c_int, [C.c_int, C.c_char_p]),
     "uav_conv_gemm_f16": (C.c_int, [C.POINTER(ConvParams), c_p]),
     "uav_groupnorm_workspace_bytes": (i64, [i32, i32]),
-    "uav_groupnorm_scale_shift": (C.c_int, [c_p, c_p, i32, i32, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
-    "uav_groupnorm_apply": (C.c_int, [c_p, c_p, i32, i32, i32, i64, c_p, c_p, i32, c_p, c_p]),
+    "uav_groupnorm_scale_shift": (C.c_int, [c_p, c_p, i32, i32, i32, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
+    "uav_groupnorm_apply": (C.c_int, [c_p, c_p, i32, i32, i32, i32, i64, c_p, c_p, i32, c_p, c_p]),
     "uav_layernorm_f16": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, f32, c_p]),
     "uav_attention_f16": (C.c_int, [c_p, i64, c_p, i64, c_p, i64, c_p, i64, i32, i32, i32, i32, i32, i32, f32, c_p, c_p]),
     "uav_temporal_attention_f16": (C.c_int, [c_p, c_p, i32, i32, i64, i32, i32, f32, c_p, c_p, i32, c_p, c_p]),
@@ -56,6 +57,8 @@ SIGNATURES = {
     "uav_cfg_ddim_v0": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, f32, f32, f32, i32, f32, c_p]),
     "uav_ddim_vt": (C.c_int, [c_p, c_p, c_p, c_p, i64, f32, f32, f32, f32, f32, i32, f32, c_p]),
     "uav_axpby_f16": (C.c_int, [c_p, c_p, c_p, i64, f32, f32, c_p]),
+    "uav_cast_f32_f16": (C.c_int, [c_p, c_p, i64, c_p]),
+    "uav_sft_fuse": (C.c_int, [c_p, c_p, c_p, c_p, i64, f32, i32, i32, c_p]),
     "uav_conv_gemm_f32": (C.c_int, [C.POINTER(ConvParams), c_p]),
     "uav_instnorm_f32": (C.c_int, [c_p, c_p, i32, i32, i32, f32, i32, c_p]),
     "uav_add_relu_f32": (C.c_int, [c_p, c_p, c_p, i64, i32, c_p]),

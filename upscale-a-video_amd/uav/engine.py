@@ -40,8 +40,17 @@ class Geom:
         return Geom(self.b, self.t, h, w)
 
 
+def _stamp(tensors):
+    """Identity of a parameter's CURRENT value: storage pointer + in-place version counter (bumped by copy_, mul_,
+    `random_init_`, optimiser steps ...); replaced / cast / moved parameters get a new pointer."""
+    return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
+
+
 class PackedCache:
-    """Per-model cache of packed weights, invalidated when parameters are replaced/cast/moved."""
+    """Per-model cache of packed weights.  Dropped wholesale on _apply / load_state_dict, and every entry carries the
+    stamp of the parameters it was built from, so in-place edits after the first forward (`p.data.copy_`,
+    `init_weights.random_init_`, load_state_dict on a plain nn.Linear child) rebuild it instead of silently serving
+    stale packed fp16 weights."""
 
     def __init__(self):
         self.store = {}
@@ -49,12 +58,13 @@ class PackedCache:
     def clear(self):
         self.store.clear()
 
-    def get(self, key, builder):
-        v = self.store.get(key)
-        if v is None:
-            v = builder()
-            self.store[key] = v
-        return v
+    def get(self, key, builder, src=()):
+        stamp = _stamp(src)
+        hit = self.store.get(key)
+        if hit is None or hit[0] != stamp:
+            hit = (stamp, builder())
+            self.store[key] = hit
+        return hit[1]
 
 
 class EngineModule(nn.Module):
@@ -85,6 +95,30 @@ class EngineModule(nn.Module):
         return r
 
 
+def device_guard(t):
+    """Context manager making `t`'s GPU the current device for the duration of a model call: launches go to torch's
+    current stream of the current device (ops._stream), so a model sitting on a non-current GPU (`pipe.to('cuda:1')`
+    without torch.cuda.set_device) would otherwise launch on device 0's stream against device-1 pointers."""
+    if isinstance(t, torch.Tensor) and t.is_cuda:
+        return torch.cuda.device(t.device)
+    import contextlib
+    return contextlib.nullcontext()
+
+
+def guarded(fn):
+    """Method decorator: run `fn` with the GPU of its first CUDA tensor argument as the current device."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrap(self, *a, **kw):
+        t = next((x for x in list(a) + list(kw.values()) if isinstance(x, torch.Tensor) and x.is_cuda), None)
+        if t is None or t.device.index == torch.cuda.current_device():
+            return fn(self, *a, **kw)
+        with torch.cuda.device(t.device):
+            return fn(self, *a, **kw)
+    return wrap
+
+
 def _dev(p):
     if not p.is_cuda:
         raise ops._lib.UavError("model parameters must be on the GPU before forward (call .to('cuda')); "
@@ -97,7 +131,7 @@ def packed_conv(mod: EngineModule, name, conv: nn.Module, geglu=False):
     def build():
         dev = _dev(conv.weight)
         return ops.pack_conv(conv.weight, conv.bias, geglu=geglu, device=dev)
-    return mod._cache().get(("conv", name), build)
+    return mod._cache().get(("conv", name), build, (conv.weight, conv.bias))
 
 
 def packed_cat(mod: EngineModule, name, linears):
@@ -109,21 +143,21 @@ def packed_cat(mod: EngineModule, name, linears):
         if linears[0].bias is not None:
             b = torch.cat([l.bias.detach() for l in linears], dim=0)
         return ops.pack_conv(w, b, device=dev)
-    return mod._cache().get(("cat", name), build)
+    return mod._cache().get(("cat", name), build, [l.weight for l in linears] + [l.bias for l in linears])
 
 
 def f32_param(mod: EngineModule, name, tensor):
     def build():
         _dev(tensor)
         return tensor.detach().float().contiguous()
-    return mod._cache().get(("f32", name), build)
+    return mod._cache().get(("f32", name), build, (tensor,))
 
 
 def f16_param(mod: EngineModule, name, tensor):
     def build():
         _dev(tensor)
         return tensor.detach().half().contiguous()
-    return mod._cache().get(("f16", name), build)
+    return mod._cache().get(("f16", name), build, (tensor,))
 
 
 def group_norm(mod: EngineModule, name, gn: nn.GroupNorm, x, *, n_inst, rows_per_inst, silu, x2=None, c_real=None):

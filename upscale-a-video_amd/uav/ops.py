@@ -6,6 +6,7 @@ the output buffers.  Activations are channels-last fp16 matrices [rows][C], rows
 (batch, frame, y, x).  There is no eager/CPU fallback.
 """
 import ctypes as C
+import functools
 import math
 from dataclasses import dataclass
 from typing import Optional
@@ -17,12 +18,27 @@ from . import _lib
 HALF = torch.float16
 
 
+_LAST_DEV = -1     # device index of the tensor most recently handed to _p() (benign race between threads: same device)
+
+
 def _stream():
+    """Stream every launch of this call is ordered on: torch's current stream of the CURRENT device.  The tensors whose
+    pointers were just taken (_p) must live on that device — kernels launched on device A's stream against device-B
+    pointers fault or run on the wrong GPU — so a mismatch raises instead (the model entry points switch the current
+    device to their tensors' device, engine.device_guard; library state such as the dynamic-LDS attribute is per device)."""
+    cur = torch.cuda.current_device()
+    if _LAST_DEV != cur:
+        raise _lib.UavError(f"tensors live on cuda:{_LAST_DEV} but the current device is cuda:{cur}: wrap the call in "
+                            f"`with torch.cuda.device({_LAST_DEV})` (the model / pipeline entry points do)")
     return torch.cuda.current_stream().cuda_stream
 
 
 def _p(t):
-    return None if t is None else t.data_ptr()
+    global _LAST_DEV
+    if t is None:
+        return None
+    _LAST_DEV = t.device.index
+    return t.data_ptr()
 
 
 def _req(t, dtype=None, name="tensor"):
@@ -201,7 +217,11 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
         _req(rowbias, torch.float32, "rowbias")
     p.residual = _p(residual); p.res_stride = 0 if residual is None else residual.shape[-1]
     if residual is not None:
-        _req(residual, HALF, "residual")
+        if residual.dtype == torch.float32:            # fp32 residual stream (VAE decoder)
+            _req(residual, torch.float32, "residual")
+            flags |= _lib.CONV_RES_F32
+        else:
+            _req(residual, HALF, "residual")
         if residual.numel() != m * residual.shape[-1]:
             raise _lib.UavError("residual rows != output rows")
     p.out = _p(out); p.out_stride = out.shape[-1]
@@ -220,8 +240,10 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
     return out
 
 
+@functools.lru_cache(maxsize=256)
 def _factor_rows(m):
-    """m = n_img * hi with hi < 65536 (the kernel packs pixel coordinates in 16 bits)."""
+    """m = n_img * hi with hi < 65536 (the kernel packs pixel coordinates in 16 bits).  Memoised: the divisor search is
+    a Python loop (~0.6 ms for the UNet's token counts) and the UNet issues ~160 linears per forward."""
     if m < 65536:
         return 1, m
     for hi in range(min(m, 65535), 0, -1):
@@ -238,11 +260,21 @@ def linear(x, wt: ConvW, *, residual=None, out_scale=1.0, rowbias=None, rows_per
 
 
 # ------------------------------------------------------------------------------------------------
+def _gn_dtype(x1, x2):
+    """GroupNorm inputs are fp16 rows, or fp32 rows (fp32 residual stream of the VAE decoder); both sources alike."""
+    if x1.dtype not in (HALF, torch.float32):
+        raise _lib.UavError(f"groupnorm input must be fp16 or fp32, got {x1.dtype}")
+    _req(x1, x1.dtype, "x1")
+    if x2 is not None:
+        _req(x2, x1.dtype, "x2")
+    return 1 if x1.dtype == torch.float32 else 0
+
+
 def groupnorm_scale_shift(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps, x2=None, c_real=None):
     lib = _lib.load()
-    _req(x1, HALF, "x1")
+    xf32 = _gn_dtype(x1, x2)
     c1 = x1.shape[-1]
-    c2 = 0 if x2 is None else _req(x2, HALF, "x2").shape[-1]
+    c2 = 0 if x2 is None else x2.shape[-1]
     c = c1 + c2
     if c_real is None:
         c_real = c
@@ -251,23 +283,24 @@ def groupnorm_scale_shift(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps
     ws_bytes = lib.uav_groupnorm_workspace_bytes(n_inst, c)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x1.device)
     ev = PROFILER.begin()
-    rc = lib.uav_groupnorm_scale_shift(_p(x1), _p(x2), c1, c2, c_real, n_inst, rows_per_inst, groups, eps,
+    rc = lib.uav_groupnorm_scale_shift(_p(x1), _p(x2), xf32, c1, c2, c_real, n_inst, rows_per_inst, groups, eps,
                                        _p(gamma), _p(beta), _p(scale), _p(shift), _p(ws), ws_bytes, _stream())
     _lib.check(rc, "uav_groupnorm_scale_shift")
-    PROFILER.end(ev, "groupnorm_stats", 0.0, 2.0 * n_inst * rows_per_inst * c)
+    PROFILER.end(ev, "groupnorm_stats", 0.0, (4.0 if xf32 else 2.0) * n_inst * rows_per_inst * c)
     return scale, shift
 
 
 def groupnorm_apply(x1, scale, shift, *, n_inst, rows_per_inst, silu, x2=None):
     lib = _lib.load()
+    xf32 = _gn_dtype(x1, x2)
     c1 = x1.shape[-1]
     c2 = 0 if x2 is None else x2.shape[-1]
     y = torch.empty((n_inst * rows_per_inst, c1 + c2), dtype=HALF, device=x1.device)
     ev = PROFILER.begin()
-    rc = lib.uav_groupnorm_apply(_p(x1), _p(x2), c1, c2, n_inst, rows_per_inst, _p(scale), _p(shift),
+    rc = lib.uav_groupnorm_apply(_p(x1), _p(x2), xf32, c1, c2, n_inst, rows_per_inst, _p(scale), _p(shift),
                                  1 if silu else 0, _p(y), _stream())
     _lib.check(rc, "uav_groupnorm_apply")
-    PROFILER.end(ev, "groupnorm_apply", 0.0, 4.0 * n_inst * rows_per_inst * (c1 + c2))
+    PROFILER.end(ev, "groupnorm_apply", 0.0, (6.0 if xf32 else 4.0) * n_inst * rows_per_inst * (c1 + c2))
     return y
 
 
@@ -398,6 +431,29 @@ def axpby(x, z, a, b):
     y = torch.empty_like(x)
     _lib.check(lib.uav_axpby_f16(_p(_req(x, HALF)), _p(_req(z, HALF)), _p(y), x.numel(), a, b, _stream()), "uav_axpby_f16")
     return y
+
+
+def cast_f16(x):
+    """fp32 rows -> fp16 rows (no-op for fp16 input)."""
+    if x.dtype == HALF:
+        return x
+    lib = _lib.load()
+    y = torch.empty(x.shape, dtype=HALF, device=x.device)
+    _lib.check(lib.uav_cast_f32_f16(_p(_req(x, torch.float32, "x")), _p(y), x.numel(), _stream()), "uav_cast_f32_f16")
+    return y
+
+
+def sft_fuse(dec, scale, shift, w, out_f32=False):
+    """dec + w*(dec*scale + shift) (Fuse_sft_block); inputs all fp16 or all fp32."""
+    lib = _lib.load()
+    _req(dec, None, "dec"); _req(scale, dec.dtype, "scale"); _req(shift, dec.dtype, "shift")
+    if dec.dtype not in (HALF, torch.float32):
+        raise _lib.UavError("sft_fuse: fp16 or fp32 rows expected")
+    out = torch.empty(dec.shape, dtype=torch.float32 if out_f32 else HALF, device=dec.device)
+    rc = lib.uav_sft_fuse(_p(dec), _p(scale), _p(shift), _p(out), dec.numel(), float(w), int(dec.dtype == torch.float32),
+                          int(out_f32), _stream())
+    _lib.check(rc, "uav_sft_fuse")
+    return out
 
 
 def propagate_step(feat_prev, feat_cur, flow_prop, flow_check, out, *, c, h, w, feat_chan_stride, flow_chan_stride,
