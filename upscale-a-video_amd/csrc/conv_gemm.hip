@@ -822,6 +822,227 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
     conv_epilogue<4, 2>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);     // ablation builds (DBG 1-5)
 }
 
+// ---------------------------------------------------------------------------------------------
+// 256x256x64 kernel, DMA INTERLEAVED with the MFMAs (round 2).  Same tile, LDS image, fragment reads, accumulator
+// layout and epilogue as conv_gemm256_kernel<0>; what changes is WHERE the 8 global_load_lds of the next stage are
+// issued.  The round-1 loop issued them back to back right after the barrier: VMEM issue is in order and the 8 waves of
+// the workgroup push 64 x 1 KiB through the CU's one texture-address path at once, so every wave sat in its DMA issue
+// block for ~1300 cycles per k-step while both waves of each SIMD had no MFMA in flight (ablation: 8.25 ms with, 5.82 ms
+// without the DMA block).  Here
+//   * the addresses of stage ks+1 are computed at the END of k-step ks-1, after the wave's last MFMA has issued: the
+//     VALU work runs beside the matrix pipe's drain (and the partner wave's MFMAs) instead of on the post-barrier
+//     critical path;
+//   * the W operand needs no per-lane address arithmetic at all: scalar row base (s_add on SGPRs) + a constant 32-bit
+//     lane offset (`global_load_lds_dwordx4 v, s[..]`);
+//   * the 8 DMA instructions sit INSIDE the hand-scheduled k-step, one every few MFMAs (pattern V), so the address
+//     path works while the matrix pipe does, and M0 (LDS destination) is written by s_add right before each.
+// Stage hand-over is unchanged (2 stages, vmcnt(0) + barrier per k-step), so the numerics and the tile walk are
+// bit-identical to the round-1 kernel (tests/test_fullsize_gpu.py compares them).
+template <int V>
+__global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi32 = lane >> 5, l32 = lane & 31;
+
+    const unsigned n_tiles = p.n_pad / LN;
+    const int slot_log = (tid & 7) ^ ((tid >> 4) & 7);
+    const int rbase = tid >> 3;                          // 0..63; rows r = pass*64 + rbase
+    const int hw_o = p.ho * p.wo;
+    const int ups = p.upsample ? 1 : 0;
+    const int ylim = p.upsample ? p.ho : p.hi, xlim = p.upsample ? p.wo : p.wi;
+
+    // tile id -> (m tile, n tile), frame-fastest for temporal taps (see conv_gemm256_kernel)
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    unsigned mt = tile / n_tiles;
+    const unsigned nt = tile - mt * n_tiles;
+    if (p.kt > 1 && p.tile_order) {
+        const unsigned hw_ = (unsigned)hw_o;
+        if (hw_ % LM == 0) {
+            const unsigned S_ = hw_ / LM, per_clip_ = S_ * (unsigned)p.t_len;
+            const unsigned c_ = mt / per_clip_, r_ = mt - c_ * per_clip_;
+            const unsigned sp_ = r_ / (unsigned)p.t_len, t_ = r_ - sp_ * (unsigned)p.t_len;
+            mt = c_ * per_clip_ + t_ * S_ + sp_;
+        }
+    }
+    const long long m0 = (long long)mt * LM;
+    const int n0 = nt * LN;
+    int rimg[4], rtl[4], rys[4], rxs[4];
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const long long m_ = m0 + ps * 64 + rbase;
+        const bool ok_ = m_ < p.M;
+        const int mm_ = ok_ ? (int)m_ : 0;
+        const int im_ = mm_ / hw_o; const int rem_ = mm_ - im_ * hw_o;
+        const int yo_ = rem_ / p.wo; const int xo_ = rem_ - yo_ * p.wo;
+        rimg[ps] = im_ - p.pad_t; rtl[ps] = im_ % p.t_len - p.pad_t;
+        rys[ps] = ok_ ? yo_ * p.stride - p.pad_h : -(1 << 28); rxs[ps] = xo_ * p.stride - p.pad_w;
+    }
+    const int cin = p.c1 + p.c2;
+    const int ntaps = p.kt * p.kh * p.kw;
+    const int nk = p.k_pad / BK;
+    // W operand: scalar base of piece ps at K offset kb = wtile + ps*wps + kb, per-lane constant byte offset woff
+    const char* wtile = p.w + (long long)n0 * p.k_pad * 2;
+    const long long wps = 64ll * p.k_pad * 2;
+    const unsigned woff = (unsigned)(((long long)rbase * p.k_pad + slot_log * 8) * 2);
+    int kdt = 0, kdy = 0, kdx = 0, ktap = 0, kc = 0;     // wave-uniform: tap / channel offset of the NEXT stage to address
+    const char* gx0; const char* gx1; const char* gx2; const char* gx3;
+    long long wkb;
+
+#define XADDR(PS, G)                                                                                         \
+    {                                                                                                        \
+        const int tt = rtl[PS] + kdt, yv = rys[PS] + kdy, xv = rxs[PS] + kdx;                                \
+        const bool ok = ((unsigned)tt < (unsigned)p.t_len) & ((unsigned)yv < (unsigned)ylim) &               \
+                        ((unsigned)xv < (unsigned)xlim);                                                     \
+        const int px = ((rimg[PS] + kdt) * p.hi + (yv >> ups)) * p.wi + (xv >> ups);                         \
+        const long long d = (xsrc - p.zero_page) + ((long long)px * xcs + xcoff) * 2;                        \
+        G = p.zero_page + (ok ? d : 0ll);                                                                    \
+    }
+#define COMPUTE_ADDR()                                                                                       \
+    {                                                                                                        \
+        const bool first = kc < p.c1;                                                                        \
+        const char* xsrc = first ? p.a1 : p.a2;                                                              \
+        const int xcs = first ? p.c1 : p.c2;                                                                 \
+        const int xcoff = (first ? kc : kc - p.c1) + slot_log * 8;                                           \
+        XADDR(0, gx0) XADDR(1, gx1) XADDR(2, gx2) XADDR(3, gx3)                                              \
+        wkb = ((long long)ktap * cin + kc) * 2;                                                              \
+        if (p.korder) {                          /* tap-innermost K order (see conv_gemm_kernel) */          \
+            ++ktap;                                                                                          \
+            if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } }                           \
+            if (ktap == ntaps) { ktap = 0; kdt = 0; kdy = 0; kdx = 0; kc += BK; }                            \
+        } else {                                                                                             \
+            kc += BK;                                                                                        \
+            if (kc >= cin) { kc = 0; ++ktap; if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } } } \
+        }                                                                                                    \
+    }
+
+    const int wn = wave & 1, wm = wave >> 1;
+    float16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int sw = (l32 >> 1) & 7;
+    const unsigned ldsb = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned bW = ldsb + (wn * 128 + l32) * 128, bX = ldsb + (wm * 64 + l32) * 128;
+    unsigned so[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) so[kk] = ((kk * 2 + hi32) ^ sw) << 4;
+    const unsigned ldsw = ldsb + wave * 1024;           // this wave's 1-KiB slice inside every 8-KiB piece
+
+    // LDS-DMA pieces of one stage: X rows ps*64.. -> +ps*8 KiB, W rows likewise behind the 32-KiB X tile.  M0 carries
+    // the wave-uniform LDS destination; it is compiler-reserved, so the block saves and restores it.
+#define DX(I, OFF) "s_cbranch_vccz .Lnd%=_" #I "\n" "s_add_u32 m0, %[ldsn], " #OFF "\n" "s_nop 0\n" "global_load_lds_dwordx4 %[gx" #I "], off\n" ".Lnd%=_" #I ":\n"
+#define DW(I, OFF) "s_cbranch_vccz .Lnw%=_" #I "\n" "s_add_u32 m0, %[ldsn], " #OFF "\n" "s_nop 0\n" "global_load_lds_dwordx4 %[woff], %[gw" #I "]\n" ".Lnw%=_" #I ":\n"
+#define D0 DX(0, 0)
+#define D1 DX(1, 8192)
+#define D2 DX(2, 16384)
+#define D3 DX(3, 24576)
+#define D4 DW(0, 32768)
+#define D5 DW(1, 40960)
+#define D6 DW(2, 49152)
+#define D7 DW(3, 57344)
+#define NO ""
+#define DMA_OPERANDS                                                                                         \
+    [gx0] "v"(gx0), [gx1] "v"(gx1), [gx2] "v"(gx2), [gx3] "v"(gx3), [woff] "v"(woff),                        \
+    [gw0] "s"(gw0), [gw1] "s"(gw1), [gw2] "s"(gw2), [gw3] "s"(gw3), [ldsn] "s"(ldsn), [dodma] "s"(dodma)
+
+    // ---- prologue: stage 0 -> buffer 0, addresses of stage 1 ---------------------------------
+    COMPUTE_ADDR()
+    {
+        const char* gw0 = wtile + wkb; const char* gw1 = gw0 + wps; const char* gw2 = gw1 + wps; const char* gw3 = gw2 + wps;
+        const unsigned ldsn = ldsw, dodma = __builtin_amdgcn_readfirstlane(1u);
+        unsigned m0s;
+        asm volatile("s_mov_b32 %[m0s], m0\n" "s_cmp_lg_u32 %[dodma], 0\n" "s_cselect_b64 vcc, -1, 0\n"
+                     D0 D1 D2 D3 D4 D5 D6 D7 "s_mov_b32 m0, %[m0s]\n"
+                     : [m0s] "=&s"(m0s) : DMA_OPERANDS : "memory", "scc", "vcc");
+    }
+    if (nk > 1) COMPUTE_ADDR()
+
+#define RD(D, A, OFF) "ds_read_b128 %[" #D "], %[" #A "] offset:" #OFF "\n"
+#define RDSET(S, A, AX) RD(w##S##0, A, 32768) RD(x##S##0, AX, 0) RD(x##S##1, AX, 4096) RD(w##S##1, A, 36864) RD(w##S##2, A, 40960) RD(w##S##3, A, 45056)
+#define MF(C, A, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #A "], %[" #B "], %[" #C "]\n"
+#define WT(N) "s_waitcnt lgkmcnt(" #N ")\n"
+    // one 8-MFMA slice with a DMA slot after each MFMA pair
+#define MFSETD(S, N0, N1, N2, N3, N4, SA, SB, SC, SD)                                          \
+    WT(N0) MF(c00, w##S##0, x##S##0) WT(N1) MF(c01, w##S##0, x##S##1) SA                       \
+    WT(N2) MF(c10, w##S##1, x##S##0) MF(c11, w##S##1, x##S##1) SB                              \
+    WT(N3) MF(c20, w##S##2, x##S##0) MF(c21, w##S##2, x##S##1) SC                              \
+    WT(N4) MF(c30, w##S##3, x##S##0) MF(c31, w##S##3, x##S##1) SD
+#define KSTEP(PRE, A0, A1, A2, A3, B0, B1, B2, B3, C0, C1, C2, C3, E0, E1, E2, E3)             \
+    "s_waitcnt lgkmcnt(0)\n" RDSET(0, aw0, ax0) RDSET(1, aw1, ax1) PRE                         \
+    MFSETD(0, 10, 9, 8, 7, 6, A0, A1, A2, A3) RDSET(0, aw2, ax2)                               \
+    MFSETD(1, 10, 9, 8, 7, 6, B0, B1, B2, B3) RDSET(1, aw3, ax3)                               \
+    MFSETD(0, 10, 9, 8, 7, 6, C0, C1, C2, C3) MFSETD(1, 4, 3, 2, 1, 0, E0, E1, E2, E3)
+#define ACC_OPERANDS                                                                                             \
+    [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]),                  \
+    [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]), [c30] "+v"(acc[3][0]), [c31] "+v"(acc[3][1]),                  \
+    [w00] "=&v"(w00), [w01] "=&v"(w01), [w02] "=&v"(w02), [w03] "=&v"(w03), [x00] "=&v"(x00), [x01] "=&v"(x01),  \
+    [w10] "=&v"(w10), [w11] "=&v"(w11), [w12] "=&v"(w12), [w13] "=&v"(w13), [x10] "=&v"(x10), [x11] "=&v"(x11)
+#define RD_OPERANDS                                                                                              \
+    [aw0] "v"(aw0), [aw1] "v"(aw1), [aw2] "v"(aw2), [aw3] "v"(aw3), [ax0] "v"(ax0), [ax1] "v"(ax1), [ax2] "v"(ax2), [ax3] "v"(ax3)
+
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const unsigned sb = cur * LSTAGE;
+        const unsigned aw0 = bW + sb + so[0], aw1 = bW + sb + so[1], aw2 = bW + sb + so[2], aw3 = bW + sb + so[3];
+        const unsigned ax0 = bX + sb + so[0], ax1 = bX + sb + so[1], ax2 = bX + sb + so[2], ax3 = bX + sb + so[3];
+        half8_t w00, w01, w02, w03, x00, x01, w10, w11, w12, w13, x10, x11;
+        // ONE asm statement for every k-step (two statements in an if/else made the register allocator shuffle the 128
+        // accumulators between them: 373 spilled VGPRs); the last k-step skips its DMA slots through VCC.
+        const char* gw0 = wtile + wkb; const char* gw1 = gw0 + wps; const char* gw2 = gw1 + wps; const char* gw3 = gw2 + wps;
+        const unsigned ldsn = ldsw + (cur ^ 1) * LSTAGE;
+        const unsigned dodma = __builtin_amdgcn_readfirstlane(ks + 1 < nk ? 1u : 0u);      // must reach the asm in an SGPR
+        unsigned m0s;
+#define KSTEP_STMT(...)                                                                                          \
+        asm volatile("s_mov_b32 %[m0s], m0\n" "s_cmp_lg_u32 %[dodma], 0\n" "s_cselect_b64 vcc, -1, 0\n"         \
+                     KSTEP(__VA_ARGS__) "s_mov_b32 m0, %[m0s]\n"                                                 \
+                     : ACC_OPERANDS, [m0s] "=&s"(m0s) : RD_OPERANDS, DMA_OPERANDS : "memory", "scc", "vcc");
+        if constexpr (V == 1) {            // front-loaded: 2 while the first fragments are in flight, then one per MFMA pair
+            KSTEP_STMT(D0 D1, D2, D3, D4, D5, D6, D7, NO, NO, NO, NO, NO, NO, NO, NO, NO, NO)
+        } else if constexpr (V == 2) {     // one DMA every 4 MFMAs over the first 28
+            KSTEP_STMT(D0, NO, D1, NO, D2, NO, D3, NO, D4, NO, D5, NO, D6, NO, D7, NO, NO)
+        } else {                           // V == 3: one per MFMA pair for the X gathers, then every 4 MFMAs for W
+            KSTEP_STMT(D0, D1, D2, D3, NO, D4, NO, D5, NO, D6, NO, D7, NO, NO, NO, NO, NO)
+        }
+#undef KSTEP_STMT
+        // addresses of stage ks+2: VALU beside the matrix pipe's drain, off the post-barrier critical path
+        if (ks + 2 < nk) COMPUTE_ADDR()
+        cur ^= 1;
+    }
+#undef RD
+#undef RDSET
+#undef MF
+#undef WT
+#undef MFSETD
+#undef KSTEP
+#undef ACC_OPERANDS
+#undef RD_OPERANDS
+#undef DMA_OPERANDS
+#undef DX
+#undef DW
+#undef D0
+#undef D1
+#undef D2
+#undef D3
+#undef D4
+#undef D5
+#undef D6
+#undef D7
+#undef NO
+#undef XADDR
+#undef COMPUTE_ADDR
+    // the MFMAs issued last may still be in flight and the compiler cannot see them (see conv_gemm256_kernel)
+    asm volatile("s_nop 15\ns_nop 15" ::: "memory");
+    conv_epilogue<4, 2>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);
+}
+
 
 }  // namespace
 
@@ -862,11 +1083,11 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     // the dynamic-LDS attribute of the 256x256 kernels and the CU count are PER DEVICE (std::call_once per device index),
     // so a second GPU, or a second host thread driving the library (bench --clips-per-step), never launches before the
     // attribute is in place.
-    struct ConvEnv { int korder, tile_order, force_tile, dbg, persist; };
+    struct ConvEnv { int korder, tile_order, force_tile, dbg, persist, dmav; };
     static const ConvEnv env = [] {
         auto geti = [](const char* k, int d) { const char* e = getenv(k); return e ? atoi(e) : d; };
         return ConvEnv{geti("UAV_CONV_KORDER", 1), geti("UAV_CONV_TILE_ORDER", 1), geti("UAV_CONV_TILE", 0),
-                       geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0)};
+                       geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0), geti("UAV_CONV_DMAV", 0)};
     }();
     a.korder = env.korder;
     a.tile_order = env.tile_order;
@@ -889,7 +1110,9 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
             const void* fns[] = {(const void*)conv_gemm256_kernel<0>, (const void*)conv_gemm256_kernel<1>,
                                  (const void*)conv_gemm256_kernel<2>, (const void*)conv_gemm256_kernel<3>,
                                  (const void*)conv_gemm256_kernel<4>, (const void*)conv_gemm256_kernel<5>,
-                                 (const void*)conv_gemm256_kernel<6>, (const void*)conv_gemm256_kernel<0, 1>};
+                                 (const void*)conv_gemm256_kernel<6>, (const void*)conv_gemm256_kernel<0, 1>,
+                                 (const void*)conv_gemm256i_kernel<1>, (const void*)conv_gemm256i_kernel<2>,
+                                 (const void*)conv_gemm256i_kernel<3>};
             for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
             hipDeviceProp_t prop;
             dev_ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
@@ -903,6 +1126,9 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         else if (dbg == 3) hipLaunchKernelGGL(conv_gemm256_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 5) hipLaunchKernelGGL(conv_gemm256_kernel<5>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 6) hipLaunchKernelGGL(conv_gemm256_kernel<6>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+        else if (env.dmav == 1) hipLaunchKernelGGL(conv_gemm256i_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+        else if (env.dmav == 2) hipLaunchKernelGGL(conv_gemm256i_kernel<2>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+        else if (env.dmav == 3) hipLaunchKernelGGL(conv_gemm256i_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if ((persist || (q->flags & UAV_CONV_PERSISTENT)) && grid256 > ncu) {
             // persistent form: one workgroup per CU walks tiles wg, wg + ncu, ... (UAV_CONV_PERSIST=0 disables)
             hipLaunchKernelGGL((conv_gemm256_kernel<0, 1>), dim3((unsigned)ncu), dim3(512), 2 * LSTAGE, s, a);
