@@ -1087,7 +1087,7 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     static const ConvEnv env = [] {
         auto geti = [](const char* k, int d) { const char* e = getenv(k); return e ? atoi(e) : d; };
         return ConvEnv{geti("UAV_CONV_KORDER", 1), geti("UAV_CONV_TILE_ORDER", 1), geti("UAV_CONV_TILE", 0),
-                       geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0), geti("UAV_CONV_DMAV", 0)};
+                       geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0), geti("UAV_CONV_DMAV", 1)};
     }();
     a.korder = env.korder;
     a.tile_order = env.tile_order;
