@@ -1,0 +1,221 @@
+"""The reference's OWN command-line program, `inference_upscale_a_video.py`, executed end to end against the drop-in
+package.  Runs in the build container only (needs /root/reference; skipped elsewhere).
+
+What runs unmodified from /root/reference: the whole `__main__` body (argument parsing, `from_pretrained` ->
+`from_config(json path)` -> `load_state_dict(strict=True)` -> `.half()` -> attribute assignment -> `pipeline.to`, the
+video pre-processing, the tile loop with its shared generator, the stitching, the post-processing and the save path),
+plus the reference's `utils.py` and `configs/CKPT_PTH.py`.  What the test supplies:
+  * `models_video` = upscale-a-video_amd/models_video (the product), its HIP entry points swapped for the torch stand-ins
+    of tests/cpu_ops.py (there is no GPU here);
+  * a synthetic `pretrained_models/upscale_a_video/` directory written into a temp cwd: tiny seeded UNet / VAE weights in
+    the reference's file layout, scheduler JSONs, a tiny CLIP text model + tokenizer saved with `save_pretrained`;
+  * empty stand-ins for third-party modules that are absent from the container (cv2, imageio, pyfiglet, torchvision,
+    llava) — `torchvision.io.read_video` hands out a synthetic clip and `imageio.mimwrite` captures what would be encoded;
+  * the two device strings of the CLI ('cuda:0' / 'cuda:1') rewritten to 'cpu' in the source text before `exec`.
+The captured video must equal what `uav.tiling.upscale_tiled` / a direct pipeline call produce with the same modules.
+"""
+import json
+import os
+import sys
+import types
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("UAV_REFERENCE_ROOT", "/root/reference")
+
+pytestmark = pytest.mark.skipif(not os.path.isfile(os.path.join(REF, "inference_upscale_a_video.py")),
+                                reason="needs the reference tree (build container only)")
+
+
+def _write_pretrained(root):
+    """pretrained_models/upscale_a_video/ in the layout the CLI reads (inference_upscale_a_video.py:101-125)."""
+    import golden_cases as GC
+    import synth
+    from tokenizers import pre_tokenizers
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTokenizer
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from models_video.unet_video import UNetVideoModel
+    base = os.path.join(root, "pretrained_models", "upscale_a_video")
+    for sub in ("vae", "unet", "scheduler", "low_res_scheduler", "propagator"):
+        os.makedirs(os.path.join(base, sub), exist_ok=True)
+    # tokenizer: character-level CLIP BPE (no merges); text encoder: 2-layer CLIP, hidden = the UNet's cross_attention_dim
+    alpha = sorted(pre_tokenizers.ByteLevel.alphabet())
+    vocab = {"<|startoftext|>": 0, "<|endoftext|>": 1}
+    for ch in alpha:
+        vocab[ch] = len(vocab)
+    for ch in alpha:
+        vocab[ch + "</w>"] = len(vocab)
+    CLIPTokenizer(vocab=vocab, merges=[], model_max_length=77).save_pretrained(os.path.join(base, "tokenizer"))
+    torch.manual_seed(0)
+    cfg = CLIPTextConfig(vocab_size=len(vocab), hidden_size=GC.UNET_TINY["cross_attention_dim"], intermediate_size=128,
+                         num_hidden_layers=2, num_attention_heads=2, max_position_embeddings=77, eos_token_id=1, bos_token_id=0,
+                         pad_token_id=1)
+    CLIPTextModel(cfg).save_pretrained(os.path.join(base, "text_encoder"))
+    json.dump({"_class_name": "VideoUpscalePipeline"}, open(os.path.join(base, "model_index.json"), "w"))
+    json.dump(dict(GC.SCHED, _class_name="DDIMScheduler"), open(os.path.join(base, "scheduler", "scheduler_config.json"), "w"))
+    json.dump(dict(_class_name="DDPMScheduler", num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02,
+                   beta_schedule="scaled_linear"), open(os.path.join(base, "low_res_scheduler", "scheduler_config.json"), "w"))
+    for fname, cfgd, wname in (("vae_3d_config.json", GC.VAE3D_TINY, "vae_3d.bin"), ("vae_video_config.json", GC.VAEVIDEO_TINY, "vae_video.bin")):
+        json.dump(dict(cfgd, _class_name="AutoencoderKLVideo", _diffusers_version="0.9.0.dev0"), open(os.path.join(base, "vae", fname), "w"))
+        vae = AutoencoderKLVideo.from_config(dict(cfgd))
+        torch.save(synth.synth_state_dict(vae.state_dict(), seed=4321), os.path.join(base, "vae", wname))
+    json.dump(dict(GC.UNET_TINY, _class_name="UNetVideoModel", _diffusers_version="0.9.0.dev0"),
+              open(os.path.join(base, "unet", "unet_video_config.json"), "w"))
+    unet = UNetVideoModel.from_config(dict(GC.UNET_TINY))
+    torch.save(synth.synth_state_dict(unet.state_dict(), seed=1234), os.path.join(base, "unet", "unet_video.bin"))
+    return base
+
+
+class _Capture:
+    def __init__(self):
+        self.videos = []
+
+
+def _stub_modules(clip_u8, cap):
+    """Third-party modules the CLI imports and this container lacks.  Returns the names put into sys.modules."""
+    names = []
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        names.append(name)
+        return m
+    mod("cv2")
+    mod("pyfiglet", figlet_format=lambda text, font=None: text)
+    mod("imageio", mimwrite=lambda path, frames, fps=None, quality=None, output_params=None: cap.videos.append((path, frames, fps)))
+    tv = mod("torchvision")
+    tv.utils = mod("torchvision.utils", flow_to_image=lambda f: f, save_image=lambda *a, **k: None)
+    tv.io = mod("torchvision.io", read_video=lambda filename, pts_unit=None, output_format=None: (clip_u8.clone(), None, {"video_fps": 8}))
+    ll = mod("llava")
+    ll.llava_agent = mod("llava.llava_agent", LLavaAgent=object)
+    return names
+
+
+def _run_cli(tmp_path, monkeypatch, argv, clip_u8):
+    """exec the reference CLI's source (device strings -> 'cpu') with cwd = tmp_path; returns the captured videos."""
+    import cpu_ops
+    src = open(os.path.join(REF, "inference_upscale_a_video.py")).read()
+    assert src.count("'cuda:0'") == 3 and src.count("'cuda:1'") == 1
+    src = src.replace("'cuda:0'", "'cpu'").replace("'cuda:1'", "'cpu'")
+    cap = _Capture()
+    saved_mods = {k: sys.modules.get(k) for k in ("cv2", "pyfiglet", "imageio", "torchvision", "torchvision.utils", "torchvision.io",
+                                                  "llava", "llava.llava_agent", "utils", "configs", "configs.CKPT_PTH")}
+    saved_path = list(sys.path)
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(sys, "argv", ["inference_upscale_a_video.py"] + argv)
+    # the product's models_video first, then the reference root for `utils` and `configs.CKPT_PTH`
+    sys.path[:0] = [os.path.join(ROOT, "upscale-a-video_amd"), REF]
+    import transformers  # noqa: F401  (must be imported before the bare torchvision stand-in exists)
+    from transformers import CLIPTextModel, CLIPTokenizer  # noqa: F401
+    _stub_modules(clip_u8, cap)
+    for k in ("utils", "configs", "configs.CKPT_PTH"):
+        sys.modules.pop(k, None)
+    cpu_ops.install()
+    try:
+        env = {"__name__": "__main__", "__file__": os.path.join(REF, "inference_upscale_a_video.py")}
+        exec(compile(src, env["__file__"], "exec"), env)
+    finally:
+        cpu_ops.restore()
+        sys.path[:] = saved_path
+        for k, v in saved_mods.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    import models_video.unet_video as uv
+    assert uv.__file__.startswith(os.path.join(ROOT, "upscale-a-video_amd")), "the CLI must have imported the drop-in package"
+    return cap.videos, env
+
+
+def _clip_u8(t, h, w, seed):
+    import synth
+    x = synth.synth_clip(1, t, h, w, seed=seed)[0].permute(1, 0, 2, 3)                      # (T,C,H,W) in [-1,1]
+    return ((x / 2 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8)
+
+
+def _to_u8(images):
+    """The CLI's own post-processing (inference_upscale_a_video.py:355-357)."""
+    out = images[0].permute(1, 0, 2, 3).cpu()                                             # t c h w
+    return ((out / 2 + 0.5).clamp(0, 1) * 255).permute(0, 2, 3, 1).contiguous().numpy().astype("uint8")
+
+
+def _load_like_cli(base, use_video_vae):
+    import cpu_ops  # noqa: F401
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
+    from models_video.scheduling_ddim import DDIMScheduler
+    from models_video.unet_video import UNetVideoModel
+    pipe = VideoUpscalePipeline.from_pretrained(base, torch_dtype=torch.float16)
+    name = "vae_video" if use_video_vae else "vae_3d"
+    pipe.vae = AutoencoderKLVideo.from_config(os.path.join(base, "vae", name + "_config.json"))
+    pipe.vae.load_state_dict(torch.load(os.path.join(base, "vae", name + ".bin"), map_location="cpu"))
+    pipe.unet = UNetVideoModel.from_config(os.path.join(base, "unet", "unet_video_config.json"))
+    pipe.unet.load_state_dict(torch.load(os.path.join(base, "unet", "unet_video.bin"), map_location="cpu"), strict=True)
+    pipe.unet = pipe.unet.half().eval()
+    pipe.scheduler = DDIMScheduler.from_config(os.path.join(base, "scheduler", "scheduler_config.json"))
+    pipe.propagator = None
+    return pipe.to("cpu")
+
+
+def test_reference_cli_tile_branch_runs_on_the_dropin(tmp_path, monkeypatch):
+    """`--no_llava --perform_tile --tile_size 64` on a 2-frame 68x160 clip (two tiles sharing one generator, H not a
+    multiple of 8): the video the CLI would encode equals uav.tiling.upscale_tiled on the same modules, bit for bit."""
+    import cpu_ops
+    sys.path.insert(0, os.path.join(ROOT, "upscale-a-video_amd"))
+    base = _write_pretrained(str(tmp_path))
+    clip = _clip_u8(2, 68, 160, seed=33)
+    videos, env = _run_cli(tmp_path, monkeypatch, ["-i", "inputs/clip.mp4", "-o", "results", "--no_llava", "--perform_tile",
+                                                   "--tile_size", "64", "-s", "2", "--a_prompt", "p", "--n_prompt", "n"], clip)
+    assert len(videos) == 1
+    path, frames, fps = videos[0]
+    assert path.endswith("results/video/clip_n120_g6_s2.mp4") and fps == 8
+    assert frames.shape == (2, 4 * 68, 4 * 160, 3) and frames.dtype.name == "uint8"
+    assert env["args"].perform_tile and env["pipeline"].unet.dtype == torch.float16
+    assert type(env["pipeline"]).__module__ == "models_video.pipeline_upscale_a_video"
+    # the same job through the product's own tile scheduler
+    from uav import tiling
+    cpu_ops.install()
+    try:
+        monkeypatch.chdir(tmp_path)
+        pipe = _load_like_cli(base, use_video_vae=False)
+        vfr = ((clip / 255. - 0.5) * 2).unsqueeze(0).permute(0, 2, 1, 3, 4).contiguous()
+        out = tiling.upscale_tiled(pipe, "p", vfr, None, torch.Generator(device="cpu").manual_seed(10), tile_size=64,
+                                   num_inference_steps=2, guidance_scale=6, noise_level=120, negative_prompt="n", propagation_steps=[])
+    finally:
+        cpu_ops.restore()
+    mine = _to_u8(out)
+    assert mine.shape == frames.shape
+    assert (mine != frames).mean() == 0.0, f"{(mine != frames).mean()} of the bytes differ"
+    assert frames.std() > 5                         # not a constant image
+
+
+def test_reference_cli_video_vae_no_tile_runs_on_the_dropin(tmp_path, monkeypatch):
+    """`--use_video_vae --no_llava` on a 3-frame 16x24 clip (no tiling, SFT-conditioned video VAE), 1 DDIM step."""
+    import cpu_ops
+    sys.path.insert(0, os.path.join(ROOT, "upscale-a-video_amd"))
+    base = _write_pretrained(str(tmp_path))
+    clip = _clip_u8(3, 16, 24, seed=34)
+    videos, env = _run_cli(tmp_path, monkeypatch, ["-i", "inputs/clip.mp4", "-o", "results", "--no_llava", "--use_video_vae",
+                                                   "-s", "1", "-g", "6", "-n", "100", "--save_suffix", "x"], clip)
+    path, frames, fps = videos[0]
+    assert path.endswith("results/video/clip_n100_g6_s1_x.mp4")
+    assert frames.shape == (3, 64, 96, 3)
+    assert not env["args"].perform_tile and env["pipeline"].vae.decoder.condition_img
+    cpu_ops.install()
+    try:
+        monkeypatch.chdir(tmp_path)
+        pipe = _load_like_cli(base, use_video_vae=True)
+        vfr = ((clip / 255. - 0.5) * 2).unsqueeze(0).permute(0, 2, 1, 3, 4).contiguous()
+        out = pipe("best quality, extremely detailed", image=vfr, flows_bi=None, generator=torch.Generator(device="cpu").manual_seed(10),
+                   num_inference_steps=1, guidance_scale=6, noise_level=100, negative_prompt="blur, worst quality",
+                   propagation_steps=[]).images
+    finally:
+        cpu_ops.restore()
+    assert (_to_u8(out) != frames).mean() == 0.0
