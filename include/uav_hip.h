@@ -188,6 +188,26 @@ int uav_cast_f32_f16(const float* x, void* y, int64_t n, void* stream);
 int uav_sft_fuse(const void* dec, const void* scale, const void* shift, void* out, int64_t n, float w,
                  int32_t in_f32, int32_t out_f32, void* stream);
 
+/* ---- K12: colour correction of the decoded frames (CLI --color_fix AdaIn | Wavelet) --------------------
+ * fp32 planes: a (T,C,H,W) tensor is `planes` = T*C images of h*w.  Replaces (reference
+ * models_video/color_correction.py and inference_upscale_a_video.py:322-333):
+ *   F.interpolate(scale_factor=4, mode='bicubic')                 uav_resize_bicubic_f32 (ATen cubic convolution, A = -0.75,
+ *                                                                 src = scale*(dst+0.5)-0.5, clamped taps; scale = in/out or 1/scale_factor)
+ *   calc_mean_std (:43-57): per-plane mean and UNBIASED variance  uav_plane_stats_f32 (deterministic two-stage, fp64 combine)
+ *   adaptive_instance_normalization (:59-71)                      uav_adain_apply_f32: (x-cm)/sqrt(cv+eps)*sqrt(sv+eps)+sm
+ *   wavelet_blur (:73-91) + decomposition step (:101-104)         uav_atrous_blur_f32: 3x3 [1 2 1]x[1 2 1]/16, dilation `radius`,
+ *                                                                 replicate padding; high_inout (optional) += src - low
+ */
+int64_t uav_plane_stats_workspace_bytes(int32_t planes);
+int uav_plane_stats_f32(const float* x, int32_t planes, int64_t hw, float* mean_out, float* var_out,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+int uav_adain_apply_f32(const float* x, float* out, int32_t planes, int64_t hw, const float* c_mean, const float* c_var,
+                        const float* s_mean, const float* s_var, float eps, void* stream);
+int uav_atrous_blur_f32(const float* src, float* low_out, float* high_inout, int32_t planes, int32_t h, int32_t w,
+                        int32_t radius, void* stream);
+int uav_resize_bicubic_f32(const float* src, float* dst, int32_t planes, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                           float scale_h, float scale_w, void* stream);
+
 /* ---- K10: flow-guided propagation step -----------------------------------------------
  * Replaces one recurrence step of Propagation.forward (propagation_module.py:234-254) with
  * fbConsistencyCheck (:140-149) and flow_warp (:104-135): planar fp16 features, one frame of a

@@ -120,6 +120,16 @@ def pipeline_inputs(case, seed=400):
     return image, flows
 
 
+def colorfix_inputs(seed=500):
+    """Decoded frames (content) and the bicubic-upsampled LR frames (style) of the CLI's colour fix: (T,3,H,W) fp32."""
+    g = _g(seed)
+    t, h, w = 2, 24, 20
+    lr = synth.synth_clip(1, t, h, w, seed=seed)[0].permute(1, 0, 2, 3).contiguous()          # (T,3,h,w) in [-1,1]
+    content = torch.nn.functional.interpolate(lr, scale_factor=4, mode="nearest") * 0.8 + 0.15 + \
+        0.2 * torch.randn(t, 3, 4 * h, 4 * w, generator=g)
+    return lr, content.clamp(-1, 1).contiguous()
+
+
 # FULL-WIDTH cases (released architecture), generated by `make_golden.py --full` from the reference's own modules
 FULL_CASES = {
     "unet_full_t8_64": (2, 8, 64, 64),

@@ -24,6 +24,7 @@ sys.path.insert(0, HERE)
 import ref_stubs  # noqa: E402
 import synth  # noqa: E402
 import uav_oracle as O  # noqa: E402
+from golden_cases import colorfix_inputs  # noqa: E402
 from golden_cases import (UNET_TINY, VAE3D_TINY, VAEVIDEO_TINY, SCHED, unet_inputs, vae_inputs, prop_inputs,  # noqa: E402
                           pipeline_inputs, PIPE_CASES, PROP_HALF_CASES, prop_half_inputs, FULL_CASES)
 
@@ -173,6 +174,7 @@ def main():
     make_vae_wlr_golden(ns, pin)
     make_prop_half_goldens(ns, pin)
     make_pipe_half_golden(ns, pin)
+    make_colorfix_golden(ns, pin)
     make_fullwidth_goldens(ns, pin)
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
     print("wrote", GOLD)
@@ -541,15 +543,30 @@ def make_pipe_half_golden(ns, pin):
     print("pipe_t10_vaevideo_prop_refhalf", pin["cases"]["pipe_t10_vaevideo_prop_refhalf"], flush=True)
 
 
+def make_colorfix_golden(ns, pin):
+    """The CLI's colour fix (inference_upscale_a_video.py:322-333) with the reference's own functions: bicubic 4x of the LR
+    frames, then AdaIN and the 5-level wavelet reconstruction of the decoded frames."""
+    lr, content = colorfix_inputs()
+    style = torch.nn.functional.interpolate(lr, scale_factor=4, mode="bicubic")
+    adain = ns.color.adaptive_instance_normalization(content, style)
+    wave = ns.color.wavelet_reconstruction(content, style)
+    high, low = ns.color.wavelet_decomposition(content)
+    pin["cases"]["colorfix"] = {"adain_absmean": adain.abs().mean().item(), "wavelet_absmean": wave.abs().mean().item(),
+                                "telescoped_high_maxabs_dev": (high - (content - low)).abs().max().item()}
+    torch.save({"style_bicubic4": style.clone(), "adain": adain.clone(), "wavelet": wave.clone(), "high": high.clone(), "low": low.clone()},
+               os.path.join(GOLD, "colorfix.pt"))
+    print("colorfix", pin["cases"]["colorfix"], flush=True)
+
+
 def only(section):
     """`python oracle/make_golden.py --raft | --unet`: regenerate one section's fixtures and PINNING.json entries."""
     torch.set_num_threads(8)
     ns = ref_stubs.import_reference()
     pin = json.load(open(os.path.join(GOLD, "PINNING.json")))
     {"raft": make_raft_goldens, "unet": make_unet_goldens, "tiles": make_tile_goldens, "pipe14": make_dup_tail_golden,
-     "vaewlr": make_vae_wlr_golden, "prophalf": make_prop_half_goldens, "pipehalf": make_pipe_half_golden, "full": make_fullwidth_goldens}[section](ns, pin)
+     "vaewlr": make_vae_wlr_golden, "prophalf": make_prop_half_goldens, "pipehalf": make_pipe_half_golden, "colorfix": make_colorfix_golden, "full": make_fullwidth_goldens}[section](ns, pin)
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
-    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else only("tiles") if "--tiles" in sys.argv else only("pipe14") if "--pipe14" in sys.argv else only("vaewlr") if "--vaewlr" in sys.argv else only("pipehalf") if "--pipehalf" in sys.argv else only("prophalf") if "--prophalf" in sys.argv else only("full") if "--full" in sys.argv else main()
+    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else only("tiles") if "--tiles" in sys.argv else only("pipe14") if "--pipe14" in sys.argv else only("vaewlr") if "--vaewlr" in sys.argv else only("colorfix") if "--colorfix" in sys.argv else only("pipehalf") if "--pipehalf" in sys.argv else only("prophalf") if "--prophalf" in sys.argv else only("full") if "--full" in sys.argv else main()

@@ -344,4 +344,7 @@ def import_reference():
     pkg.UNetVideoModel = ns.unet_video.UNetVideoModel
     pkg.Propagation = ns.propagation.Propagation
     ns.pipeline = importlib.import_module("models_video.pipeline_upscale_a_video")
+    if "torchvision.transforms" not in sys.modules:        # color_correction.py imports two names it never uses
+        _mod("torchvision.transforms", ToTensor=None, ToPILImage=None)
+    ns.color = importlib.import_module("models_video.color_correction")
     return ns

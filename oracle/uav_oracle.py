@@ -672,3 +672,40 @@ def raft_bi_forward(sd, frames, iters=20):
     ff = ff.reshape(b, t - 1, 2, h, w).permute(0, 2, 1, 3, 4)
     fb = fb.reshape(b, t - 1, 2, h, w).permute(0, 2, 1, 3, 4)
     return ff.contiguous(), fb.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------
+# colour correction (models_video/color_correction.py), fp32
+def adain(content, style, eps=1e-5):
+    """adaptive_instance_normalization (:59-71) with calc_mean_std (:43-57: UNBIASED variance + eps)."""
+    def ms(f):
+        b, c = f.shape[:2]
+        flat = f.reshape(b, c, -1)
+        return flat.mean(dim=2).reshape(b, c, 1, 1), (flat.var(dim=2) + eps).sqrt().reshape(b, c, 1, 1)
+    sm, ss = ms(style)
+    cm, cs = ms(content)
+    return (content - cm) / cs * ss + sm
+
+
+def atrous_blur(image, radius):
+    """wavelet_blur (:73-91): [1 2 1]x[1 2 1]/16 with dilation `radius` on a replicate-padded image."""
+    k1 = torch.tensor([0.25, 0.5, 0.25], dtype=image.dtype)
+    k = (k1[:, None] * k1[None, :])[None, None].repeat(image.shape[1], 1, 1, 1)
+    return F.conv2d(F.pad(image, (radius,) * 4, mode="replicate"), k, groups=image.shape[1], dilation=radius)
+
+
+def wavelet_decomposition(image, levels=5):
+    high = torch.zeros_like(image)                                              # :93-106
+    for i in range(levels):
+        low = atrous_blur(image, 2 ** i)
+        high = high + (image - low)
+        image = low
+    return high, image
+
+
+def wavelet_reconstruction(content, style):
+    return wavelet_decomposition(content)[0] + wavelet_decomposition(style)[1]  # :108-118
+
+
+def bicubic4(frames):
+    return F.interpolate(frames, scale_factor=4, mode="bicubic")                 # inference_upscale_a_video.py:327

@@ -108,6 +108,18 @@ def test_oracle_propagation_vs_golden():
         assert (out - gold).abs().max().item() < 2e-3
 
 
+def test_oracle_colorfix_vs_golden():
+    """Oracle restatement of the colour fix against the reference's own outputs (tests/golden/colorfix.pt)."""
+    lr, content = GC.colorfix_inputs()
+    gold = torch.load(os.path.join(GOLD, "colorfix.pt"))
+    style = O.bicubic4(lr)
+    assert (style - gold["style_bicubic4"]).abs().max().item() < 1e-6
+    assert (O.adain(content, style) - gold["adain"]).abs().max().item() < 1e-5
+    assert (O.wavelet_reconstruction(content, style) - gold["wavelet"]).abs().max().item() < 1e-5
+    high, low = O.wavelet_decomposition(content)
+    assert (high - gold["high"]).abs().max().item() < 1e-5 and (low - gold["low"]).abs().max().item() < 1e-5
+
+
 def test_oracle_ddim_vs_golden():
     rec = json.load(open(os.path.join(GOLD, "ddim.json")))
     sch = O.DDIM(**GC.SCHED)

@@ -14,10 +14,11 @@
 // groups may straddle the seam (1536 channels / 32 groups = 48), which per-channel partials
 // handle for free.  Deterministic: no atomics.
 #include "uav_common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int GN_MAX_CHUNKS = 512;
+constexpr int GN_MAX_CHUNKS = 2048;
 
 struct GnSrc {
     const char* x1; const char* x2; int c1, c2;
@@ -42,7 +43,7 @@ UAV_DEVINL void gn_load8(const GnSrc& s, long long row, int v, float (&f)[8]) {
     }
 }
 
-template <bool F32>
+template <bool F32, int U>
 __global__ __launch_bounds__(256) void gn_partial_kernel(GnSrc s, long long rows_per_inst, int chunks,
                                                          float* __restrict__ ws) {
     __shared__ float red[256 * 16];
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnSrc s, long long rows
 #pragma unroll
     for (int j = 0; j < 8; ++j) { sm[j] = 0.f; sq[j] = 0.f; }
     if (active) {
-        constexpr int U = 8;                                // independent 16-B loads in flight per thread
+        // U independent 16-B loads in flight per thread
         for (long long r = r0 + ro; r < r1; r += (long long)rpp * U) {
             float x[U][8];
 #pragma unroll
@@ -210,12 +211,20 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const char* __restrict__
     }
 }
 
+int gn_variant() {
+    static const int v = [] { const char* e = getenv("UAV_GN_VAR"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
 int gn_chunks(int n_inst, long long rows_per_inst, int c) {
     const int rpp = 256 / (c >> 3);
-    long long by_rows = (rows_per_inst + (long long)rpp * 32 - 1) / ((long long)rpp * 32);  // >= 4 unrolled passes per block
-    long long want = 4096 / (n_inst > 0 ? n_inst : 1); if (want < 1) want = 1;
+    const int var = gn_variant();
+    const int passes = var == 0 ? 32 : var == 1 ? 16 : 8;
+    long long by_rows = (rows_per_inst + (long long)rpp * passes - 1) / ((long long)rpp * passes);
+    long long want = (var == 0 ? 4096 : var == 1 ? 8192 : 16384) / (n_inst > 0 ? n_inst : 1); if (want < 1) want = 1;
     long long ch = by_rows < want ? by_rows : want;
-    if (ch > GN_MAX_CHUNKS) ch = GN_MAX_CHUNKS;
+    const int cap = var == 0 ? 512 : GN_MAX_CHUNKS;
+    if (ch > cap) ch = cap;
     if (ch < 1) ch = 1;
     return (int)ch;
 }
@@ -223,7 +232,7 @@ int gn_chunks(int n_inst, long long rows_per_inst, int c) {
 }  // namespace
 
 extern "C" int64_t uav_groupnorm_workspace_bytes(int32_t n_inst, int32_t c) {
-    return (int64_t)n_inst * GN_MAX_CHUNKS * c * 2 * 4;
+    return (int64_t)n_inst * (gn_variant() == 0 ? 512 : GN_MAX_CHUNKS) * c * 2 * 4;
 }
 
 extern "C" int uav_groupnorm_scale_shift(const void* x1, const void* x2, int32_t x_f32, int32_t c1, int32_t c2, int32_t c_real,
@@ -239,12 +248,14 @@ extern "C" int uav_groupnorm_scale_shift(const void* x1, const void* x2, int32_t
     if (workspace_bytes < (int64_t)n_inst * chunks * c * 2 * 4) return UAV_EINVAL;
     GnSrc s{(const char*)x1, (const char*)x2, c1, c2};
     hipStream_t st = (hipStream_t)stream;
-    if (x_f32)
-        hipLaunchKernelGGL(gn_partial_kernel<true>, dim3(chunks, n_inst), dim3(256), 0, st, s, (long long)rows_per_inst, chunks,
-                           (float*)workspace);
-    else
-        hipLaunchKernelGGL(gn_partial_kernel<false>, dim3(chunks, n_inst), dim3(256), 0, st, s, (long long)rows_per_inst, chunks,
-                           (float*)workspace);
+    const int var = gn_variant();
+#define GN_PARTIAL(F, UU) hipLaunchKernelGGL((gn_partial_kernel<F, UU>), dim3(chunks, n_inst), dim3(256), 0, st, s, \
+                                             (long long)rows_per_inst, chunks, (float*)workspace)
+    if (x_f32) { if (var == 0) GN_PARTIAL(true, 8); else GN_PARTIAL(true, 4); }
+    else if (var == 0) GN_PARTIAL(false, 8);
+    else if (var == 3) GN_PARTIAL(false, 8);
+    else GN_PARTIAL(false, 4);
+#undef GN_PARTIAL
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n_inst), dim3(256), 0, st, (const float*)workspace, chunks, c, c_real,
                        groups, (long long)rows_per_inst, eps, gamma, beta, scale_out, shift_out);
     return uav_launch_status();

@@ -622,3 +622,56 @@ def convex_upsample_f32(flow_rows, mask_rows, n, h, w):
     rc = lib.uav_convex_upsample_f32(_p(flow_rows), flow_rows.stride(0), _p(mask_rows), _p(out), n, h, w, _stream())
     _lib.check(rc, "uav_convex_upsample_f32")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# colour correction (K12): fp32 planes (T*C, H, W)
+def _planes(x):
+    x = _req(x.contiguous(), F32, "x")
+    if x.dim() < 2:
+        raise _lib.UavError("expected (..., H, W)")
+    h, w = x.shape[-2:]
+    return x, x.numel() // (h * w), h, w
+
+
+def plane_stats_f32(x):
+    """Per-plane mean and unbiased variance of (..., H, W) fp32 -> two fp32 vectors [planes]."""
+    lib = _lib.load()
+    x, planes, h, w = _planes(x)
+    mean = torch.empty(planes, dtype=F32, device=x.device); var = torch.empty_like(mean)
+    nb = lib.uav_plane_stats_workspace_bytes(planes)
+    ws = torch.empty(nb, dtype=torch.uint8, device=x.device)
+    _lib.check(lib.uav_plane_stats_f32(_p(x), planes, h * w, _p(mean), _p(var), _p(ws), nb, _stream()), "uav_plane_stats_f32")
+    return mean, var
+
+
+def adain_apply_f32(x, c_mean, c_var, s_mean, s_var, eps=1e-5):
+    lib = _lib.load()
+    x, planes, h, w = _planes(x)
+    out = torch.empty_like(x)
+    rc = lib.uav_adain_apply_f32(_p(x), _p(out), planes, h * w, _p(c_mean), _p(c_var), _p(s_mean), _p(s_var), float(eps), _stream())
+    _lib.check(rc, "uav_adain_apply_f32")
+    return out
+
+
+def atrous_blur_f32(x, radius, high=None):
+    """3x3 a-trous blur (dilation `radius`, replicate padding); `high` (optional, same shape) accumulates x - blur(x) in place."""
+    lib = _lib.load()
+    x, planes, h, w = _planes(x)
+    low = torch.empty_like(x)
+    if high is not None:
+        _req(high, F32, "high")
+    _lib.check(lib.uav_atrous_blur_f32(_p(x), _p(low), _p(high), planes, h, w, int(radius), _stream()), "uav_atrous_blur_f32")
+    return low
+
+
+def resize_bicubic_f32(x, ho, wo, scale_h=None, scale_w=None):
+    """F.interpolate(x, mode='bicubic', align_corners=False): pass scale_* = 1/scale_factor when a scale factor was given
+    (ATen uses it verbatim), else in/out."""
+    lib = _lib.load()
+    x, planes, hi, wi = _planes(x)
+    out = torch.empty(tuple(x.shape[:-2]) + (ho, wo), dtype=F32, device=x.device)
+    sh = hi / ho if scale_h is None else scale_h
+    sw = wi / wo if scale_w is None else scale_w
+    _lib.check(lib.uav_resize_bicubic_f32(_p(x), _p(out), planes, hi, wi, ho, wo, float(sh), float(sw), _stream()), "uav_resize_bicubic_f32")
+    return out
