@@ -32,9 +32,24 @@ sys.path.insert(0, os.path.join(ROOT, "upscale-a-video_amd"))
 
 METRIC = "upscaled frames/sec (4x, 30 DDIM steps, 8-frame 320p clip)"
 PEAK_TFLOPS_F16 = 2500.0        # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBPS = 8000.0          # HBM3E spec peak (6.3 TB/s measured achievable), same guide
 
 
-def build_pipeline(dev, height, width, unet_cfg=None, vae_cfg=None):
+def build_text_encoder(dev, dim, kind):
+    """`clip`: the ViT-H/14 text tower of the released pipeline (24 layers, width 1024, 16 heads, 354 M parameters, random
+    init) on the HIP kernels (uav/clip_text.py); `standin`: the deterministic embedding table of SURVEY.md §8 row a19."""
+    from uav.standin_text import StandInTextEncoder, StandInTokenizer
+    tok = StandInTokenizer()
+    if kind == "standin":
+        return StandInTextEncoder(tok, dim), tok
+    from uav.clip_text import UavCLIPTextModel
+    torch.manual_seed(99)
+    te = UavCLIPTextModel(vocab_size=49408, hidden_size=dim, intermediate_size=4 * dim, num_hidden_layers=24,
+                          num_attention_heads=dim // 64, max_position_embeddings=77, hidden_act="gelu").half().to(dev).eval()
+    return te, tok
+
+
+def build_pipeline(dev, height, width, unet_cfg=None, vae_cfg=None, text_encoder="clip"):
     from uav import configs, init_weights
     from uav.standin_text import StandInTextEncoder, StandInTokenizer
     from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
@@ -47,8 +62,8 @@ def build_pipeline(dev, height, width, unet_cfg=None, vae_cfg=None):
     init_weights.random_init_(unet, seed=1234)
     vae = AutoencoderKLVideo.from_config(dict(vae_cfg)).half().to(dev).eval()
     init_weights.random_init_(vae, seed=4321)
-    tok = StandInTokenizer()
-    pipe = VideoUpscalePipeline(text_encoder=StandInTextEncoder(tok, unet_cfg["cross_attention_dim"]), tokenizer=tok,
+    te, tok = build_text_encoder(dev, unet_cfg["cross_attention_dim"], text_encoder)
+    pipe = VideoUpscalePipeline(text_encoder=te, tokenizer=tok,
                                 low_res_scheduler=DDPMScheduler(**configs.LOW_RES_DDPM),
                                 scheduler=DDIMScheduler(**configs.DDIM), vae=vae, unet=unet, propagator=None).to(dev)
     return pipe
@@ -158,6 +173,8 @@ def main():
     ap.add_argument("--vae-fp16", action="store_true",
                     help="A/B switch: all-fp16 VAE decoder rows (round-1 behaviour, ~1e-3 rel-L2 vs the fp32 reference decode) "
                          "instead of the default fp32 residual stream (~6e-4); the mode timed is named in config.workload")
+    ap.add_argument("--text-encoder", choices=["clip", "standin"], default="clip",
+                    help="clip: ViT-H/14 text tower (random init) on the HIP kernels, run once per distinct prompt pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     args = ap.parse_args()
@@ -188,7 +205,7 @@ def main():
     if lib.uav_device_check(local_rank, None) != 0:
         raise SystemExit("bench.py needs an MI355X (gfx950)")
 
-    pipe = build_pipeline(dev, args.height, args.width)
+    pipe = build_pipeline(dev, args.height, args.width, text_encoder=args.text_encoder)
     pipe.vae.stream_dtype = torch.float16 if args.vae_fp16 else torch.float32
     pipe.cfg_shared_input = not args.no_cfg_share
     pipe.shard_windows = args.shard_windows
@@ -289,7 +306,9 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.shard_windows else "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"configs[{3 if args.shard_windows else 2 if args.propagation else 1}]: {args.frames}-frame {args.height}x{args.width}->{4 * args.height}x{4 * args.width}, "
-                                   f"{args.ddim_steps} DDIM steps, guidance 6, noise_level 120, vae_3d ("
+                                   f"{args.ddim_steps} DDIM steps, guidance 6, noise_level 120, "
+                                   + ("CLIP ViT-H text tower on HIP kernels (one encode per distinct prompt pair), " if args.text_encoder == "clip" else "stand-in text embedding, ")
+                                   + "vae_3d ("
                                    + ("all-fp16 decoder rows" if args.vae_fp16 else "fp32 residual stream, fp16 MFMA operands") + "), "
                                    + (f"RAFT flows (20 iters, {raft_s * 1e3:.0f} ms, outside the timed region like the reference) + "
                                       f"latent propagation at steps {psteps}; " if args.propagation else "no propagation; ")
@@ -325,13 +344,22 @@ def main():
             if name == "conv_gemm" and os.path.exists(tfile) and not (args.propagation or args.shard_windows or args.frames != 8):
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
-                               "frac": ach / PEAK_TFLOPS_F16, "traffic": traffic, "launches": d["launches"],
+                               "frac": ach / PEAK_TFLOPS_F16, "traffic": traffic,
+                               "traffic_source": None if traffic is None else "replayed from profiles/pmc_conv_traffic.json (separate rocprofv3 "
+                                                 "--pmc pass over this command, tools/pmc_traffic.sh); not measured by this run",
+                               "launches": d["launches"],
                                "avg_launch_us": d["seconds"] / d["launches"] * 1e6,
                                "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
                                "kernel_time_share": d["seconds"] / total_s}
+            # per kernel: MFMA-bound ones against the dense fp16 peak, HBM-bound ones (algorithmic bytes: every operand
+            # read / written once) against the 8 TB/s HBM3E peak
+            hbm_bound = ("groupnorm_stats", "groupnorm_apply", "layernorm", "temporal_attention", "attention_d64")
             res["kernel_breakdown"] = {k: {"launches": v["launches"], "ms": round(v["seconds"] * 1e3, 2),
                                            "tflops": round(v["flops"] / v["seconds"] / 1e12, 1) if v["flops"] else None,
-                                           "GBps": round(v["bytes"] / v["seconds"] / 1e9, 1)}
+                                           "GBps": round(v["bytes"] / v["seconds"] / 1e9, 1),
+                                           "bound": "hbm" if k in hbm_bound else "mfma",
+                                           "frac": round(v["bytes"] / v["seconds"] / 1e9 / PEAK_HBM_GBPS, 3) if k in hbm_bound
+                                           else (round(v["flops"] / v["seconds"] / 1e12 / PEAK_TFLOPS_F16, 3) if v["flops"] else None)}
                                        for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])}
             res["kernel_time_ms_per_step"] = total_s / args.steps * 1e3
         if world == 1 and not args.no_cpu_baseline:

@@ -56,6 +56,8 @@ int  uav_device_check(int dev, char* name_out);
  */
 #define UAV_CONV_GEGLU    1u   /* rows of W interleaved [32 value | 32 gate]; out width n/2 */
 #define UAV_CONV_OUT_F32  2u   /* store fp32 instead of fp16 */
+#define UAV_CONV_GELU       256u /* out = gelu_erf(conv + bias + rowbias) (+ residual) * scale  (CLIP ViT-H MLP) */
+#define UAV_CONV_QUICK_GELU 512u /* x * sigmoid(1.702 x) (OpenAI CLIP MLP) */
 #define UAV_CONV_RES_F32  128u /* `residual` is fp32 [M][res_stride] (fp32 residual stream of the VAE decoder) */
 
 typedef struct {
@@ -126,6 +128,7 @@ int uav_attention_f16(const void* q, int64_t q_stride, const void* k, int64_t k_
                       const void* v, int64_t v_stride, void* out, int64_t o_stride,
                       int32_t bq, int32_t lq, int32_t lk, int32_t q_per_kv,
                       int32_t heads, int32_t head_dim, float scale,
+                      int32_t causal /* 1: key j visible to query i only if j <= i (CLIP text encoder; lq == lk, d 64|128) */,
                       const void* zero_page /* >=16 B of device zeros */, void* stream);
 
 /* ---- K7: per-pixel temporal attention --------------------------------------------------

@@ -23,7 +23,7 @@ def _h(x):
 
 # ---------------------------------------------------------------------------------------------------------------------
 def conv_gemm(a1, wt, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None, rowbias=None, rows_per_batch=0,
-              residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None, persistent=False):
+              residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None, persistent=False, act=None):
     c1 = a1.shape[-1]
     c2 = 0 if a2 is None else a2.shape[-1]
     assert c1 + c2 == wt.cin_p, (c1, c2, wt.cin_p)
@@ -61,6 +61,10 @@ def conv_gemm(a1, wt, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=Fals
     if wt.geglu:
         yb = y.reshape(m, wt.n // 64, 2, 32)                                          # [32 value | 32 gate] blocks
         y = (yb[:, :, 0] * F.gelu(yb[:, :, 1])).reshape(m, wt.n // 2)
+    if act == "gelu":
+        y = F.gelu(y)
+    elif act == "quick_gelu":
+        y = y * torch.sigmoid(1.702 * y)
     if residual is not None:
         assert residual.shape[0] == m
         y = y + residual.float()[:, : y.shape[1]]
@@ -76,9 +80,9 @@ def _factor_rows(m):
     return 1, m
 
 
-def linear(x, wt, *, residual=None, out_scale=1.0, rowbias=None, rows_per_batch=0, out_f32=False):
+def linear(x, wt, *, residual=None, out_scale=1.0, rowbias=None, rows_per_batch=0, out_f32=False, act=None):
     return conv_gemm(x, wt, n_img=1, t_len=1, hi=x.shape[0], wi=1, residual=residual, out_scale=out_scale, rowbias=rowbias,
-                     rows_per_batch=rows_per_batch, out_f32=out_f32)
+                     rows_per_batch=rows_per_batch, out_f32=out_f32, act=act)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -103,13 +107,17 @@ def layernorm(x, gamma, beta, eps=1e-5):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def attention(q, k, v, *, bq, lq, lk, heads, head_dim, q_per_kv=1, scale=None, q_stride=None, k_stride=None, v_stride=None):
+def attention(q, k, v, *, bq, lq, lk, heads, head_dim, q_per_kv=1, scale=None, q_stride=None, k_stride=None, v_stride=None,
+              causal=False):
     c = heads * head_dim
     scale = head_dim ** -0.5 if scale is None else scale
     qh = q.float().reshape(bq, lq, heads, head_dim).permute(0, 2, 1, 3)
     kh = k.float().reshape(bq // q_per_kv, lk, heads, head_dim).repeat_interleave(q_per_kv, 0).permute(0, 2, 1, 3)
     vh = v.float().reshape(bq // q_per_kv, lk, heads, head_dim).repeat_interleave(q_per_kv, 0).permute(0, 2, 1, 3)
-    p = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
+    sc = qh @ kh.transpose(-1, -2) * scale
+    if causal:
+        sc = sc + torch.full((lq, lk), float("-inf")).triu(1)
+    p = torch.softmax(sc, dim=-1)
     return _h((p @ vh).permute(0, 2, 1, 3).reshape(bq * lq, c))
 
 

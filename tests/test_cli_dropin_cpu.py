@@ -52,7 +52,7 @@ def _write_pretrained(root):
     CLIPTokenizer(vocab=vocab, merges=[], model_max_length=77).save_pretrained(os.path.join(base, "tokenizer"))
     torch.manual_seed(0)
     cfg = CLIPTextConfig(vocab_size=len(vocab), hidden_size=GC.UNET_TINY["cross_attention_dim"], intermediate_size=128,
-                         num_hidden_layers=2, num_attention_heads=2, max_position_embeddings=77, eos_token_id=1, bos_token_id=0,
+                         num_hidden_layers=2, num_attention_heads=1, max_position_embeddings=77, eos_token_id=1, bos_token_id=0,
                          pad_token_id=1)
     CLIPTextModel(cfg).save_pretrained(os.path.join(base, "text_encoder"))
     json.dump({"_class_name": "VideoUpscalePipeline"}, open(os.path.join(base, "model_index.json"), "w"))

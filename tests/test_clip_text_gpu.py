@@ -1,0 +1,71 @@
+"""MI355X-native CLIP text encoder (uav/clip_text.py) against transformers' `CLIPTextModel` (fp32, CPU) with seeded
+random weights: a small quick-GELU model (OpenAI-CLIP style) and the ViT-H/14 text tower the released pipeline ships
+(24 layers, width 1024, 16 heads, GELU, 77 tokens).  Tolerance: activations / weights are fp16 with fp32 accumulation,
+the reference CLI runs this model in fp16 as well (from_pretrained(torch_dtype=float16)) -> rel-L2 <= 3e-3 vs fp32."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l2(a, b):
+    a = a.float().cpu(); b = b.float().cpu()
+    return ((a - b).norm() / (b.norm() + 1e-12)).item()
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("small_quick_gelu", dict(vocab_size=300, hidden_size=128, intermediate_size=256, num_hidden_layers=3, num_attention_heads=2, hidden_act="quick_gelu")),
+    ("vit_h_text_tower", dict(vocab_size=49408, hidden_size=1024, intermediate_size=4096, num_hidden_layers=24, num_attention_heads=16, hidden_act="gelu")),
+])
+def test_clip_text_encoder_vs_transformers(dev, name, kw):
+    from transformers import CLIPTextConfig, CLIPTextModel
+    from uav.clip_text import UavCLIPTextModel
+    torch.manual_seed(7)
+    cfg = CLIPTextConfig(max_position_embeddings=77, bos_token_id=0, eos_token_id=1, pad_token_id=1, **kw)
+    hf = CLIPTextModel(cfg).eval()
+    with torch.no_grad():
+        for p in hf.parameters():
+            p.copy_(p.half().float())                 # fp16-representable weights: both sides compute on identical values
+    ids = torch.randint(2, kw["vocab_size"], (2, 77)); ids[:, 0] = 0; ids[0, 9:] = 1; ids[1, 40:] = 1
+    with torch.no_grad():
+        ref = hf(ids)[0]
+    m = UavCLIPTextModel.from_hf(hf).half().to(dev)
+    assert list(m.state_dict().keys()) == list(hf.state_dict().keys())
+    out = m(ids.to(dev))
+    assert out[0].shape == ref.shape and out[0].dtype == torch.float16 and out.last_hidden_state is out[0]
+    e = rel_l2(out[0], ref)
+    assert e < 3e-3, f"{name}: rel-L2 {e}"
+    # causality: changing a later token must not change earlier positions
+    ids2 = ids.clone(); ids2[:, 50:] = 5
+    out2 = m(ids2.to(dev))[0]
+    assert torch.equal(out2[:, :50], out[0][:, :50]) and not torch.equal(out2[:, 50:], out[0][:, 50:])
+
+
+def test_pipeline_from_pretrained_uses_native_text_encoder(dev, tmp_path):
+    """`VideoUpscalePipeline.from_pretrained` (inference_upscale_a_video.py:101) hands back the HIP text encoder."""
+    import os
+    from tokenizers import pre_tokenizers
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTokenizer
+    from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
+    from uav.clip_text import UavCLIPTextModel
+    base = str(tmp_path)
+    alpha = sorted(pre_tokenizers.ByteLevel.alphabet())
+    vocab = {"<|startoftext|>": 0, "<|endoftext|>": 1}
+    for ch in alpha:
+        vocab[ch] = len(vocab)
+    for ch in alpha:
+        vocab[ch + "</w>"] = len(vocab)
+    CLIPTokenizer(vocab=vocab, merges=[], model_max_length=77).save_pretrained(os.path.join(base, "tokenizer"))
+    torch.manual_seed(1)
+    cfg = CLIPTextConfig(vocab_size=len(vocab), hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2,
+                         max_position_embeddings=77, eos_token_id=1, bos_token_id=0, pad_token_id=1)
+    hf = CLIPTextModel(cfg); hf.save_pretrained(os.path.join(base, "text_encoder"))
+    pipe = VideoUpscalePipeline.from_pretrained(base, torch_dtype=torch.float16).to(dev)
+    assert isinstance(pipe.text_encoder, UavCLIPTextModel) and pipe.text_encoder.dtype == torch.float16
+    emb = pipe._encode_prompt("best quality, extremely detailed", dev, 1, True, "blur, worst quality")
+    assert emb.shape == (2, 77, 128) and emb.dtype == torch.float16
+    tok = pipe.tokenizer(["blur, worst quality", "best quality, extremely detailed"], padding="max_length", max_length=77, truncation=True,
+                         return_tensors="pt")
+    with torch.no_grad():
+        ref = hf.eval()(tok.input_ids)[0]
+    assert rel_l2(emb, ref) < 3e-3

@@ -358,10 +358,11 @@ def test_cabi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.uav_groupnorm_scale_shift(P, None, 1, 64, 0, 64, 1, 16, 7, 1e-5, None, None, P, P, P, 1 << 20, None) == ESHAPE
     assert lib.uav_groupnorm_scale_shift(P, None, 0, 64, 0, 64, 1, 16, 32, 1e-5, None, None, P, P, P, 8, None) == EINVAL    # workspace too small
     # attention: null / shape / alignment
-    assert lib.uav_attention_f16(None, 64, P, 64, P, 64, P, 64, 1, 8, 8, 1, 1, 64, 0.125, P, None) == EINVAL
-    assert lib.uav_attention_f16(P, 64, P, 64, P, 64, P, 64, 3, 8, 8, 2, 1, 64, 0.125, P, None) == ESHAPE        # bq % q_per_kv
-    assert lib.uav_attention_f16(P, 60, P, 64, P, 64, P, 64, 1, 8, 8, 1, 1, 64, 0.125, P, None) == EALIGN
-    assert lib.uav_attention_f16(P, 96, P, 96, P, 96, P, 96, 1, 8, 8, 1, 1, 96, 0.125, P, None) == ESHAPE        # head_dim not built
+    assert lib.uav_attention_f16(None, 64, P, 64, P, 64, P, 64, 1, 8, 8, 1, 1, 64, 0.125, 0, P, None) == EINVAL
+    assert lib.uav_attention_f16(P, 64, P, 64, P, 64, P, 64, 3, 8, 8, 2, 1, 64, 0.125, 0, P, None) == ESHAPE        # bq % q_per_kv
+    assert lib.uav_attention_f16(P, 60, P, 64, P, 64, P, 64, 1, 8, 8, 1, 1, 64, 0.125, 0, P, None) == EALIGN
+    assert lib.uav_attention_f16(P, 96, P, 96, P, 96, P, 96, 1, 8, 8, 1, 1, 96, 0.125, 0, P, None) == ESHAPE        # head_dim not built
+    assert lib.uav_attention_f16(P, 64, P, 64, P, 64, P, 64, 1, 8, 16, 1, 1, 64, 0.125, 1, P, None) == ESHAPE       # causal needs lq == lk
     # temporal attention: T > 8 is not on the path
     assert lib.uav_temporal_attention_f16(P, P, 1, 9, 16, 512, 8, 0.125, P, P, 32, P, None) == ESHAPE
     assert lib.uav_resize_bilinear_f32(None, P, 1, 4, 4, 8, 8, 1.0, 1.0, None) == EINVAL

@@ -32,6 +32,7 @@ struct AttnArgs {
     int bq, lq, lk, q_per_kv, heads;
     float scale_log2;
     const char* zero_page;
+    int causal;                 // 1: key j is visible to query i only if j <= i (CLIP text encoder)
 };
 
 constexpr int KV = 32;          // keys per tile
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_kernel(AttnArgs 
         for (int r = 0; r < 16; ++r) {
             const int key = key0 + (r & 3) + 8 * (r >> 2);
             float s = sacc[r] * p.scale_log2;
-            s = key < p.lk ? s : -INFINITY;
+            s = (key < p.lk) & (!p.causal | (key <= qrow)) ? s : -INFINITY;
             sacc[r] = s; mx = fmaxf(mx, s);
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
@@ -388,14 +389,15 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
 
 extern "C" int uav_attention_f16(const void* q, int64_t q_stride, const void* k, int64_t k_stride, const void* v,
                                  int64_t v_stride, void* out, int64_t o_stride, int32_t bq, int32_t lq, int32_t lk,
-                                 int32_t q_per_kv, int32_t heads, int32_t head_dim, float scale, const void* zero_page,
-                                 void* stream) {
+                                 int32_t q_per_kv, int32_t heads, int32_t head_dim, float scale, int32_t causal,
+                                 const void* zero_page, void* stream) {
     if (!q || !k || !v || !out || !zero_page) return UAV_EINVAL;
     if (bq <= 0 || lq <= 0 || lk <= 0 || heads <= 0 || q_per_kv <= 0 || (bq % q_per_kv)) return UAV_ESHAPE;
     if ((q_stride % 8) || (k_stride % 8) || (v_stride % 8) || (o_stride % 4)) return UAV_EALIGN;
     if (heads > 65535 || bq > 65535) return UAV_ESHAPE;
     AttnArgs a{(const char*)q, q_stride, (const char*)k, k_stride, (const char*)v, v_stride, (char*)out, o_stride,
-               bq, lq, lk, q_per_kv, heads, scale * 1.44269504088896341f, (const char*)zero_page};
+               bq, lq, lk, q_per_kv, heads, scale * 1.44269504088896341f, (const char*)zero_page, causal ? 1 : 0};
+    if (causal && (head_dim == 512 || lq != lk)) return UAV_ESHAPE;      // causal mask: self-attention in the generic kernel only
     hipStream_t s = (hipStream_t)stream;
     switch (head_dim) {
         case 64: return launch_attn<64>(a, s);

@@ -231,14 +231,15 @@ UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long 
     const bool geglu = p.flags & UAV_CONV_GEGLU;
     const bool of32 = p.flags & UAV_CONV_OUT_F32;
     const bool rf32 = p.flags & UAV_CONV_RES_F32;
-    if (of32 && !geglu && p.bias && !p.rowbias && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n && !(p.out_stride & 3) &&
+    const unsigned actf = p.flags & (UAV_CONV_GELU | UAV_CONV_QUICK_GELU);      // activation: generic path only (tiny GEMMs)
+    if (of32 && !actf && !geglu && p.bias && !p.rowbias && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n && !(p.out_stride & 3) &&
         (!p.residual || (rf32 && !(p.res_stride & 3)))) {
         if (p.residual) conv_epilogue_f32_fast<NI, MI, true>(p, acc, mw0, nw0, l32, hi32);
         else conv_epilogue_f32_fast<NI, MI, false>(p, acc, mw0, nw0, l32, hi32);
         return;
     }
     // wave-uniform fast-path test
-    if (!of32 && !rf32 && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n && !(p.out_stride & 7) &&
+    if (!of32 && !rf32 && !actf && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n && !(p.out_stride & 7) &&
         (!p.residual || !(p.res_stride & 7))) {
         if (geglu) {
             if (p.bias) conv_epilogue_geglu_fast<NI, MI, true>(p, acc, mw0, nw0, l32, hi32);
@@ -313,7 +314,7 @@ UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long 
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
                 const int nq = nw0 + ni * 32 + 16 * gp;               // first channel of this quad pair (wave-uniform)
-                const bool wide = !of32 && !rf32 && (nq + 16 <= p.n) && !(p.out_stride & 7) && !(p.res_stride & 7);
+                const bool wide = !of32 && !rf32 && !actf && (nq + 16 <= p.n) && !(p.out_stride & 7) && !(p.res_stride & 7);
                 if (wide) {
                     const int nl = nq + 8 * hi32;                     // the 8 channels this lane loads / stores
                     uint32_t R[4] = {0, 0, 0, 0};
@@ -373,6 +374,11 @@ UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long 
                             float4_t b = *(const float4_t*)(rb + n);
 #pragma unroll
                             for (int j = 0; j < 4; ++j) v[j] += b[j];
+                        }
+                        if (actf) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                v[j] = (actf & UAV_CONV_GELU) ? uav_gelu_erf(v[j]) : v[j] / (1.0f + __expf(-1.702f * v[j]));
                         }
                         if (p.residual) {
                             if (rf32) {
@@ -1283,6 +1289,7 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     if ((q->flags & UAV_CONV_GEGLU) && ((q->flags & UAV_CONV_OUT_F32) || q->residual || q->rowbias || (q->n % 64)))
         return UAV_ESHAPE;
     if ((q->flags & UAV_CONV_RES_F32) && !q->residual) return UAV_EINVAL;
+    if ((q->flags & (UAV_CONV_GELU | UAV_CONV_QUICK_GELU)) && (q->flags & UAV_CONV_GEGLU)) return UAV_ESHAPE;
     if (q->upsample && (q->stride != 1 || q->ho != 2 * q->hi || q->wo != 2 * q->wi)) return UAV_ESHAPE;
     if (q->t_len <= 0 || q->n_img % q->t_len) return UAV_ESHAPE;
     if (q->ho >= 65536 || q->wo >= 65536) return UAV_ESHAPE;

@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const char* __restrict__
 }
 
 int gn_variant() {
-    static const int v = [] { const char* e = getenv("UAV_GN_VAR"); return e ? atoi(e) : 0; }();
+    static const int v = [] { const char* e = getenv("UAV_GN_VAR"); return e ? atoi(e) : 1; }();
     return v;
 }
 

@@ -63,6 +63,7 @@ def window_schedule(t_total, short_seq=8, overlap_seq=2):
 
 class VideoUpscalePipeline(ConfigMixin):
     config_name = "model_index.json"
+    native_text_encoder = True         # from_pretrained converts the CLIP text model to uav.clip_text.UavCLIPTextModel
 
     def __init__(self, text_encoder=None, tokenizer=None, low_res_scheduler=None, scheduler: DDIMScheduler = None,
                  vae=None, unet=None, propagator=None, max_noise_level: int = 350):
@@ -94,6 +95,10 @@ class VideoUpscalePipeline(ConfigMixin):
         from transformers import CLIPTextModel, CLIPTokenizer
         tok = CLIPTokenizer.from_pretrained(os.path.join(path, "tokenizer"))
         te = CLIPTextModel.from_pretrained(os.path.join(path, "text_encoder"), torch_dtype=torch_dtype)
+        if cls.native_text_encoder:
+            # same weights, same arithmetic, on the HIP kernels (uav/clip_text.py) instead of eager transformers ops
+            from uav.clip_text import UavCLIPTextModel
+            te = UavCLIPTextModel.from_hf(te)
         lrs_dir = os.path.join(path, "low_res_scheduler")
         lrs = DDPMScheduler.from_config(lrs_dir) if os.path.isdir(lrs_dir) else DDPMScheduler()
         return cls(text_encoder=te, tokenizer=tok, low_res_scheduler=lrs)

@@ -37,6 +37,7 @@ CONV_GEGLU = 1
 CONV_OUT_F32 = 2
 CONV_PERSISTENT = 64
 CONV_RES_F32 = 128
+CONV_GELU, CONV_QUICK_GELU = 256, 512
 CONV_RELU, CONV_SIGMOID, CONV_TANH = 4, 8, 16
 
 # name -> (restype, argtypes); the complete export list of include/uav_hip.h
@@ -48,7 +49,7 @@ SIGNATURES = {
     "uav_groupnorm_scale_shift": (C.c_int, [c_p, c_p, i32, i32, i32, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
     "uav_groupnorm_apply": (C.c_int, [c_p, c_p, i32, i32, i32, i32, i64, c_p, c_p, i32, c_p, c_p]),
     "uav_layernorm_f16": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, f32, c_p]),
-    "uav_attention_f16": (C.c_int, [c_p, i64, c_p, i64, c_p, i64, c_p, i64, i32, i32, i32, i32, i32, i32, f32, c_p, c_p]),
+    "uav_attention_f16": (C.c_int, [c_p, i64, c_p, i64, c_p, i64, c_p, i64, i32, i32, i32, i32, i32, i32, f32, i32, c_p, c_p]),
     "uav_temporal_attention_f16": (C.c_int, [c_p, c_p, i32, i32, i64, i32, i32, f32, c_p, c_p, i32, c_p, c_p]),
     "uav_linear_small": (C.c_int, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, c_p]),
     "uav_timestep_embedding": (C.c_int, [c_p, i32, i32, i32, f32, c_p, c_p]),

@@ -180,7 +180,7 @@ def pack_conv(weight, bias=None, geglu=False, device=None, n_store_align=4):
 
 def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None,
               rowbias=None, rows_per_batch=0, residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None,
-              persistent=False):
+              persistent=False, act=None):
     """out[M][n_out] = scale*(conv(a1|a2, W) + bias + rowbias[m//rows_per_batch] + residual)."""
     lib = _lib.load()
     _req(a1, HALF, "a1")
@@ -208,6 +208,8 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
     if out is None:
         out = torch.empty((m, n_out), dtype=torch.float32 if out_f32 else HALF, device=a1.device)
     flags = (_lib.CONV_GEGLU if wt.geglu else 0) | (_lib.CONV_OUT_F32 if out_f32 else 0) | (_lib.CONV_PERSISTENT if persistent else 0)
+    if act is not None:
+        flags |= {"gelu": _lib.CONV_GELU, "quick_gelu": _lib.CONV_QUICK_GELU}[act]
     p = _lib.ConvParams()
     p.a1 = _p(a1); p.a2 = _p(a2); p.c1 = c1; p.c2 = c2
     p.w = _p(wt.w); p.bias = _p(wt.bias)
@@ -252,11 +254,11 @@ def _factor_rows(m):
     raise _lib.UavError("unreachable")
 
 
-def linear(x, wt: ConvW, *, residual=None, out_scale=1.0, rowbias=None, rows_per_batch=0, out_f32=False):
+def linear(x, wt: ConvW, *, residual=None, out_scale=1.0, rowbias=None, rows_per_batch=0, out_f32=False, act=None):
     """nn.Linear over token rows x[M][K] (a 1x1 'conv': every row is one pixel)."""
     n_img, hi = _factor_rows(x.shape[0])
     return conv_gemm(x, wt, n_img=n_img, t_len=1, hi=hi, wi=1, residual=residual, out_scale=out_scale,
-                     rowbias=rowbias, rows_per_batch=rows_per_batch, out_f32=out_f32)
+                     rowbias=rowbias, rows_per_batch=rows_per_batch, out_f32=out_f32, act=act)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -324,7 +326,7 @@ def layernorm(x, gamma, beta, eps=1e-5):
 
 # ------------------------------------------------------------------------------------------------
 def attention(q, k, v, *, bq, lq, lk, heads, head_dim, q_per_kv=1, scale=None,
-              q_stride=None, k_stride=None, v_stride=None):
+              q_stride=None, k_stride=None, v_stride=None, causal=False):
     """softmax(scale*QK^T)V.  q/k/v are fp16 views whose row strides (in elements) may exceed
     heads*head_dim (slices of a fused projection)."""
     lib = _lib.load()
@@ -337,7 +339,7 @@ def attention(q, k, v, *, bq, lq, lk, heads, head_dim, q_per_kv=1, scale=None,
         scale = head_dim ** -0.5
     ev = PROFILER.begin()
     rc = lib.uav_attention_f16(_p(q), q_stride, _p(k), k_stride, _p(v), v_stride, _p(out), c, bq, lq, lk, q_per_kv,
-                               heads, head_dim, scale, _p(zero_page(q.device)), _stream())
+                               heads, head_dim, scale, int(causal), _p(zero_page(q.device)), _stream())
     _lib.check(rc, "uav_attention_f16")
     PROFILER.end(ev, f"attention_d{head_dim}", 4.0 * bq * heads * lq * lk * head_dim, 2.0 * (2 * bq * lq * c + 2 * (bq // q_per_kv) * lk * c))
     return out
