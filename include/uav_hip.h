@@ -210,6 +210,10 @@ int uav_atrous_blur_f32(const float* src, float* low_out, float* high_inout, int
                         int32_t radius, void* stream);
 int uav_resize_bicubic_f32(const float* src, float* dst, int32_t planes, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
                            float scale_h, float scale_w, void* stream);
+/* F.interpolate(mode='area') (adaptive average pooling) of fp32 planes, result multiplied by `mul`: the flow resize of
+ * Propagation.forward (propagation_module.py:206-209) when flows and latents differ in resolution */
+int uav_resize_area_f32(const float* src, float* dst, int32_t planes, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                        float mul, void* stream);
 
 /* ---- K10: flow-guided propagation step -----------------------------------------------
  * Replaces one recurrence step of Propagation.forward (propagation_module.py:234-254) with

@@ -216,6 +216,11 @@ def propagate_step(feat_prev, feat_cur, flow_prop, flow_check, out, *, c, h, w, 
     return out
 
 
+def resize_area_f32(x, ho, wo, mul=1.0):
+    lead = x.shape[:-2]
+    return (F.interpolate(x.reshape((-1, 1) + tuple(x.shape[-2:])).float(), (ho, wo), mode="area") * mul).reshape(tuple(lead) + (ho, wo))
+
+
 def cast_f16(x):
     return x if x.dtype == HALF else _h(x)
 
@@ -227,7 +232,7 @@ def sft_fuse(dec, scale, shift, w, out_f32=False):
     return y if out_f32 else _h(y)
 
 
-_OPS = ("cast_f16", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "temporal_attention", "linear_small",
+_OPS = ("resize_area_f32", "cast_f16", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "temporal_attention", "linear_small",
         "timestep_embedding", "pack_nhwc", "unpack_ncthw", "axpby", "cfg_ddim_v0", "ddim_vt")
 
 

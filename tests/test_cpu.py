@@ -120,6 +120,17 @@ def test_oracle_colorfix_vs_golden():
     assert (high - gold["high"]).abs().max().item() < 1e-5 and (low - gold["low"]).abs().max().item() < 1e-5
 
 
+def test_bench_self_launch_refuses_without_enough_gpus(capsys):
+    """`python bench.py --gpus N` with no launcher re-execs under torch.distributed.run (bench.self_launch); with fewer
+    than N visible GPUs it must fail loudly instead of printing a 1-rank line."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("uav_bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    assert torch.cuda.device_count() == 0
+    assert bench.self_launch(2) == 2
+    assert "only 0 GPU(s) are visible" in capsys.readouterr().err
+
+
 def test_oracle_ddim_vs_golden():
     rec = json.load(open(os.path.join(GOLD, "ddim.json")))
     sch = O.DDIM(**GC.SCHED)

@@ -399,3 +399,24 @@ def test_cast_and_sft_fuse(ops, dev):
     ref = dec + 0.6 * (dec * sc + sh)
     assert rel_l2(ops.sft_fuse(dec, sc, sh, 0.6, out_f32=True), ref) < 1e-6
     assert rel_l2(ops.sft_fuse(dec.half(), sc.half(), sh.half(), 0.6), dec.half().float() + 0.6 * (dec.half().float() * sc.half().float() + sh.half().float())) < 1e-3
+
+
+def test_resize_area_and_propagation_flow_resize(ops, dev):
+    """F.interpolate(mode='area') kernel (integer and fractional ratios) and Propagation.forward with flows at twice
+    the latent resolution (reference propagation_module.py:206-209: area resize, flows scaled by w / w_f)."""
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(3, 2, 37, 50, generator=g)
+    for (ho, wo) in ((37, 50), (18, 25), (12, 17), (74, 100)):
+        ref = F.interpolate(x, (ho, wo), mode="area") * 0.5
+        out = ops.resize_area_f32(x.to(dev), ho, wo, mul=0.5)
+        assert out.shape == ref.shape and (out.cpu() - ref).abs().max().item() < 1e-6
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import golden_cases as GC
+    from models_video.propagation_module import Propagation
+    xl, ff, fb = GC.prop_inputs(5, 24, 32)
+    up = lambda f: F.interpolate(f.reshape(1, 2 * 4, 24, 32), scale_factor=2, mode="nearest").reshape(1, 2, 4, 48, 64) * 2.0
+    prop = Propagation(4, learnable=False); prop.coord_f16 = False
+    a = prop(xl.half().to(dev), ff.to(dev), fb.to(dev), interpolation="nearest", mode="fuse", fuse_scale=0.5, alpha1=0.001, alpha2=0.05)
+    b = prop(xl.half().to(dev), up(ff).to(dev), up(fb).to(dev), interpolation="nearest", mode="fuse", fuse_scale=0.5, alpha1=0.001, alpha2=0.05)
+    assert ((a.float() - b.float()).abs() > 1e-2).float().mean().item() < 5e-3

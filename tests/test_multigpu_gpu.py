@@ -1,0 +1,40 @@
+"""Multi-GPU path on real hardware (needs >= 2 visible MI355X; skipped on the 1-GPU boxes of the pool): `bench.py --gpus 2`
+launched WITHOUT a launcher must re-exec itself under torch.distributed.run, one rank per GPU over RCCL, and print one
+JSON line with n_gpus = 2.  The window-sharded pipeline (BASELINE configs[3]) is bit-identical to the
+single-GPU call (checked on CPU/gloo in tests/test_cpu.py::test_dist_gloo_world2; here on nccl)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _need2():
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs")
+
+
+def test_bench_self_launch_two_ranks():
+    _need2()
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--height", "64", "--width", "64",
+           "--ddim-steps", "2", "--no-cpu-baseline", "--text-encoder", "standin"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["clips_per_step"] == 2
+
+
+def test_bench_shard_windows_two_ranks():
+    _need2()
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--height", "64", "--width", "64",
+           "--ddim-steps", "2", "--frames", "14", "--shard-windows", "--no-cpu-baseline", "--text-encoder", "standin"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["frames_per_clip"] == 14

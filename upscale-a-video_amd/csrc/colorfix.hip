@@ -131,7 +131,31 @@ __global__ __launch_bounds__(256) void resize_bicubic_kernel(const float* __rest
     dst[((long long)blockIdx.z * ho + y) * wo + x] = acc;
 }
 
+// F.interpolate(mode='area') = adaptive average pooling: window [floor(o*in/out), ceil((o+1)*in/out)) per axis; `mul`
+// folds the flow rescale of Propagation.forward (propagation_module.py:206-209: flows * w / w_f).
+__global__ __launch_bounds__(256) void resize_area_kernel(const float* __restrict__ src, float* __restrict__ dst, int hi, int wi,
+                                                          int ho, int wo, float mul) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= wo) return;
+    const float* p = src + (long long)blockIdx.z * hi * wi;
+    const int y0 = (int)(((long long)y * hi) / ho), y1 = (int)((((long long)(y + 1)) * hi + ho - 1) / ho);
+    const int x0 = (int)(((long long)x * wi) / wo), x1 = (int)((((long long)(x + 1)) * wi + wo - 1) / wo);
+    float acc = 0.f;
+    for (int yy = y0; yy < y1; ++yy)
+        for (int xx = x0; xx < x1; ++xx) acc += p[(long long)yy * wi + xx];
+    dst[((long long)blockIdx.z * ho + y) * wo + x] = acc / (float)((y1 - y0) * (x1 - x0)) * mul;
+}
+
 }  // namespace
+
+extern "C" int uav_resize_area_f32(const float* src, float* dst, int32_t planes, int32_t hi, int32_t wi, int32_t ho, int32_t wo,
+                                   float mul, void* stream) {
+    if (!src || !dst) return UAV_EINVAL;
+    if (planes <= 0 || planes > 65535 || hi <= 0 || wi <= 0 || ho <= 0 || ho > 65535 || wo <= 0) return UAV_ESHAPE;
+    hipLaunchKernelGGL(resize_area_kernel, dim3((wo + 255) / 256, ho, planes), dim3(256), 0, (hipStream_t)stream, src, dst, hi, wi,
+                       ho, wo, mul);
+    return uav_launch_status();
+}
 
 extern "C" int64_t uav_plane_stats_workspace_bytes(int32_t planes) { return (int64_t)planes * CF_CHUNKS * 2 * 8; }
 

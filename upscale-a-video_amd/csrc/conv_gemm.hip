@@ -923,56 +923,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
         }                                                                                                    \
     }
 
-    // Incremental addressing (V >= 5).  For everything but the folded nearest-2x upsample the source pixel of tap
-    // (dt,dy,dx) is px0 + (dt*hi + dy)*wi + dx with px0 the (possibly virtual) tap-(0,0,0) pixel of the row: the tap
-    // enters as ONE wave-uniform 64-bit offset, and which taps fall into the zero padding is a per-row property that
-    // does not change over the K loop -> a bit mask over the taps, built once per tile.  Per stage and row this leaves
-    // one 64-bit mad, one 64-bit add and a select (~9 VALU instead of ~25), which matters because the address block of
-    // the LAST wave to finish its MFMAs runs with the matrix pipe idle.
-    const bool fast_addr = V >= 5 && !p.upsample && ntaps <= 32;
-    int px0[4] = {0, 0, 0, 0};
-    unsigned vmask[4] = {0u, 0u, 0u, 0u};
-    if (fast_addr) {
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) px0[ps] = (rimg[ps] * p.hi + rys[ps]) * p.wi + rxs[ps];
-        int tdt = 0, tdy = 0, tdx = 0;
-        for (int tap = 0; tap < ntaps; ++tap) {
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const bool ok = ((unsigned)(rtl[ps] + tdt) < (unsigned)p.t_len) & ((unsigned)(rys[ps] + tdy) < (unsigned)ylim) &
-                                ((unsigned)(rxs[ps] + tdx) < (unsigned)xlim);
-                vmask[ps] |= (ok ? 1u : 0u) << tap;
-            }
-            if (++tdx == p.kw) { tdx = 0; if (++tdy == p.kh) { tdy = 0; ++tdt; } }
-        }
-    }
-#define XADDR_FAST(PS, G)                                                                                    \
-    {                                                                                                        \
-        const long long d = sdelta + ((long long)px0[PS] * xcs2 + slot16);                                   \
-        G = p.zero_page + (((vmask[PS] >> ktap) & 1u) ? d : 0ll);                                            \
-    }
-#define COMPUTE_ADDR_FAST()                                                                                  \
-    {                                                                                                        \
-        const bool first = kc < p.c1;                                                                        \
-        const char* xsrc = first ? p.a1 : p.a2;                                                              \
-        const int xcs = first ? p.c1 : p.c2;                                                                 \
-        const int xcs2 = xcs * 2;                                                                            \
-        const long long slot16 = slot_log * 16;                                                              \
-        const int tapd = (kdt * p.hi + kdy) * p.wi + kdx;                                                    \
-        const long long sdelta = (xsrc - p.zero_page) + ((long long)tapd * xcs + (first ? kc : kc - p.c1)) * 2; \
-        XADDR_FAST(0, gx0) XADDR_FAST(1, gx1) XADDR_FAST(2, gx2) XADDR_FAST(3, gx3)                          \
-        wkb = ((long long)ktap * cin + kc) * 2;                                                              \
-        if (p.korder) {                                                                                      \
-            ++ktap;                                                                                          \
-            if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } }                           \
-            if (ktap == ntaps) { ktap = 0; kdt = 0; kdy = 0; kdx = 0; kc += BK; }                            \
-        } else {                                                                                             \
-            kc += BK;                                                                                        \
-            if (kc >= cin) { kc = 0; ++ktap; if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } } } \
-        }                                                                                                    \
-    }
-#define COMPUTE_ADDR_ANY() { if (fast_addr) COMPUTE_ADDR_FAST() else COMPUTE_ADDR() }
-
     const int wn = wave & 1, wm = wave >> 1;
     float16_t acc[4][2];
 #pragma unroll
@@ -1008,7 +958,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
     [gw0] "s"(gw0), [gw1] "s"(gw1), [gw2] "s"(gw2), [gw3] "s"(gw3), [ldsn] "s"(ldsn), [dodma] "s"(dodma)
 
     // ---- prologue: stage 0 -> buffer 0, addresses of stage 1 ---------------------------------
-    COMPUTE_ADDR_ANY()
+    COMPUTE_ADDR()
     {
         const char* gw0 = wtile + wkb; const char* gw1 = gw0 + wps; const char* gw2 = gw1 + wps; const char* gw3 = gw2 + wps;
         const unsigned ldsn = ldsw, dodma = __builtin_amdgcn_readfirstlane(1u);
@@ -1017,7 +967,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
                      D0 D1 D2 D3 D4 D5 D6 D7 "s_mov_b32 m0, %[m0s]\n"
                      : [m0s] "=&s"(m0s) : DMA_OPERANDS : "memory", "scc", "vcc");
     }
-    if (nk > 1) COMPUTE_ADDR_ANY()
+    if (nk > 1) COMPUTE_ADDR()
 
 #define RD(D, A, OFF) "ds_read_b128 %[" #D "], %[" #A "] offset:" #OFF "\n"
 #define RDSET(S, A, AX) RD(w##S##0, A, 32768) RD(x##S##0, AX, 0) RD(x##S##1, AX, 4096) RD(w##S##1, A, 36864) RD(w##S##2, A, 40960) RD(w##S##3, A, 45056)
@@ -1064,16 +1014,12 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
             KSTEP_STMT(D0 D1, D2, D3, D4, D5, D6, D7, NO, NO, NO, NO, NO, NO, NO, NO, NO, NO)
         } else if constexpr (V == 2) {     // one DMA every 4 MFMAs over the first 28
             KSTEP_STMT(D0, NO, D1, NO, D2, NO, D3, NO, D4, NO, D5, NO, D6, NO, D7, NO, NO)
-        } else if constexpr (V == 3) {     // one per MFMA pair for the X gathers, then every 4 MFMAs for W
+        } else {                           // V == 3: one per MFMA pair for the X gathers, then every 4 MFMAs for W
             KSTEP_STMT(D0, D1, D2, D3, NO, D4, NO, D5, NO, D6, NO, D7, NO, NO, NO, NO, NO)
-        } else if constexpr (V == 5) {     // nothing ahead of the first MFMA, then one per MFMA pair (+ incremental addressing)
-            KSTEP_STMT(NO, D0, D1, D2, D3, D4, D5, D6, D7, NO, NO, NO, NO, NO, NO, NO, NO)
-        } else {                           // V == 6: pattern 1 + incremental addressing
-            KSTEP_STMT(D0 D1, D2, D3, D4, D5, D6, D7, NO, NO, NO, NO, NO, NO, NO, NO, NO, NO)
         }
 #undef KSTEP_STMT
         // addresses of stage ks+2: VALU beside the matrix pipe's drain, off the post-barrier critical path
-        if (ks + 2 < nk) COMPUTE_ADDR_ANY()
+        if (ks + 2 < nk) COMPUTE_ADDR()
         cur ^= 1;
     }
 #undef RD
@@ -1098,9 +1044,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
 #undef NO
 #undef XADDR
 #undef COMPUTE_ADDR
-#undef XADDR_FAST
-#undef COMPUTE_ADDR_FAST
-#undef COMPUTE_ADDR_ANY
     // the MFMAs issued last may still be in flight and the compiler cannot see them (see conv_gemm256_kernel)
     asm volatile("s_nop 15\ns_nop 15" ::: "memory");
     conv_epilogue<4, 2>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);
@@ -1396,8 +1339,7 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
                                  (const void*)conv_gemm256_kernel<4>, (const void*)conv_gemm256_kernel<5>,
                                  (const void*)conv_gemm256_kernel<6>, (const void*)conv_gemm256_kernel<0, 1>,
                                  (const void*)conv_gemm256i_kernel<1>, (const void*)conv_gemm256i_kernel<2>,
-                                 (const void*)conv_gemm256i_kernel<3>, (const void*)conv_gemm256i_kernel<5>,
-                                 (const void*)conv_gemm256i_kernel<6>};
+                                 (const void*)conv_gemm256i_kernel<3>};
             for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
             (void)hipFuncSetAttribute((const void*)conv_gemm256r_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RSLOTS * RUNIT);
             hipDeviceProp_t prop;
@@ -1416,8 +1358,6 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         else if (env.dmav == 1) hipLaunchKernelGGL(conv_gemm256i_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (env.dmav == 2) hipLaunchKernelGGL(conv_gemm256i_kernel<2>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (env.dmav == 3) hipLaunchKernelGGL(conv_gemm256i_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
-        else if (env.dmav == 5) hipLaunchKernelGGL(conv_gemm256i_kernel<5>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
-        else if (env.dmav == 6) hipLaunchKernelGGL(conv_gemm256i_kernel<6>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if ((persist || (q->flags & UAV_CONV_PERSISTENT)) && grid256 > ncu) {
             // persistent form: one workgroup per CU walks tiles wg, wg + ncu, ... (UAV_CONV_PERSIST=0 disables)
             hipLaunchKernelGGL((conv_gemm256_kernel<0, 1>), dim3((unsigned)ncu), dim3(512), 2 * LSTAGE, s, a);

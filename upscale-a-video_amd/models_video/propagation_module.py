@@ -38,9 +38,15 @@ class Propagation(nn.Module):
         b, c, t, h, w = x.shape
         if b != 1:
             raise NotImplementedError("the pipeline propagates one clip at a time (batch 1)")
-        if tuple(flows_forward.shape[-3:]) != (t - 1, h, w) or tuple(flows_backward.shape[-3:]) != (t - 1, h, w):
-            raise NotImplementedError("flows must already be at latent resolution (area-resize of flows is not built; "
-                                      "latents live at LR resolution so the CLI never needs it)")
+        if flows_forward.shape[2] != t - 1 or flows_backward.shape[2] != t - 1:
+            raise NotImplementedError("flows must carry T-1 frames (the reference's trilinear-in-time area resize is never "
+                                      "exercised: RAFT_bi returns T-1 flows)")
+        if tuple(flows_forward.shape[-2:]) != (h, w) or tuple(flows_backward.shape[-2:]) != (h, w):
+            # reference :206-209: F.interpolate(flows, (t-1, h, w), mode='area') * (w / w_f) — identity for this pipeline
+            # (latents live at LR resolution), needed when a caller hands over flows of another resolution
+            s = 1.0 * w / flows_forward.shape[-1]
+            flows_forward = ops.resize_area_f32(flows_forward.float(), h, w, mul=s).to(flows_forward.dtype)
+            flows_backward = ops.resize_area_f32(flows_backward.float(), h, w, mul=s).to(flows_backward.dtype)
         if mode == "copy":
             fuse_scale = 1.0
         elif mode != "fuse":

@@ -65,6 +65,7 @@ SIGNATURES = {
     "uav_adain_apply_f32": (C.c_int, [c_p, c_p, i32, i64, c_p, c_p, c_p, c_p, f32, c_p]),
     "uav_atrous_blur_f32": (C.c_int, [c_p, c_p, c_p, i32, i32, i32, i32, c_p]),
     "uav_resize_bicubic_f32": (C.c_int, [c_p, c_p, i32, i32, i32, i32, i32, f32, f32, c_p]),
+    "uav_resize_area_f32": (C.c_int, [c_p, c_p, i32, i32, i32, i32, i32, f32, c_p]),
     "uav_conv_gemm_f32": (C.c_int, [C.POINTER(ConvParams), c_p]),
     "uav_instnorm_f32": (C.c_int, [c_p, c_p, i32, i32, i32, f32, i32, c_p]),
     "uav_add_relu_f32": (C.c_int, [c_p, c_p, c_p, i64, i32, c_p]),

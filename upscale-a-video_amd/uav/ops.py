@@ -677,3 +677,12 @@ def resize_bicubic_f32(x, ho, wo, scale_h=None, scale_w=None):
     sw = wi / wo if scale_w is None else scale_w
     _lib.check(lib.uav_resize_bicubic_f32(_p(x), _p(out), planes, hi, wi, ho, wo, float(sh), float(sw), _stream()), "uav_resize_bicubic_f32")
     return out
+
+
+def resize_area_f32(x, ho, wo, mul=1.0):
+    """F.interpolate(x, (ho, wo), mode='area') * mul on (..., H, W) fp32."""
+    lib = _lib.load()
+    x, planes, hi, wi = _planes(x)
+    out = torch.empty(tuple(x.shape[:-2]) + (ho, wo), dtype=F32, device=x.device)
+    _lib.check(lib.uav_resize_area_f32(_p(x), _p(out), planes, hi, wi, ho, wo, float(mul), _stream()), "uav_resize_area_f32")
+    return out
