@@ -170,6 +170,9 @@ def main():
                     help="clips upscaled CONCURRENTLY per GPU in one step, one HIP stream (and host thread) each: the "
                          "HBM-bound kernels of one clip run beside the MFMA-bound kernels of the other (serving mode); "
                          "per-launch HIP events are switched off because launches overlap")
+    ap.add_argument("--video-vae", action="store_true",
+                    help="BASELINE configs[4] building block: the SFT-conditioned video VAE (vae_video config, 3x3x3 convs) instead "
+                         "of vae_3d; use with --height 348 --width 384 for one CLI tile of a 540p frame")
     ap.add_argument("--vae-fp16", action="store_true",
                     help="A/B switch: all-fp16 VAE decoder rows (round-1 behaviour, ~1e-3 rel-L2 vs the fp32 reference decode) "
                          "instead of the default fp32 residual stream (~6e-4); the mode timed is named in config.workload")
@@ -205,7 +208,9 @@ def main():
     if lib.uav_device_check(local_rank, None) != 0:
         raise SystemExit("bench.py needs an MI355X (gfx950)")
 
-    pipe = build_pipeline(dev, args.height, args.width, text_encoder=args.text_encoder)
+    from uav import configs as _cfg
+    pipe = build_pipeline(dev, args.height, args.width, text_encoder=args.text_encoder,
+                          vae_cfg=_cfg.VAE_VIDEO if args.video_vae else None)
     pipe.vae.stream_dtype = torch.float16 if args.vae_fp16 else torch.float32
     pipe.cfg_shared_input = not args.no_cfg_share
     pipe.shard_windows = args.shard_windows
@@ -305,10 +310,11 @@ def main():
             "metric": METRIC, "value": frames_total / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if args.shard_windows else "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"configs[{3 if args.shard_windows else 2 if args.propagation else 1}]: {args.frames}-frame {args.height}x{args.width}->{4 * args.height}x{4 * args.width}, "
+            "config": {"workload": f"configs[{3 if args.shard_windows else 4 if args.video_vae else 2 if args.propagation else 1}]"
+                                   + (" (one spatial tile of a 540p clip)" if args.video_vae else "") + f": {args.frames}-frame {args.height}x{args.width}->{4 * args.height}x{4 * args.width}, "
                                    f"{args.ddim_steps} DDIM steps, guidance 6, noise_level 120, "
                                    + ("CLIP ViT-H text tower on HIP kernels (one encode per distinct prompt pair), " if args.text_encoder == "clip" else "stand-in text embedding, ")
-                                   + "vae_3d ("
+                                   + ("vae_video (" if args.video_vae else "vae_3d (")
                                    + ("all-fp16 decoder rows" if args.vae_fp16 else "fp32 residual stream, fp16 MFMA operands") + "), "
                                    + (f"RAFT flows (20 iters, {raft_s * 1e3:.0f} ms, outside the timed region like the reference) + "
                                       f"latent propagation at steps {psteps}; " if args.propagation else "no propagation; ")
@@ -341,7 +347,7 @@ def main():
             # TCC_EA0_RDREQ / WRREQ with the gfx950 corrections of MI355X_MICROARCH.md) and stays null without it.
             traffic = None
             tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_conv_traffic.json")
-            if name == "conv_gemm" and os.path.exists(tfile) and not (args.propagation or args.shard_windows or args.frames != 8):
+            if name == "conv_gemm" and os.path.exists(tfile) and not (args.propagation or args.shard_windows or args.video_vae or args.frames != 8 or args.height != 320 or args.width != 320):
                 traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
             res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
                                "frac": ach / PEAK_TFLOPS_F16, "traffic": traffic,
