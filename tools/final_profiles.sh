@@ -3,8 +3,7 @@
 # kept under gpurun_out/ (the raw rocprofv3 databases exceed the 64-MiB merge limit).
 mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; cd /tmp; export TMPDIR=/tmp
 timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_final -o bench -- python $R/bench.py --steps 2 --no-cpu-baseline > $R/gpurun_out/bench_under_rocprof.json 2> $R/gpurun_out/bench_under_rocprof.err
-for f in $(find /tmp/prof_final -name "*kernel_stats*"); do cp $f $R/gpurun_out/rocprofv3_kernel_stats_bench.csv; done
-ls /tmp/prof_final/* | head
+python $R/tools/rocpd_top_kernels.py $(find /tmp/prof_final -name "*.db" | head -1) $R/gpurun_out/rocprofv3_kernel_stats_bench.csv "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --no-cpu-baseline (MI355X, round 2; rocpd view top_kernels; 1 warmup + 2 timed clips)"
 timeout 300 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum \
   -d /tmp/pmc_traffic -o traffic -- python $R/bench.py --no-cpu-baseline --no-kernel-events --warmup 0 --steps 1 > $R/gpurun_out/pmc_traffic_bench.json 2> $R/gpurun_out/pmc_traffic.err
 DB=$(find /tmp/pmc_traffic -name "*.db" | head -1); echo "db=$DB"
