@@ -44,7 +44,7 @@ UAV_DEVINL void gn_load8(const GnSrc& s, long long row, int v, float (&f)[8]) {
 }
 
 template <bool F32, int U>
-__global__ __launch_bounds__(256) void gn_partial_kernel(GnSrc s, long long rows_per_inst, int chunks,
+__global__ __launch_bounds__(256) void gn_partial_kernel(GnSrc s, long long rows_per_inst, int chunks, int c_real, int groups,
                                                          float* __restrict__ ws) {
     __shared__ float red[256 * 16];
     const int c = s.c1 + s.c2, cvec = c >> 3;
@@ -81,21 +81,34 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(GnSrc s, long long rows
 #pragma unroll
     for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = sm[j]; red[tid * 16 + 8 + j] = sq[j]; }
     __syncthreads();
+    float a[16];
     if (tid < cvec) {
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            float a = 0.f;
-            for (int q = 0; q < rpp; ++q) a += red[(q * cvec + tid) * 16 + j];
-            // layout: ws[inst][chunk][0:c] = sums, [c:2c] = sumsq
-            float* dst = ws + ((long long)(inst * chunks + chunk) * 2 * c);
-            dst[(j < 8 ? 0 : c) + tid * 8 + (j & 7)] = a;
+            a[j] = 0.f;
+            for (int q = 0; q < rpp; ++q) a[j] += red[(q * cvec + tid) * 16 + j];
         }
+    }
+    __syncthreads();
+    // per-channel totals of this chunk -> LDS [0:c] sums, [c:2c] sums of squares, then one (sum, sumsq) pair per GROUP:
+    // the finalize pass reads chunks x 2 floats per group instead of chunks x 2 x (C/G) (it was a third of the statistics
+    // time at 2048 chunks: 36 us per launch)
+    if (tid < cvec) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { red[tid * 8 + j] = a[j]; red[c + tid * 8 + j] = a[8 + j]; }
+    }
+    __syncthreads();
+    const int cpg = c_real / groups;
+    float* dst = ws + (long long)(inst * chunks + chunk) * 2 * groups;
+    for (int g = tid; g < groups; g += 256) {
+        float gs = 0.f, gq = 0.f;
+        for (int k = 0; k < cpg; ++k) { gs += red[g * cpg + k]; gq += red[c + g * cpg + k]; }
+        dst[g] = gs; dst[groups + g] = gq;
     }
 }
 
-// One workgroup per (group, instance): fp64 reduction of the per-chunk per-channel partials of the
-// group's channels, then scale/shift for those channels.  (A single block per instance walking all
-// chunks serially cost ~0.23 ms per GroupNorm — more than the statistics pass itself at 1/8 res.)
+// One workgroup per (group, instance): fp64 reduction of the per-chunk (sum, sumsq) pairs of the group, then scale/shift
+// for its channels.
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ ws, int chunks, int c, int c_real,
                                                           int groups, long long rows_per_inst, float eps,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -103,13 +116,11 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
     __shared__ double rs[256], rq[256];
     const int g = blockIdx.x, inst = blockIdx.y, tid = threadIdx.x;
     const int cpg = c_real / groups;
-    const float* base = ws + (long long)inst * chunks * 2 * c;
+    const float* base = ws + (long long)inst * chunks * 2 * groups;
     double a = 0.0, b = 0.0;
-    const int items = chunks * cpg;
-    for (int it = tid; it < items; it += 256) {
-        const int k = it / cpg, ch = g * cpg + (it - k * cpg);
-        a += base[(long long)k * 2 * c + ch];
-        b += base[(long long)k * 2 * c + c + ch];
+    for (int k = tid; k < chunks; k += 256) {
+        a += base[(long long)k * 2 * groups + g];
+        b += base[(long long)k * 2 * groups + groups + g];
     }
     rs[tid] = a; rq[tid] = b;
     __syncthreads();
@@ -245,12 +256,13 @@ extern "C" int uav_groupnorm_scale_shift(const void* x1, const void* x2, int32_t
     if (c_real <= 0 || c_real > c || groups <= 0 || (c_real % groups) || n_inst <= 0 || rows_per_inst <= 0) return UAV_ESHAPE;
     if (n_inst > 65535) return UAV_ESHAPE;
     const int chunks = gn_chunks(n_inst, rows_per_inst, c);
-    if (workspace_bytes < (int64_t)n_inst * chunks * c * 2 * 4) return UAV_EINVAL;
+    if (workspace_bytes < (int64_t)n_inst * chunks * groups * 2 * 4) return UAV_EINVAL;
+    if (groups > 2048) return UAV_ESHAPE;
     GnSrc s{(const char*)x1, (const char*)x2, c1, c2};
     hipStream_t st = (hipStream_t)stream;
     const int var = gn_variant();
 #define GN_PARTIAL(F, UU) hipLaunchKernelGGL((gn_partial_kernel<F, UU>), dim3(chunks, n_inst), dim3(256), 0, st, s, \
-                                             (long long)rows_per_inst, chunks, (float*)workspace)
+                                             (long long)rows_per_inst, chunks, c_real, groups, (float*)workspace)
     if (x_f32) { if (var == 0) GN_PARTIAL(true, 8); else GN_PARTIAL(true, 4); }
     else if (var == 0) GN_PARTIAL(false, 8);
     else if (var == 3) GN_PARTIAL(false, 8);
