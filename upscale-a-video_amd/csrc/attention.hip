@@ -18,6 +18,8 @@
 // Roofline: MFMA-bound for L >= ~1k (4*L*d FLOP per query row); the text cross-attention
 // (Lk=77) is HBM-bound on reading Q / writing O.
 #include "uav_common.h"
+#include <stdlib.h>
+#include <utility>
 
 namespace {
 
@@ -366,7 +368,208 @@ __global__ __launch_bounds__(512, 2) void attn512_kernel(AttnArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// head_dim = 512, ONE WAVE PER SIMD (round 2).  The pair-split kernel above spends three barriers and a 32-KiB
+// partial-score exchange per 32-key tile because two waves share each query block.  Here a wave owns 32 queries and the
+// WHOLE head: 128 Q registers in the VGPR half and the 256 fp32 O^T accumulators in the ACCUMULATOR half of the unified
+// register file (a 256-thread workgroup at one wave per SIMD may use all 512) -> no exchange, no pair, and with the V^T
+// image double-buffered ONE barrier per tile.  4 waves = 128 queries per workgroup; per tile a wave issues 32 MFMAs for
+// S^T = K Q^T and 32 for O^T += V^T P^T, fed from the same K (DMA) / V^T (register-transposed) LDS images as before.
+// hipcc cannot allocate this itself (with the accumulators as C++ variables it shuffled them between the two halves:
+// 1306 v_accvgpr moves and 377 spilled registers in the loop), so O^T tile i lives in a[16i : 16i+15] BY NAME: the P.V
+// MFMAs, the (rare) online-softmax rescale and the final read-out are inline asm on those registers; every statement
+// lists the whole accumulator file as clobbered, which also makes the kernel descriptor allocate it, and the compiler
+// never touches AGPRs itself (checked in the .s: no v_accvgpr outside the asm blocks, no scratch).
+#define O5W_CLOBBERS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \
+    "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", \
+    "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", \
+    "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", \
+    "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", \
+    "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", \
+    "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", \
+    "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", \
+    "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", \
+    "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", \
+    "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", \
+    "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", \
+    "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", \
+    "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", \
+    "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", \
+    "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+
+template <int I> UAV_DEVINL void o5w_mfma(const half8_t& va, const half8_t& pb) {
+    // s_nop 1: the V^T fragment may have been packed by VALU moves right before (VALU write -> MFMA operand read)
+    asm volatile("s_nop 1\n v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(va), "v"(pb), "i"(16 * I), "i"(16 * I + 15) : O5W_CLOBBERS);
+}
+// S^T accumulation in VGPRs BY CONSTRAINT: left to itself hipcc put this chain into a[0:15] — on top of O^T tile 0.
+UAV_DEVINL void o5w_mfma_s0(float16_t& acc, const half8_t& a, const half8_t& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+}
+UAV_DEVINL void o5w_mfma_s(float16_t& acc, const half8_t& a, const half8_t& b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
+template <int N> UAV_DEVINL void o5w_zero1() { asm volatile("v_accvgpr_write_b32 a%c0, 0" :: "i"(N) : O5W_CLOBBERS); }
+template <int N> UAV_DEVINL void o5w_scale1(float f) {
+    float t;
+    asm volatile("v_accvgpr_read_b32 %0, a%c2\n s_nop 1\n v_mul_f32 %0, %0, %1\n s_nop 1\n v_accvgpr_write_b32 a%c2, %0"
+                 : "=&v"(t) : "v"(f), "i"(N) : O5W_CLOBBERS);
+}
+template <int N> UAV_DEVINL float o5w_read1() { float t; asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(t) : "i"(N)); return t; }
+template <int... N> UAV_DEVINL void o5w_zero_all(std::integer_sequence<int, N...>) { (o5w_zero1<N>(), ...); }
+template <int... N> UAV_DEVINL void o5w_scale_all(float f, std::integer_sequence<int, N...>) { (o5w_scale1<N>(f), ...); }
+template <int B, int... N> UAV_DEVINL void o5w_read16(float (&o)[16], std::integer_sequence<int, N...>) { ((o[N] = o5w_read1<B + N>()), ...); }
+
+constexpr int SMEM5W = 2 * K5_BYTES + 2 * V5_BYTES;      // 64 KiB K + 72 KiB V^T = 136 KiB
+
+template <int I> UAV_DEVINL void o5w_pv_tile(const char* vt, int l32, int hi, const half8_t (&pf)[2]) {
+    const char* vrow = vt + (I * 32 + l32) * VT_STRIDE + hi * 8;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        half4_t a = *(const half4_t*)(vrow + s2 * 32);
+        half4_t c = *(const half4_t*)(vrow + s2 * 32 + 16);
+        half8_t vf = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+        o5w_mfma<I>(vf, pf[s2]);
+    }
+}
+template <int... I> UAV_DEVINL void o5w_pv_all(const char* vt, int l32, int hi, const half8_t (&pf)[2], std::integer_sequence<int, I...>) {
+    (o5w_pv_tile<I>(vt, l32, hi, pf), ...);
+}
+template <int I> UAV_DEVINL void o5w_store_tile(char* optr, int hi, float inv) {
+    float o[16];
+    o5w_read16<16 * I>(o, std::make_integer_sequence<int, 16>{});
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        half4_t h = {(half_t)(o[4 * g] * inv), (half_t)(o[4 * g + 1] * inv), (half_t)(o[4 * g + 2] * inv), (half_t)(o[4 * g + 3] * inv)};
+        *(half4_t*)(optr + (I * 32 + 8 * g + 4 * hi) * 2) = h;
+    }
+}
+template <int... I> UAV_DEVINL void o5w_store_all(char* optr, int hi, float inv, std::integer_sequence<int, I...>) {
+    (o5w_store_tile<I>(optr, hi, inv), ...);
+}
+
+__global__ __launch_bounds__(256, 1) void attn512w_kernel(AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;
+    char* Vt = smem + 2 * K5_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int bk = b / p.q_per_kv;
+    const char* kbase = p.k + (long long)bk * p.lk * p.k_stride * 2;
+    const char* vbase = p.v + (long long)bk * p.lk * p.v_stride * 2;
+
+    const int qrow = q0 + l32;
+    const int qr = qrow < p.lq ? qrow : p.lq - 1;
+    const char* qptr = p.q + ((long long)b * p.lq + qr) * p.q_stride * 2;
+    half8_t qf[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) qf[s] = *(const half8_t*)(qptr + (16 * s + 8 * hi) * 2);
+
+    o5w_zero_all(std::make_integer_sequence<int, 256>{});
+    float m_run = -INFINITY, l_run = 0.f;
+    const int nt = (p.lk + KV - 1) / KV;
+
+    auto issue_k = [&](int stage, int t) {                  // one 1-KiB key row per wave-instruction, 8 rows per wave
+        char* dst = Ks + stage * K5_BYTES;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int row = ps * 4 + wave;
+            const int sl = lane ^ (row & 15);
+            const int key = t * KV + row;
+            const char* g = key < p.lk ? kbase + ((long long)key * p.k_stride + sl * 8) * 2 : p.zero_page;
+            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + (ps * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+    };
+    half8_t vst[2][4];                                      // two (4 keys x 8 dims) units per thread
+    auto load_v = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int unit = u * 256 + tid, kg = unit & 7, dv = unit >> 3;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int key = t * KV + kg * 4 + i;
+                half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+                vst[u][i] = key < p.lk ? *(const half8_t*)(vbase + ((long long)key * p.v_stride + dv * 8) * 2) : z;
+            }
+        }
+    };
+    auto store_v = [&](int buf) {
+        char* vt = Vt + buf * V5_BYTES;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int unit = u * 256 + tid, kg = unit & 7, dv = unit >> 3;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                half4_t w = {vst[u][0][e], vst[u][1][e], vst[u][2][e], vst[u][3][e]};
+                *(half4_t*)(vt + (dv * 8 + e) * VT_STRIDE + kg * 8) = w;
+            }
+        }
+    };
+
+    issue_k(0, 0);
+    load_v(0);
+    for (int t = 0; t < nt; ++t) {
+        store_v(t & 1);                                     // V^T buffer t&1 was last read two tiles ago
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                    // the only barrier of the tile
+        if (t + 1 < nt) { issue_k((t + 1) & 1, t + 1); load_v(t + 1); }
+
+        const char* kst = Ks + (t & 1) * K5_BYTES + l32 * 1024;
+        const int ksw = l32 & 15;
+        float16_t sacc;
+#pragma unroll
+        for (int s = 0; s < 32; ++s) {
+            half8_t kf = *(const half8_t*)(kst + (((2 * s + hi) ^ ksw) << 4));
+            if (s == 0) o5w_mfma_s0(sacc, kf, qf[0]); else o5w_mfma_s(sacc, kf, qf[s]);
+        }
+        asm volatile("s_nop 15" : "+v"(sacc));                // XDL write -> VALU read of the scores (hipcc cannot see the MFMAs)
+        const int key0 = t * KV + 4 * hi;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 8 * (r >> 2);
+            float sc = sacc[r] * p.scale_log2;
+            sc = key < p.lk ? sc : -INFINITY;
+            sacc[r] = sc; mx = fmaxf(mx, sc);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float ps = 0.f;
+        half8_t pf[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(sacc[r] - m_new);
+            ps += e;
+            pf[r >> 3][r & 7] = (half_t)e;
+        }
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+        if (!__all(alpha == 1.0f)) {                           // exact deferred rescale (see attn_kernel); rare after the first tiles
+            asm volatile("s_nop 15\ns_nop 15" ::: "memory");   // the previous tile's MFMAs must have written the accumulators
+            o5w_scale_all(alpha, std::make_integer_sequence<int, 256>{});
+            asm volatile("s_nop 3" ::: "memory");
+        }
+        o5w_pv_all(Vt + (t & 1) * V5_BYTES, l32, hi, pf, std::make_integer_sequence<int, 16>{});
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    asm volatile("s_nop 15\ns_nop 15" ::: "memory");           // last MFMAs -> accumulator reads
+    if (qrow < p.lq) {
+        char* optr = p.o + ((long long)b * p.lq + qrow) * p.o_stride * 2;
+        o5w_store_all(optr, hi, inv, std::make_integer_sequence<int, 16>{});
+    }
+}
+
 int launch_attn512(const AttnArgs& a, hipStream_t s) {
+    static const int variant = [] { const char* e = getenv("UAV_ATTN512"); return e ? atoi(e) : 0; }();
+    if (variant == 1) {
+        static UavDynLds ldsw;
+        if (int rc = uav_set_dyn_lds(ldsw, (const void*)attn512w_kernel, SMEM5W)) return rc;
+        hipLaunchKernelGGL(attn512w_kernel, dim3((a.lq + 127) / 128, 1, a.bq), dim3(256), SMEM5W, s, a);
+        return uav_launch_status();
+    }
     static UavDynLds lds;
     if (int rc = uav_set_dyn_lds(lds, (const void*)attn512_kernel, SMEM5)) return rc;
     dim3 grid((a.lq + 127) / 128, 1, a.bq);
