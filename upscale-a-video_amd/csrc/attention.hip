@@ -563,8 +563,11 @@ __global__ __launch_bounds__(256, 1) void attn512w_kernel(AttnArgs p) {
 }
 
 int launch_attn512(const AttnArgs& a, hipStream_t s) {
-    static const int variant = [] { const char* e = getenv("UAV_ATTN512"); return e ? atoi(e) : 0; }();
-    if (variant == 1) {
+    // one wave per SIMD (attn512w) pays once the grid fills the chip more than twice over: +9.6 % at L = 102 400, -5 % at
+    // L = 25 600 (200 workgroups on 256 CUs), profiles/r02_ab_attn512_one_wave_per_simd_run12.log; UAV_ATTN512=0|1 forces a kernel
+    static const int variant = [] { const char* e = getenv("UAV_ATTN512"); return e ? atoi(e) : -1; }();
+    const long long wgs = (long long)((a.lq + 127) / 128) * a.bq;
+    if (variant == 1 || (variant < 0 && wgs >= 512)) {
         static UavDynLds ldsw;
         if (int rc = uav_set_dyn_lds(ldsw, (const void*)attn512w_kernel, SMEM5W)) return rc;
         hipLaunchKernelGGL(attn512w_kernel, dim3((a.lq + 127) / 128, 1, a.bq), dim3(256), SMEM5W, s, a);
