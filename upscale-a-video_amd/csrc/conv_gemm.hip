@@ -1269,197 +1269,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256r_kernel(ConvArgs p) {
     conv_epilogue<4, 2>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);
 }
 
-// ---------------------------------------------------------------------------------------------
-// 256x256x64 kernel, PING-PONG wave groups (round 2, experiment UAV_CONV_DMAV=7).  Same tile, LDS image, DMA pieces,
-// accumulation order and epilogue as conv_gemm256i_kernel (bit-identical results).  The 8 waves are two groups of four
-// (waves w and w+4 share a SIMD); a k-step is two PHASES separated by workgroup barriers, and the groups run them half
-// a k-step apart:
-//     phase 2s   : group A  LOAD(s)  = 8 DMA pieces of stage s+1, all 24 fragments of stage s -> registers, address
-//                                      arithmetic of stage s+2, wait for its own DMA;        group B  MFMA(s-1)
-//     phase 2s+1 : group A  MFMA(s)  = 32 back-to-back MFMAs, nothing else in the stream;    group B  LOAD(s)
-// so each SIMD always has one wave in a pure matrix segment beside one in a pure memory segment (guide: T3/T5, "a rendezvous
-// structure pays when the merged interval is complementary").  A whole k-step of fragments (96 VGPRs) lives in registers
-// between a wave's LOAD and MFMA phases, which is why this kernel takes the incremental addressing of the removed V=5/6
-// experiment (8 instead of 16 row constants) and is not used for the folded nearest-2x upsample.
-// Hazards: a stage buffer is overwritten by the DMA of stage s+2 no earlier than phase 2s+2, after the last fragment read
-// of stage s (phase 2s+1, ends with lgkmcnt(0) before its barrier); stage s+1 is complete before its first read (phase
-// 2s+2): group A waited for its pieces at the end of phase 2s, group B at the end of phase 2s+1, each ahead of a barrier.
-__global__ __launch_bounds__(512, 2) void conv_gemm256p_kernel(ConvArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int grp = wave >> 2;
-    const int hi32 = lane >> 5, l32 = lane & 31;
-
-    const unsigned n_tiles = p.n_pad / LN;
-    const int slot_log = (tid & 7) ^ ((tid >> 4) & 7);
-    const int rbase = tid >> 3;
-    const int hw_o = p.ho * p.wo;
-
-    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
-    unsigned mt = tile / n_tiles;
-    const unsigned nt = tile - mt * n_tiles;
-    if (p.kt > 1 && p.tile_order) {
-        const unsigned hw_ = (unsigned)hw_o;
-        if (hw_ % LM == 0) {
-            const unsigned S_ = hw_ / LM, per_clip_ = S_ * (unsigned)p.t_len;
-            const unsigned c_ = mt / per_clip_, r_ = mt - c_ * per_clip_;
-            const unsigned sp_ = r_ / (unsigned)p.t_len, t_ = r_ - sp_ * (unsigned)p.t_len;
-            mt = c_ * per_clip_ + t_ * S_ + sp_;
-        }
-    }
-    const long long m0 = (long long)mt * LM;
-    const int n0 = nt * LN;
-    const int cin = p.c1 + p.c2;
-    const int ntaps = p.kt * p.kh * p.kw;
-    const int nk = p.k_pad / BK;
-    // per-row constants: tap-(0,0,0) source pixel (may be virtual) and the validity bit mask over the taps
-    int px0[4];
-    unsigned vmask[4] = {0u, 0u, 0u, 0u};
-    {
-        int rtl[4], rys[4], rxs[4];
-#pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            const long long m_ = m0 + ps * 64 + rbase;
-            const bool ok_ = m_ < p.M;
-            const int mm_ = ok_ ? (int)m_ : 0;
-            const int im_ = mm_ / hw_o; const int rem_ = mm_ - im_ * hw_o;
-            const int yo_ = rem_ / p.wo; const int xo_ = rem_ - yo_ * p.wo;
-            rtl[ps] = im_ % p.t_len - p.pad_t;
-            rys[ps] = ok_ ? yo_ * p.stride - p.pad_h : -(1 << 28); rxs[ps] = xo_ * p.stride - p.pad_w;
-            px0[ps] = ((im_ - p.pad_t) * p.hi + (ok_ ? rys[ps] : 0)) * p.wi + rxs[ps];
-        }
-        int tdt = 0, tdy = 0, tdx = 0;
-        for (int tap = 0; tap < ntaps; ++tap) {
-#pragma unroll
-            for (int ps = 0; ps < 4; ++ps) {
-                const bool ok = ((unsigned)(rtl[ps] + tdt) < (unsigned)p.t_len) & ((unsigned)(rys[ps] + tdy) < (unsigned)p.hi) &
-                                ((unsigned)(rxs[ps] + tdx) < (unsigned)p.wi);
-                vmask[ps] |= (ok ? 1u : 0u) << tap;
-            }
-            if (++tdx == p.kw) { tdx = 0; if (++tdy == p.kh) { tdy = 0; ++tdt; } }
-        }
-    }
-    const char* wtile = p.w + (long long)n0 * p.k_pad * 2;
-    const long long wps = 64ll * p.k_pad * 2;
-    const unsigned woff = (unsigned)(((long long)rbase * p.k_pad + slot_log * 8) * 2);
-    int kdt = 0, kdy = 0, kdx = 0, ktap = 0, kc = 0;
-    const char* gx0; const char* gx1; const char* gx2; const char* gx3;
-    long long wkb;
-
-#define XADDR_FAST(PS, G)                                                                                    \
-    {                                                                                                        \
-        const long long d = sdelta + ((long long)px0[PS] * xcs2 + slot16);                                   \
-        G = p.zero_page + (((vmask[PS] >> ktap) & 1u) ? d : 0ll);                                            \
-    }
-#define COMPUTE_ADDR()                                                                                       \
-    {                                                                                                        \
-        const bool first = kc < p.c1;                                                                        \
-        const char* xsrc = first ? p.a1 : p.a2;                                                              \
-        const int xcs = first ? p.c1 : p.c2;                                                                 \
-        const int xcs2 = xcs * 2;                                                                            \
-        const long long slot16 = slot_log * 16;                                                              \
-        const int tapd = (kdt * p.hi + kdy) * p.wi + kdx;                                                    \
-        const long long sdelta = (xsrc - p.zero_page) + ((long long)tapd * xcs + (first ? kc : kc - p.c1)) * 2; \
-        XADDR_FAST(0, gx0) XADDR_FAST(1, gx1) XADDR_FAST(2, gx2) XADDR_FAST(3, gx3)                          \
-        wkb = ((long long)ktap * cin + kc) * 2;                                                              \
-        if (p.korder) {                                                                                      \
-            ++ktap;                                                                                          \
-            if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } }                           \
-            if (ktap == ntaps) { ktap = 0; kdt = 0; kdy = 0; kdx = 0; kc += BK; }                            \
-        } else {                                                                                             \
-            kc += BK;                                                                                        \
-            if (kc >= cin) { kc = 0; ++ktap; if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } } } \
-        }                                                                                                    \
-    }
-
-    const int wn = wave & 1, wm = wave >> 1;
-    float16_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int sw = (l32 >> 1) & 7;
-    const unsigned ldsb = (unsigned)(size_t)(lptr_t)smem;
-    const unsigned bW = ldsb + (wn * 128 + l32) * 128, bX = ldsb + (wm * 64 + l32) * 128;
-    unsigned so[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) so[kk] = ((kk * 2 + hi32) ^ sw) << 4;
-    const unsigned ldsw = ldsb + wave * 1024;
-
-#define DX(I, OFF) "s_cbranch_vccz .Lpd%=_" #I "\n" "s_add_u32 m0, %[ldsn], " #OFF "\n" "s_nop 0\n" "global_load_lds_dwordx4 %[gx" #I "], off\n" ".Lpd%=_" #I ":\n"
-#define DW(I, OFF) "s_cbranch_vccz .Lpw%=_" #I "\n" "s_add_u32 m0, %[ldsn], " #OFF "\n" "s_nop 0\n" "global_load_lds_dwordx4 %[woff], %[gw" #I "]\n" ".Lpw%=_" #I ":\n"
-#define DMA8 DX(0, 0) DX(1, 8192) DX(2, 16384) DX(3, 24576) DW(0, 32768) DW(1, 40960) DW(2, 49152) DW(3, 57344)
-#define DMA_OPERANDS                                                                                         \
-    [gx0] "v"(gx0), [gx1] "v"(gx1), [gx2] "v"(gx2), [gx3] "v"(gx3), [woff] "v"(woff),                        \
-    [gw0] "s"(gw0), [gw1] "s"(gw1), [gw2] "s"(gw2), [gw3] "s"(gw3), [ldsn] "s"(ldsn), [dodma] "s"(dodma)
-#define RD(D, A, OFF) "ds_read_b128 %[" #D "], %[" #A "] offset:" #OFF "\n"
-#define MF(C, A, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #A "], %[" #B "], %[" #C "]\n"
-
-    // ---- prologue (all waves): stage 0 -> buffer 0, landed and visible; addresses of stage 1 ----
-    COMPUTE_ADDR()
-    {
-        const char* gw0 = wtile + wkb; const char* gw1 = gw0 + wps; const char* gw2 = gw1 + wps; const char* gw3 = gw2 + wps;
-        const unsigned ldsn = ldsw, dodma = __builtin_amdgcn_readfirstlane(1u);
-        unsigned m0s;
-        asm volatile("s_mov_b32 %[m0s], m0\n" "s_cmp_lg_u32 %[dodma], 0\n" "s_cselect_b64 vcc, -1, 0\n" DMA8 "s_mov_b32 m0, %[m0s]\n"
-                     : [m0s] "=&s"(m0s) : DMA_OPERANDS : "memory", "scc", "vcc");
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    half8_t w00, w01, w02, w03, w10, w11, w12, w13, w20, w21, w22, w23, w30, w31, w32, w33, x00, x01, x10, x11, x20, x21, x30, x31;
-    // Straight-line k-step per wave: LOAD(s); barrier; MFMA(s); barrier.  Group B enters one barrier late, so its LOAD
-    // runs beside group A's MFMA and vice versa; every wave executes 2*nk barriers (B: 1 + 2*nk - 1).
-    if (grp) __builtin_amdgcn_s_barrier();
-    for (int sidx = 0; sidx < nk; ++sidx) {
-        {
-            // addresses of stage sidx+1 (the DMA of this phase): transient, so that they are not live across the MFMA phase
-            if (sidx + 1 < nk) COMPUTE_ADDR()
-            const unsigned sb = (sidx & 1) * LSTAGE;
-            const unsigned bWs = bW + sb, bXs = bX + sb;
-            unsigned ta, tb;
-            const char* gw0 = wtile + wkb; const char* gw1 = gw0 + wps; const char* gw2 = gw1 + wps; const char* gw3 = gw2 + wps;
-            const unsigned ldsn = ldsw + ((sidx + 1) & 1) * LSTAGE;
-            const unsigned dodma = __builtin_amdgcn_readfirstlane(sidx + 1 < nk ? 1u : 0u);
-            unsigned m0s;
-            asm volatile("s_mov_b32 %[m0s], m0\n" "s_cmp_lg_u32 %[dodma], 0\n" "s_cselect_b64 vcc, -1, 0\n"
-                         DMA8
-                         "v_add_u32 %[ta], %[bWs], %[so0]\n" "v_add_u32 %[tb], %[bXs], %[so0]\n" RD(w00, ta, 32768) RD(w01, ta, 36864) RD(w02, ta, 40960) RD(w03, ta, 45056) RD(x00, tb, 0) RD(x01, tb, 4096) "v_add_u32 %[ta], %[bWs], %[so1]\n" "v_add_u32 %[tb], %[bXs], %[so1]\n" RD(w10, ta, 32768) RD(w11, ta, 36864) RD(w12, ta, 40960) RD(w13, ta, 45056) RD(x10, tb, 0) RD(x11, tb, 4096) "v_add_u32 %[ta], %[bWs], %[so2]\n" "v_add_u32 %[tb], %[bXs], %[so2]\n" RD(w20, ta, 32768) RD(w21, ta, 36864) RD(w22, ta, 40960) RD(w23, ta, 45056) RD(x20, tb, 0) RD(x21, tb, 4096) "v_add_u32 %[ta], %[bWs], %[so3]\n" "v_add_u32 %[tb], %[bXs], %[so3]\n" RD(w30, ta, 32768) RD(w31, ta, 36864) RD(w32, ta, 40960) RD(w33, ta, 45056) RD(x30, tb, 0) RD(x31, tb, 4096)
-                         "s_mov_b32 m0, %[m0s]\n"
-                         "s_waitcnt lgkmcnt(0)\n"
-                         : [w00] "=&v"(w00), [w01] "=&v"(w01), [w02] "=&v"(w02), [w03] "=&v"(w03), [w10] "=&v"(w10), [w11] "=&v"(w11), [w12] "=&v"(w12), [w13] "=&v"(w13), [w20] "=&v"(w20), [w21] "=&v"(w21), [w22] "=&v"(w22), [w23] "=&v"(w23), [w30] "=&v"(w30), [w31] "=&v"(w31), [w32] "=&v"(w32), [w33] "=&v"(w33), [x00] "=&v"(x00), [x01] "=&v"(x01), [x10] "=&v"(x10), [x11] "=&v"(x11), [x20] "=&v"(x20), [x21] "=&v"(x21), [x30] "=&v"(x30), [x31] "=&v"(x31), [m0s] "=&s"(m0s), [ta] "=&v"(ta), [tb] "=&v"(tb)
-                         : [bWs] "v"(bWs), [bXs] "v"(bXs), [so0] "v"(so[0]), [so1] "v"(so[1]), [so2] "v"(so[2]), [so3] "v"(so[3]),
-                           DMA_OPERANDS
-                         : "memory", "scc", "vcc");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
-        asm volatile("s_setprio 1\n"
-                     MF(c00, w00, x00) MF(c01, w00, x01) MF(c10, w01, x00) MF(c11, w01, x01) MF(c20, w02, x00) MF(c21, w02, x01) MF(c30, w03, x00) MF(c31, w03, x01) MF(c00, w10, x10) MF(c01, w10, x11) MF(c10, w11, x10) MF(c11, w11, x11) MF(c20, w12, x10) MF(c21, w12, x11) MF(c30, w13, x10) MF(c31, w13, x11) MF(c00, w20, x20) MF(c01, w20, x21) MF(c10, w21, x20) MF(c11, w21, x21) MF(c20, w22, x20) MF(c21, w22, x21) MF(c30, w23, x20) MF(c31, w23, x21) MF(c00, w30, x30) MF(c01, w30, x31) MF(c10, w31, x30) MF(c11, w31, x31) MF(c20, w32, x30) MF(c21, w32, x31) MF(c30, w33, x30) MF(c31, w33, x31)
-                     "s_setprio 0\n"
-                     : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]),
-                       [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]), [c30] "+v"(acc[3][0]), [c31] "+v"(acc[3][1])
-                     : [w00] "v"(w00), [w01] "v"(w01), [w02] "v"(w02), [w03] "v"(w03), [w10] "v"(w10), [w11] "v"(w11), [w12] "v"(w12), [w13] "v"(w13), [w20] "v"(w20), [w21] "v"(w21), [w22] "v"(w22), [w23] "v"(w23), [w30] "v"(w30), [w31] "v"(w31), [w32] "v"(w32), [w33] "v"(w33), [x00] "v"(x00), [x01] "v"(x01), [x10] "v"(x10), [x11] "v"(x11), [x20] "v"(x20), [x21] "v"(x21), [x30] "v"(x30), [x31] "v"(x31)
-                     : "memory");
-        if (!(grp && sidx == nk - 1)) __builtin_amdgcn_s_barrier();
-    }
-#undef RD
-#undef MF
-#undef DX
-#undef DW
-#undef DMA8
-#undef DMA_OPERANDS
-#undef XADDR_FAST
-#undef COMPUTE_ADDR
-    asm volatile("s_nop 15\ns_nop 15" ::: "memory");
-    conv_epilogue<4, 2>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);
-}
-
 
 }  // namespace
 
@@ -1532,7 +1341,6 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
                                  (const void*)conv_gemm256i_kernel<1>, (const void*)conv_gemm256i_kernel<2>,
                                  (const void*)conv_gemm256i_kernel<3>};
             for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
-            (void)hipFuncSetAttribute((const void*)conv_gemm256p_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
             (void)hipFuncSetAttribute((const void*)conv_gemm256r_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RSLOTS * RUNIT);
             hipDeviceProp_t prop;
             dev_ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
@@ -1546,9 +1354,6 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         else if (dbg == 3) hipLaunchKernelGGL(conv_gemm256_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 5) hipLaunchKernelGGL(conv_gemm256_kernel<5>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 6) hipLaunchKernelGGL(conv_gemm256_kernel<6>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
-        else if (env.dmav == 7 && !q->upsample && ntaps <= 32)
-            hipLaunchKernelGGL(conv_gemm256p_kernel, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
-        else if (env.dmav == 7) hipLaunchKernelGGL(conv_gemm256i_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (env.dmav == 4) hipLaunchKernelGGL(conv_gemm256r_kernel, dim3((unsigned)grid256), dim3(512), RSLOTS * RUNIT, s, a);
         else if (env.dmav == 1) hipLaunchKernelGGL(conv_gemm256i_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (env.dmav == 2) hipLaunchKernelGGL(conv_gemm256i_kernel<2>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
