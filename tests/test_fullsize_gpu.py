@@ -113,3 +113,39 @@ def test_groupnorm_full_size_statistics(ops, dev):
     xg = x.reshape(n_inst, rows_per, groups, c // groups)[:, :, :3].double()
     mu = xg.mean(dim=(1, 3), keepdim=True); sd = (xg.var(dim=(1, 3), unbiased=False, keepdim=True) + 1e-5).sqrt()
     assert rel_l2(yg[:, :, :3], ((xg - mu) / sd).float()) < 2e-3
+
+
+def test_full_model_forward_at_config2_size(dev):
+    """The released architecture at BASELINE configs[1]'s real shapes — UNetVideoModel on (2,4,8,320,320) + (2,3,8,320,320)
+    and the vae_3d decoder on a 3-frame 320x320 chunk -> 1280x1280 — where no CPU reference is affordable: the forward is
+    deterministic (bit-identical twice), the CFG-shared head equals the duplicated evaluation bit for bit, outputs are
+    finite, and the two guidance branches differ only through the text."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import synth
+    from uav import configs, init_weights
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from models_video.unet_video import UNetVideoModel
+    unet = UNetVideoModel.from_config(dict(configs.UNET_VIDEO)).half().to(dev).eval()
+    init_weights.random_init_(unet, seed=1234)
+    gd = torch.Generator(device=dev).manual_seed(5)
+    lat = torch.randn(1, 4, 8, 320, 320, generator=gd, device=dev).half().repeat(2, 1, 1, 1, 1)
+    low = torch.randn(1, 3, 8, 320, 320, generator=gd, device=dev).half().repeat(2, 1, 1, 1, 1)
+    ehs = torch.randn(2, 77, 1024, generator=gd, device=dev).half()
+    cl = torch.tensor([120])
+    with torch.no_grad():
+        a = unet(lat, 925, low, encoder_hidden_states=ehs, class_labels=cl).sample
+        b = unet(lat, 925, low, encoder_hidden_states=ehs, class_labels=cl).sample
+        c = unet(lat, 925, low, encoder_hidden_states=ehs, class_labels=cl, cfg_shared_input=True).sample
+    assert a.shape == (2, 4, 8, 320, 320) and bool(torch.isfinite(a).all())
+    assert torch.equal(a, b) and torch.equal(a, c)
+    assert not torch.equal(a[0], a[1])
+    del unet, a, b, c
+    vae = AutoencoderKLVideo.from_config(dict(configs.VAE_3D)).to(dev).eval()
+    init_weights.random_init_(vae, seed=4321)
+    z = torch.randn(1, 4, 3, 320, 320, generator=gd, device=dev)
+    with torch.no_grad():
+        y1 = vae.decode(z, None, 1.0, clamp=(-1.0, 1.0)).sample
+        y2 = vae.decode(z, None, 1.0, clamp=(-1.0, 1.0)).sample
+    assert y1.shape == (1, 3, 3, 1280, 1280) and y1.dtype == torch.float32
+    assert torch.equal(y1, y2) and bool(torch.isfinite(y1).all()) and float(y1.abs().max()) <= 1.0
