@@ -76,11 +76,45 @@ def _build_locked(objdir, verbose):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    audit_accumulator_file()
     with open(STAMP, "w") as fh:
         fh.write(_digest())
     if verbose:
         print(f"[uav] built {LIB} from {len(objs)} objects", file=sys.stderr)
     return LIB
+
+
+def audit_accumulator_file():
+    """attn512w_kernel keeps its 256 O^T accumulators in a[0:255] BY NAME from inline asm (csrc/attention.hip).  That is
+    only sound while hipcc itself never touches the accumulator file in that kernel (it would treat the registers as free
+    between our statements): compile the file to assembly and fail the build if any compiler-generated instruction of the
+    kernel names an AGPR."""
+    src = os.path.join(CSRC, "attention.hip")
+    r = subprocess.run([HIPCC] + FLAGS + ["-S", "--cuda-device-only", "-o", "-", src], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"hipcc -S failed on {src}:\n{r.stderr}")
+    lines = r.stdout.splitlines()
+    inside = in_asm = False
+    bad = []
+    for ln in lines:
+        if "attn512w_kernel" in ln and not ln[:1].isspace() and ln.split(";")[0].rstrip().endswith(":"):
+            inside = True
+            continue
+        if not inside:
+            continue
+        if "s_endpgm" in ln:
+            break
+        if "#ASMSTART" in ln:
+            in_asm = True
+        elif "#ASMEND" in ln:
+            in_asm = False
+        elif not in_asm and not ln.lstrip().startswith(";") and ("v_accvgpr" in ln or " a[" in ln or ",a[" in ln):
+            bad.append(ln.strip())
+    if not inside:
+        raise RuntimeError("audit: attn512w_kernel not found in the assembly of attention.hip")
+    if bad:
+        raise RuntimeError("audit: hipcc uses the accumulator file inside attn512w_kernel, which names a[0:255] from inline asm:\n  "
+                           + "\n  ".join(bad[:8]))
 
 
 if __name__ == "__main__":
