@@ -58,16 +58,17 @@ class KernelProfiler:
     def __init__(self):
         self.enabled = False
         self.detail = False        # key conv launches by shape (tools / UAV_BENCH_DETAIL)
+        self.only = None           # set of kernel families to time (None = all); each event pair costs ~3 us of GPU time
         self.records = []          # (kernel, flops, bytes, start_event, end_event)
 
-    def start(self):
-        self.enabled, self.records = True, []
+    def start(self, only=None):
+        self.enabled, self.records, self.only = True, [], (None if only is None else set(only))
 
     def stop(self):
         self.enabled = False
 
-    def begin(self):
-        if not self.enabled:
+    def begin(self, family=None):
+        if not self.enabled or (self.only is not None and family not in self.only):
             return None
         e = torch.cuda.Event(enable_timing=True)
         e.record()
@@ -232,7 +233,7 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
     p.pad_t = pt; p.pad_h = ph; p.pad_w = pw; p.upsample = 1 if upsample else 0
     p.n = wt.n; p.n_pad = wt.n_pad; p.k_pad = wt.k_pad
     p.out_scale = out_scale; p.flags = flags; p.zero_page = _p(zero_page(a1.device))
-    ev = PROFILER.begin()
+    ev = PROFILER.begin("conv_gemm")
     _lib.check(lib.uav_conv_gemm_f16(C.byref(p), _stream()), "uav_conv_gemm_f16")
     # algorithmic work: 2*M*N*K over the LOGICAL taps x input channels (no padding counted)
     PROFILER.end(ev, "conv_gemm" if not PROFILER.detail else
@@ -284,7 +285,7 @@ def groupnorm_scale_shift(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps
     shift = torch.empty_like(scale)
     ws_bytes = lib.uav_groupnorm_workspace_bytes(n_inst, c)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x1.device)
-    ev = PROFILER.begin()
+    ev = PROFILER.begin("groupnorm_stats")
     rc = lib.uav_groupnorm_scale_shift(_p(x1), _p(x2), xf32, c1, c2, c_real, n_inst, rows_per_inst, groups, eps,
                                        _p(gamma), _p(beta), _p(scale), _p(shift), _p(ws), ws_bytes, _stream())
     _lib.check(rc, "uav_groupnorm_scale_shift")
@@ -298,7 +299,7 @@ def groupnorm_apply(x1, scale, shift, *, n_inst, rows_per_inst, silu, x2=None):
     c1 = x1.shape[-1]
     c2 = 0 if x2 is None else x2.shape[-1]
     y = torch.empty((n_inst * rows_per_inst, c1 + c2), dtype=HALF, device=x1.device)
-    ev = PROFILER.begin()
+    ev = PROFILER.begin("groupnorm_apply")
     rc = lib.uav_groupnorm_apply(_p(x1), _p(x2), xf32, c1, c2, n_inst, rows_per_inst, _p(scale), _p(shift),
                                  1 if silu else 0, _p(y), _stream())
     _lib.check(rc, "uav_groupnorm_apply")
@@ -318,7 +319,7 @@ def layernorm(x, gamma, beta, eps=1e-5):
     _req(x, HALF, "x")
     y = torch.empty_like(x)
     rows, c = x.numel() // x.shape[-1], x.shape[-1]
-    ev = PROFILER.begin()
+    ev = PROFILER.begin("layernorm")
     _lib.check(lib.uav_layernorm_f16(_p(x), _p(y), _p(gamma), _p(beta), rows, c, eps, _stream()), "uav_layernorm_f16")
     PROFILER.end(ev, "layernorm", 0.0, 4.0 * rows * c)
     return y
@@ -337,7 +338,7 @@ def attention(q, k, v, *, bq, lq, lk, heads, head_dim, q_per_kv=1, scale=None,
     out = torch.empty((bq * lq, c), dtype=HALF, device=q.device)
     if scale is None:
         scale = head_dim ** -0.5
-    ev = PROFILER.begin()
+    ev = PROFILER.begin("attention")
     rc = lib.uav_attention_f16(_p(q), q_stride, _p(k), k_stride, _p(v), v_stride, _p(out), c, bq, lq, lk, q_per_kv,
                                heads, head_dim, scale, int(causal), _p(zero_page(q.device)), _stream())
     _lib.check(rc, "uav_attention_f16")
@@ -349,7 +350,7 @@ def temporal_attention(qkv, *, n_batch, t_len, hw, c, heads, scale, rope_cos, ro
     lib = _lib.load()
     _req(qkv, HALF, "qkv")
     out = torch.empty((n_batch * t_len * hw, c), dtype=HALF, device=qkv.device)
-    ev = PROFILER.begin()
+    ev = PROFILER.begin("temporal_attention")
     rc = lib.uav_temporal_attention_f16(_p(qkv), _p(out), n_batch, t_len, hw, c, heads, scale, _p(rope_cos),
                                         _p(rope_sin), rot_dim, _p(bias), _stream())
     _lib.check(rc, "uav_temporal_attention_f16")
@@ -538,7 +539,7 @@ def conv_gemm_f32(a1, wt: ConvW, *, n_img, hi, wi, stride=1, pad=None, a2=None, 
     p.n = wt.n; p.n_pad = wt.n_pad; p.k_pad = wt.k_pad; p.out_scale = out_scale
     p.flags = {0: 0, 1: _lib.CONV_RELU, 2: _lib.CONV_SIGMOID, 4: _lib.CONV_TANH}[act]
     p.zero_page = _p(zero_page(a1.device))
-    ev = PROFILER.begin()
+    ev = PROFILER.begin("conv_gemm_f32")
     _lib.check(lib.uav_conv_gemm_f32(C.byref(p), _stream()), "uav_conv_gemm_f32")
     PROFILER.end(ev, "conv_gemm_f32", 2.0 * m * wt.n * wt.kh * wt.kw * wt.cin, 4.0 * (n_img * hi * wi * wt.cin + m * wt.n))
     return out
