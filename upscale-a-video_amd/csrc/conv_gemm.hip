@@ -1049,227 +1049,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
     conv_epilogue<4, 2>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);
 }
 
-// ---------------------------------------------------------------------------------------------
-// 256x256x64 kernel on a RING of five 32-KiB LDS units (all 160 KiB of the CU), counted vmcnt.  Same tile, fragment
-// reads, accumulation order and epilogue as the kernels above (bit-identical results); what changes is the depth of the
-// DMA pipeline.  A "unit" is one operand tile of one k-step: unit 2s = X tile of stage s, unit 2s+1 = W tile of stage s,
-// unit u lives in slot u % 5.  The two-stage loop had to land a whole 64-KiB stage inside one k-step and drained the
-// DMA queue to zero at every barrier; here, during k-step ks the workgroup computes on units 2ks, 2ks+1 and issues
-// W(ks+1) and X(ks+2) into the two slots the previous step just released, so the X gather (the operand with the
-// scattered, per-pixel addresses) has TWO k-steps to land and the wait at the top of a k-step is `vmcnt(4)`: one unit
-// (4 DMA instructions per wave) stays in flight across every barrier — the queue never drains (guide: counted vmcnt,
-// T3+T4).
-constexpr int RUNIT = 32768;
-constexpr int RSLOTS = 5;
-
-__global__ __launch_bounds__(512, 2) void conv_gemm256r_kernel(ConvArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hi32 = lane >> 5, l32 = lane & 31;
-
-    const unsigned n_tiles = p.n_pad / LN;
-    const int slot_log = (tid & 7) ^ ((tid >> 4) & 7);
-    const int rbase = tid >> 3;
-    const int hw_o = p.ho * p.wo;
-    const int ups = p.upsample ? 1 : 0;
-    const int ylim = p.upsample ? p.ho : p.hi, xlim = p.upsample ? p.wo : p.wi;
-
-    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
-    unsigned mt = tile / n_tiles;
-    const unsigned nt = tile - mt * n_tiles;
-    if (p.kt > 1 && p.tile_order) {
-        const unsigned hw_ = (unsigned)hw_o;
-        if (hw_ % LM == 0) {
-            const unsigned S_ = hw_ / LM, per_clip_ = S_ * (unsigned)p.t_len;
-            const unsigned c_ = mt / per_clip_, r_ = mt - c_ * per_clip_;
-            const unsigned sp_ = r_ / (unsigned)p.t_len, t_ = r_ - sp_ * (unsigned)p.t_len;
-            mt = c_ * per_clip_ + t_ * S_ + sp_;
-        }
-    }
-    const long long m0 = (long long)mt * LM;
-    const int n0 = nt * LN;
-    int rimg[4], rtl[4], rys[4], rxs[4];
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const long long m_ = m0 + ps * 64 + rbase;
-        const bool ok_ = m_ < p.M;
-        const int mm_ = ok_ ? (int)m_ : 0;
-        const int im_ = mm_ / hw_o; const int rem_ = mm_ - im_ * hw_o;
-        const int yo_ = rem_ / p.wo; const int xo_ = rem_ - yo_ * p.wo;
-        rimg[ps] = im_ - p.pad_t; rtl[ps] = im_ % p.t_len - p.pad_t;
-        rys[ps] = ok_ ? yo_ * p.stride - p.pad_h : -(1 << 28); rxs[ps] = xo_ * p.stride - p.pad_w;
-    }
-    const int cin = p.c1 + p.c2;
-    const int ntaps = p.kt * p.kh * p.kw;
-    const int nk = p.k_pad / BK;
-    const char* wtile = p.w + (long long)n0 * p.k_pad * 2;
-    const long long wps = 64ll * p.k_pad * 2;
-    const unsigned woff = (unsigned)(((long long)rbase * p.k_pad + slot_log * 8) * 2);
-    int kdt = 0, kdy = 0, kdx = 0, ktap = 0, kc = 0;     // k-state of the NEXT stage to address (the X iterator)
-    const char* gx0; const char* gx1; const char* gx2; const char* gx3;
-    long long wkb_x = 0, wkb_w = 0;                      // K byte offset of the stage gx* addresses / of the next W unit
-
-#define XADDR(PS, G)                                                                                         \
-    {                                                                                                        \
-        const int tt = rtl[PS] + kdt, yv = rys[PS] + kdy, xv = rxs[PS] + kdx;                                \
-        const bool ok = ((unsigned)tt < (unsigned)p.t_len) & ((unsigned)yv < (unsigned)ylim) &               \
-                        ((unsigned)xv < (unsigned)xlim);                                                     \
-        const int px = ((rimg[PS] + kdt) * p.hi + (yv >> ups)) * p.wi + (xv >> ups);                         \
-        const long long d = (xsrc - p.zero_page) + ((long long)px * xcs + xcoff) * 2;                        \
-        G = p.zero_page + (ok ? d : 0ll);                                                                    \
-    }
-#define COMPUTE_ADDR()                                                                                       \
-    {                                                                                                        \
-        const bool first = kc < p.c1;                                                                        \
-        const char* xsrc = first ? p.a1 : p.a2;                                                              \
-        const int xcs = first ? p.c1 : p.c2;                                                                 \
-        const int xcoff = (first ? kc : kc - p.c1) + slot_log * 8;                                           \
-        XADDR(0, gx0) XADDR(1, gx1) XADDR(2, gx2) XADDR(3, gx3)                                              \
-        wkb_x = ((long long)ktap * cin + kc) * 2;                                                            \
-        if (p.korder) {                                                                                      \
-            ++ktap;                                                                                          \
-            if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } }                           \
-            if (ktap == ntaps) { ktap = 0; kdt = 0; kdy = 0; kdx = 0; kc += BK; }                            \
-        } else {                                                                                             \
-            kc += BK;                                                                                        \
-            if (kc >= cin) { kc = 0; ++ktap; if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } } } \
-        }                                                                                                    \
-    }
-
-    const int wn = wave & 1, wm = wave >> 1;
-    float16_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int sw = (l32 >> 1) & 7;
-    const unsigned ldsb = (unsigned)(size_t)(lptr_t)smem;
-    const unsigned bW = ldsb + (wn * 128 + l32) * 128, bX = ldsb + (wm * 64 + l32) * 128;   // + slot * RUNIT
-    unsigned so[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) so[kk] = ((kk * 2 + hi32) ^ sw) << 4;
-    const unsigned ldsw = ldsb + wave * 1024;
-
-    // a DMA piece is skipped when its unit does not exist (tail of the K loop): s_cmp on the unit's flag + branch
-#define DX(I, OFF) "s_cmp_lg_u32 %[dox], 0\n" "s_cbranch_scc0 .Lrx%=_" #I "\n" "s_add_u32 m0, %[ldsx], " #OFF "\n" "s_nop 0\n" "global_load_lds_dwordx4 %[gx" #I "], off\n" ".Lrx%=_" #I ":\n"
-#define DW(I, OFF) "s_cmp_lg_u32 %[dow], 0\n" "s_cbranch_scc0 .Lrw%=_" #I "\n" "s_add_u32 m0, %[ldsn], " #OFF "\n" "s_nop 0\n" "global_load_lds_dwordx4 %[woff], %[gw" #I "]\n" ".Lrw%=_" #I ":\n"
-#define X0 DX(0, 0)
-#define X1 DX(1, 8192)
-#define X2 DX(2, 16384)
-#define X3 DX(3, 24576)
-#define W0 DW(0, 0)
-#define W1 DW(1, 8192)
-#define W2 DW(2, 16384)
-#define W3 DW(3, 24576)
-#define NO ""
-#define DMA_OPERANDS                                                                                         \
-    [gx0] "v"(gx0), [gx1] "v"(gx1), [gx2] "v"(gx2), [gx3] "v"(gx3), [woff] "v"(woff),                        \
-    [gw0] "s"(gw0), [gw1] "s"(gw1), [gw2] "s"(gw2), [gw3] "s"(gw3), [ldsn] "s"(ldsn), [ldsx] "s"(ldsx),      \
-    [dow] "s"(dow), [dox] "s"(dox)
-
-    // ---- prologue: units 0 (X0 -> slot 0), 1 (W0 -> slot 1), 2 (X1 -> slot 2); addresses of X2 ----
-    COMPUTE_ADDR()
-    {
-        const char* gw0 = wtile + wkb_x; const char* gw1 = gw0 + wps; const char* gw2 = gw1 + wps; const char* gw3 = gw2 + wps;
-        const unsigned ldsx = ldsw, ldsn = ldsw + RUNIT;
-        const unsigned dow = __builtin_amdgcn_readfirstlane(1u), dox = dow;
-        unsigned m0s;
-        asm volatile("s_mov_b32 %[m0s], m0\n" X0 X1 X2 X3 W0 W1 W2 W3 "s_mov_b32 m0, %[m0s]\n"
-                     : [m0s] "=&s"(m0s) : DMA_OPERANDS : "memory", "scc");
-    }
-    if (nk > 1) {
-        COMPUTE_ADDR()
-        wkb_w = wkb_x;                                   // K offset of W(1), issued during k-step 0
-        const char* gw0 = wtile; const char* gw1 = gw0; const char* gw2 = gw0; const char* gw3 = gw0;
-        const unsigned ldsx = ldsw + 2 * RUNIT, ldsn = ldsw;
-        const unsigned dow = __builtin_amdgcn_readfirstlane(0u), dox = __builtin_amdgcn_readfirstlane(1u);
-        unsigned m0s;
-        asm volatile("s_mov_b32 %[m0s], m0\n" X0 X1 X2 X3 "s_mov_b32 m0, %[m0s]\n"
-                     : [m0s] "=&s"(m0s) : DMA_OPERANDS : "memory", "scc");
-        if (nk > 2) COMPUTE_ADDR()
-    }
-
-#define RD(D, A, OFF) "ds_read_b128 %[" #D "], %[" #A "] offset:" #OFF "\n"
-#define RDSET(S, A, AX) RD(w##S##0, A, 0) RD(x##S##0, AX, 0) RD(x##S##1, AX, 4096) RD(w##S##1, A, 4096) RD(w##S##2, A, 8192) RD(w##S##3, A, 12288)
-#define MF(C, A, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #A "], %[" #B "], %[" #C "]\n"
-#define WT(N) "s_waitcnt lgkmcnt(" #N ")\n"
-#define MFSETD(S, N0, N1, N2, N3, N4, SA, SB, SC, SD)                                          \
-    WT(N0) MF(c00, w##S##0, x##S##0) WT(N1) MF(c01, w##S##0, x##S##1) SA                       \
-    WT(N2) MF(c10, w##S##1, x##S##0) MF(c11, w##S##1, x##S##1) SB                              \
-    WT(N3) MF(c20, w##S##2, x##S##0) MF(c21, w##S##2, x##S##1) SC                              \
-    WT(N4) MF(c30, w##S##3, x##S##0) MF(c31, w##S##3, x##S##1) SD
-#define KSTEP(PRE, A0, A1, A2, A3, B0, B1, B2, B3, C0, C1, C2, C3, E0, E1, E2, E3)             \
-    "s_waitcnt lgkmcnt(0)\n" RDSET(0, aw0, ax0) RDSET(1, aw1, ax1) PRE                         \
-    MFSETD(0, 10, 9, 8, 7, 6, A0, A1, A2, A3) RDSET(0, aw2, ax2)                               \
-    MFSETD(1, 10, 9, 8, 7, 6, B0, B1, B2, B3) RDSET(1, aw3, ax3)                               \
-    MFSETD(0, 10, 9, 8, 7, 6, C0, C1, C2, C3) MFSETD(1, 4, 3, 2, 1, 0, E0, E1, E2, E3)
-#define ACC_OPERANDS                                                                                             \
-    [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]),                  \
-    [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]), [c30] "+v"(acc[3][0]), [c31] "+v"(acc[3][1]),                  \
-    [w00] "=&v"(w00), [w01] "=&v"(w01), [w02] "=&v"(w02), [w03] "=&v"(w03), [x00] "=&v"(x00), [x01] "=&v"(x01),  \
-    [w10] "=&v"(w10), [w11] "=&v"(w11), [w12] "=&v"(w12), [w13] "=&v"(w13), [x10] "=&v"(x10), [x11] "=&v"(x11)
-#define RD_OPERANDS                                                                                              \
-    [aw0] "v"(aw0), [aw1] "v"(aw1), [aw2] "v"(aw2), [aw3] "v"(aw3), [ax0] "v"(ax0), [ax1] "v"(ax1), [ax2] "v"(ax2), [ax3] "v"(ax3)
-
-    int sx = 0;                                          // slot of X(ks); W(ks) sits in slot sx + 1 (mod 5)
-    for (int ks = 0; ks < nk; ++ks) {
-        // units 2ks and 2ks+1 must have landed; X(ks+1) (issued one k-step earlier, right before them in the queue? no:
-        // AFTER them) may stay in flight: queue order is ..., X(ks), W(ks) | X(ks+1) -> at most 4 younger DMAs.
-        if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const int swl = sx + 1 >= RSLOTS ? sx + 1 - RSLOTS : sx + 1;
-        const unsigned bxs = bX + sx * RUNIT, bws = bW + swl * RUNIT;
-        const unsigned aw0 = bws + so[0], aw1 = bws + so[1], aw2 = bws + so[2], aw3 = bws + so[3];
-        const unsigned ax0 = bxs + so[0], ax1 = bxs + so[1], ax2 = bxs + so[2], ax3 = bxs + so[3];
-        half8_t w00, w01, w02, w03, x00, x01, w10, w11, w12, w13, x10, x11;
-        const char* gw0 = wtile + wkb_w; const char* gw1 = gw0 + wps; const char* gw2 = gw1 + wps; const char* gw3 = gw2 + wps;
-        // W(ks+1) -> slot of X(ks-1) = sx + 3, X(ks+2) -> slot of W(ks-1) = sx + 4 (mod 5): both released by this barrier
-        const int s3 = sx + 3 >= RSLOTS ? sx + 3 - RSLOTS : sx + 3, s4 = sx + 4 >= RSLOTS ? sx + 4 - RSLOTS : sx + 4;
-        const unsigned ldsn = ldsw + s3 * RUNIT, ldsx = ldsw + s4 * RUNIT;
-        const unsigned dow = __builtin_amdgcn_readfirstlane(ks + 1 < nk ? 1u : 0u);
-        const unsigned dox = __builtin_amdgcn_readfirstlane(ks + 2 < nk ? 1u : 0u);
-        unsigned m0s;
-        asm volatile("s_mov_b32 %[m0s], m0\n"
-                     KSTEP(W0 W1, W2, W3, X0, X1, X2, X3, NO, NO, NO, NO, NO, NO, NO, NO, NO, NO)
-                     "s_mov_b32 m0, %[m0s]\n"
-                     : ACC_OPERANDS, [m0s] "=&s"(m0s) : RD_OPERANDS, DMA_OPERANDS : "memory", "scc");
-        wkb_w = wkb_x;                                   // the stage gx* was addressed for is the next W unit
-        if (ks + 3 < nk) COMPUTE_ADDR()                  // X(ks+3), issued during k-step ks+1
-        sx = sx + 2 >= RSLOTS ? sx + 2 - RSLOTS : sx + 2;
-    }
-#undef RD
-#undef RDSET
-#undef MF
-#undef WT
-#undef MFSETD
-#undef KSTEP
-#undef ACC_OPERANDS
-#undef RD_OPERANDS
-#undef DMA_OPERANDS
-#undef DX
-#undef DW
-#undef X0
-#undef X1
-#undef X2
-#undef X3
-#undef W0
-#undef W1
-#undef W2
-#undef W3
-#undef NO
-#undef XADDR
-#undef COMPUTE_ADDR
-    asm volatile("s_nop 15\ns_nop 15" ::: "memory");
-    conv_epilogue<4, 2>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);
-}
-
-
 }  // namespace
 
 extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
@@ -1341,7 +1120,6 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
                                  (const void*)conv_gemm256i_kernel<1>, (const void*)conv_gemm256i_kernel<2>,
                                  (const void*)conv_gemm256i_kernel<3>};
             for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
-            (void)hipFuncSetAttribute((const void*)conv_gemm256r_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, RSLOTS * RUNIT);
             hipDeviceProp_t prop;
             dev_ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
         });
@@ -1354,7 +1132,6 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         else if (dbg == 3) hipLaunchKernelGGL(conv_gemm256_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 5) hipLaunchKernelGGL(conv_gemm256_kernel<5>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 6) hipLaunchKernelGGL(conv_gemm256_kernel<6>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
-        else if (env.dmav == 4) hipLaunchKernelGGL(conv_gemm256r_kernel, dim3((unsigned)grid256), dim3(512), RSLOTS * RUNIT, s, a);
         else if (env.dmav == 1) hipLaunchKernelGGL(conv_gemm256i_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (env.dmav == 2) hipLaunchKernelGGL(conv_gemm256i_kernel<2>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (env.dmav == 3) hipLaunchKernelGGL(conv_gemm256i_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
