@@ -375,7 +375,7 @@ def main():
                                "kernel_time_share": share}
             # per kernel: MFMA-bound ones against the dense fp16 peak, HBM-bound ones (algorithmic bytes: every operand
             # read / written once) against the 8 TB/s HBM3E peak
-            hbm_bound = ("groupnorm_stats", "groupnorm_apply", "layernorm", "temporal_attention", "attention_d64")
+            hbm_bound = ("groupnorm_stats", "groupnorm_finalize_fused", "groupnorm_apply", "layernorm", "temporal_attention", "attention_d64")
             res["kernel_breakdown"] = {k: {"launches": v["launches"], "ms": round(v["seconds"] * 1e3, 2),
                                            "tflops": round(v["flops"] / v["seconds"] / 1e12, 1) if v["flops"] else None,
                                            "GBps": round(v["bytes"] / v["seconds"] / 1e9, 1),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UAV_ABI_VERSION 2
+#define UAV_ABI_VERSION 3
 
 #define UAV_EINVAL   (-1)   /* bad argument (null pointer, size not supported) */
 #define UAV_EALIGN   (-2)   /* pointer / stride alignment requirement violated */
@@ -85,9 +85,21 @@ typedef struct {
     float        out_scale;
     uint32_t     flags;
     const void*  zero_page;     /* >=256 B of device zeros (padding source for the DMA gather) */
+    /* Fused GroupNorm statistics for the CONSUMER of `out` (resnet.py:267-284: conv -> GroupNorm -> SiLU -> conv): with
+     * gn_partials != NULL the epilogue also writes, for every block of `rows` = uav_conv_gemm_gn_chunk_rows() output rows
+     * (chunk = m / rows) and every group g of n / gn_groups channels, the fp32 sum and sum of squares of the values it
+     * stores: gn_partials[(which*gn_groups + g) * (M/rows) + chunk], which = 0 sum, 1 sum of squares (2*gn_groups*M/rows
+     * floats, every element written).  uav_groupnorm_finalize_partials turns them into scale/shift tables, which saves
+     * the statistics pass over `out`.  NULL / 0: off (uav_conv_gemm_f32 ignores both). */
+    void*        gn_partials;
+    int32_t      gn_groups;
 } uav_conv_params;
 
 int uav_conv_gemm_f16(const uav_conv_params* p, void* stream);
+/* Rows per statistics chunk (64) if uav_conv_gemm_f16(p) can produce GroupNorm partials for p->gn_groups, else 0 (small
+ * launches, N tails, GEGLU / activation epilogues, groups of other than 4..128 channels): decide BEFORE setting
+ * gn_partials — a launch that cannot honour the request returns UAV_ESHAPE.  Host-only, no device work. */
+int uav_conv_gemm_gn_chunk_rows(const uav_conv_params* p);
 
 /* ---- K3: GroupNorm statistics + apply (+SiLU) ---------------------------------------
  * Replaces nn.GroupNorm on 5-D tensors (statistics over C/G x T x H x W: resnet.py:267,278,
@@ -107,6 +119,12 @@ int uav_groupnorm_scale_shift(const void* x1, const void* x2,
                               const float* gamma, const float* beta,
                               float* scale_out, float* shift_out,
                               void* workspace, int64_t workspace_bytes, void* stream);
+/* scale/shift tables from the partials a conv epilogue wrote (uav_conv_params.gn_partials): `partials` is
+ * [2][groups][chunks_total] fp32, an instance owns rows_per_inst / chunk_rows consecutive chunks
+ * (rows_per_inst % chunk_rows == 0, n_inst * rows_per_inst / chunk_rows == chunks_total). */
+int uav_groupnorm_finalize_partials(const float* partials, int64_t chunks_total, int32_t chunk_rows, int32_t c,
+                                    int32_t n_inst, int64_t rows_per_inst, int32_t groups, float eps,
+                                    const float* gamma, const float* beta, float* scale_out, float* shift_out, void* stream);
 int uav_groupnorm_apply(const void* x1, const void* x2, int32_t x_f32, int32_t c1, int32_t c2,
                         int32_t n_inst, int64_t rows_per_inst,
                         const float* scale, const float* shift, int32_t silu,

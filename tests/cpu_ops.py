@@ -23,7 +23,7 @@ def _h(x):
 
 # ---------------------------------------------------------------------------------------------------------------------
 def conv_gemm(a1, wt, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None, rowbias=None, rows_per_batch=0,
-              residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None, persistent=False, act=None):
+              residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None, persistent=False, act=None, gn_groups=None):
     c1 = a1.shape[-1]
     c2 = 0 if a2 is None else a2.shape[-1]
     assert c1 + c2 == wt.cin_p, (c1, c2, wt.cin_p)
@@ -80,7 +80,7 @@ def _factor_rows(m):
     return 1, m
 
 
-def linear(x, wt, *, residual=None, out_scale=1.0, rowbias=None, rows_per_batch=0, out_f32=False, act=None):
+def linear(x, wt, *, residual=None, out_scale=1.0, rowbias=None, rows_per_batch=0, out_f32=False, act=None, gn_groups=None):
     return conv_gemm(x, wt, n_img=1, t_len=1, hi=x.shape[0], wi=1, residual=residual, out_scale=out_scale, rowbias=rowbias,
                      rows_per_batch=rows_per_batch, out_f32=out_f32, act=act)
 

@@ -203,7 +203,7 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/uav_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.uav_version() == 2
+    assert lib.uav_version() == 3
 
 
 # ---------------------------------------------------------------------------------------------
@@ -362,6 +362,27 @@ def test_cabi_rejects_bad_arguments_without_touching_the_gpu():
     assert conv(rowbias=P, rows_per_batch=0) == ESHAPE
     assert conv(flags=128) == EINVAL              # fp32-residual flag without a residual
     assert lib.uav_conv_gemm_f16(None, None) == EINVAL
+    # fused GroupNorm statistics: offered only where every wave of the 256x256 kernel takes a fast epilogue
+    big = dict(n_img=16, hi=64, wi=64, ho=64, wo=64, n=512, n_pad=512, out_stride=512, gn_groups=32)
+
+    def gn_rows(**kw):
+        return lib.uav_conv_gemm_gn_chunk_rows(C.byref(_lib.ConvParams(**{**base, **big, **kw})))
+    assert gn_rows() == 64
+    assert gn_rows(residual=P, res_stride=512, rowbias=P, rows_per_batch=4096, rowbias_stride=512) == 64
+    assert gn_rows(flags=2, bias=P) == 64 and gn_rows(flags=2) == 0                 # fp32 out needs the bias fast path
+    assert gn_rows(flags=2, bias=P, residual=P, res_stride=512) == 0                # fp32 out + fp16 residual: generic path
+    assert gn_rows(flags=2 | 128, bias=P, residual=P, res_stride=512) == 64
+    assert gn_rows(n=128, n_pad=256, out_stride=128) == 64 and gn_rows(n=64, n_pad=256, out_stride=64, gn_groups=16) == 0
+    assert gn_rows(n_img=1, hi=8, wi=8, ho=8, wo=8) == 0                            # small grid: 128x128 kernel
+    assert gn_rows(n_img=15, hi=63, ho=63, wi=63, wo=63) == 0                       # M % 64
+    assert gn_rows(gn_groups=0) == 0 and gn_rows(gn_groups=48) == 0 and gn_rows(gn_groups=2) == 0    # 256 ch / group
+    assert gn_rows(n=1536, n_pad=1536, out_stride=1536) == 0                        # 48 channels per group
+    assert gn_rows(rowbias=P, rows_per_batch=100, rowbias_stride=512) == 0          # a wave tile would straddle batches
+    assert gn_rows(flags=1, n=1024, n_pad=1024) == 0                                # GEGLU
+    assert conv(**{**big, 'gn_partials': P, 'gn_groups': 48}) == ESHAPE                       # request that cannot be honoured
+    assert lib.uav_groupnorm_finalize_partials(None, 8, 64, 64, 1, 512, 32, 1e-5, None, None, P, P, None) == EINVAL
+    assert lib.uav_groupnorm_finalize_partials(P, 8, 64, 64, 1, 500, 32, 1e-5, None, None, P, P, None) == ESHAPE   # rows % 64
+    assert lib.uav_groupnorm_finalize_partials(P, 9, 64, 64, 1, 512, 32, 1e-5, None, None, P, P, None) == ESHAPE   # chunk count
     assert lib.uav_cast_f32_f16(None, P, 8, None) == EINVAL and lib.uav_sft_fuse(P, P, None, P, 8, 1.0, 0, 0, None) == EINVAL
     # GroupNorm
     assert lib.uav_groupnorm_scale_shift(None, None, 0, 64, 0, 64, 1, 16, 32, 1e-5, None, None, P, P, P, 1 << 20, None) == EINVAL

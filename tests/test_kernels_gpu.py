@@ -420,3 +420,75 @@ def test_resize_area_and_propagation_flow_resize(ops, dev):
     a = prop(xl.half().to(dev), ff.to(dev), fb.to(dev), interpolation="nearest", mode="fuse", fuse_scale=0.5, alpha1=0.001, alpha2=0.05)
     b = prop(xl.half().to(dev), up(ff).to(dev), up(fb).to(dev), interpolation="nearest", mode="fuse", fuse_scale=0.5, alpha1=0.001, alpha2=0.05)
     assert ((a.float() - b.float()).abs() > 1e-2).float().mean().item() < 5e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# GroupNorm statistics fused into the producing conv's epilogue (uav_conv_params.gn_partials)
+@pytest.mark.parametrize("cout,f32,res,temb,k3", [
+    (256, False, True, True, (1, 3, 3)),       # 8 channels per group: both half-waves of a quad pair
+    (256, True, True, False, (1, 1, 1)),
+    (512, False, True, True, (1, 1, 1)),       # 16
+    (512, True, False, False, (1, 3, 3)),
+    (1024, False, False, True, (3, 1, 1)),     # 32: one column tile per group
+    (2048, False, True, False, (1, 1, 1)),     # 64: two column tiles per group
+])
+def test_conv_fused_groupnorm_statistics(ops, dev, cout, f32, res, temb, k3):
+    """The partials a conv epilogue writes must (a) leave the conv output bit-identical, (b) equal the per-chunk sums of
+    the stored values (tolerance 2e-3 relative to the chunk's L1 / L2 mass: they are taken before the fp16 rounding of
+    the output), (c) give the same scale/shift tables as the stand-alone statistics pass to 1e-3, and (d) be picked up by
+    ops.groupnorm through the tensor the conv returned."""
+    g = torch.Generator().manual_seed(cout + 7 * k3[0])
+    bsz, t_len, h, w, cin, groups = 2, 2, 64, 64, 64, 32         # enough 256x256 tiles (>= 224) for the big kernel at every width:
+    if cout < 1024:
+        h, w = (128, 128) if cout == 256 else (128, 64)           # M/256 x cout/256 = 256 tiles
+    M = bsz * t_len * h * w
+    x = (torch.randn(M, cin, generator=g)).half().to(dev)
+    wt = h16(cout, cin, *k3, dev=dev, scale=(cin * k3[0] * k3[1] * k3[2]) ** -0.5, gen=g)
+    bias = torch.randn(cout, generator=g).to(dev)
+    cw = ops.pack_conv(wt, bias, device=dev)
+    rr = None
+    if res:
+        rr = torch.randn(M, cout, generator=g).to(dev)
+        rr = rr if f32 else rr.half()
+    rb = torch.randn(bsz, cout, generator=g).to(dev).contiguous() if temb else None
+    kw = dict(n_img=bsz * t_len, t_len=t_len, hi=h, wi=w, residual=rr, out_scale=1.0 / 1.3, out_f32=f32, rowbias=rb,
+              rows_per_batch=t_len * h * w)
+    y0 = ops.conv_gemm(x, cw, **kw)
+    y = ops.conv_gemm(x, cw, gn_groups=groups, **kw)
+    gn = getattr(y, "_uav_gn", None)
+    assert gn is not None and gn.rows == 64 and gn.ws.shape == (2, groups, M // 64), "launch did not produce partials"
+    assert torch.equal(y0, y)
+    cpg = cout // groups
+    yc = y.double().reshape(M // 64, 64, groups, cpg)
+    s_ref = yc.sum(dim=(1, 3)).t(); q_ref = (yc * yc).sum(dim=(1, 3)).t()
+    l1 = yc.abs().sum(dim=(1, 3)).t()
+    es = ((gn.ws[0].double() - s_ref).abs() / (l1 + 1e-6)); eq = ((gn.ws[1].double() - q_ref).abs() / (q_ref + 1e-6))
+    assert es.max().item() < 2e-3, (es.max().item(), (es > 2e-3).nonzero()[:8].tolist(), gn.ws[0][:2, :4].tolist(), s_ref[:2, :4].tolist())
+    assert eq.max().item() < 2e-3, (eq.max().item(), (eq > 2e-3).nonzero()[:8].tolist())
+    gamma = (1 + 0.1 * torch.randn(cout, generator=g)).to(dev); beta = (0.1 * torch.randn(cout, generator=g)).to(dev)
+    for n_inst, rows_per in ((bsz, t_len * h * w), (bsz * t_len, h * w)):        # 5-D and per-frame GroupNorm
+        sc1, sh1 = ops.groupnorm_scale_shift(y, gamma, beta, n_inst=n_inst, rows_per_inst=rows_per, groups=groups, eps=1e-6)
+        sc0, sh0 = ops.groupnorm_scale_shift(y0, gamma, beta, n_inst=n_inst, rows_per_inst=rows_per, groups=groups, eps=1e-6)
+        assert rel_l2(sc1, sc0) < 1e-3 and rel_l2(sh1, sh0) < 1e-3
+    # an in-place update of the tensor invalidates the partials (stand-alone pass runs instead: result follows the data)
+    y.mul_(2.0)
+    sc2, _ = ops.groupnorm_scale_shift(y, gamma, beta, n_inst=bsz, rows_per_inst=t_len * h * w, groups=groups, eps=1e-6)
+    sc5, _ = ops.groupnorm_scale_shift(y0, gamma, beta, n_inst=bsz, rows_per_inst=t_len * h * w, groups=groups, eps=1e-6)
+    assert rel_l2(sc2 * 2.0, sc5) < 1e-3
+
+
+def test_conv_fused_groupnorm_statistics_not_offered(ops, dev):
+    """Launches that cannot produce partials (small grids -> 128x128 kernel, N tails, GEGLU, 48-channel groups) return a
+    plain tensor, and GroupNorm falls back to its own statistics pass."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2 * 16 * 16, 64, generator=g).half().to(dev)
+    cw = ops.pack_conv(h16(256, 64, 1, 3, 3, dev=dev, scale=0.05, gen=g), torch.zeros(256), device=dev)
+    y = ops.conv_gemm(x, cw, n_img=2, t_len=1, hi=16, wi=16, gn_groups=32)
+    assert getattr(y, "_uav_gn", None) is None
+    x2 = torch.randn(4 * 128 * 64, 64, generator=g).half().to(dev)
+    cw2 = ops.pack_conv(h16(1536, 64, 1, 1, 1, dev=dev, scale=0.1, gen=g), torch.zeros(1536), device=dev)
+    y2 = ops.conv_gemm(x2, cw2, n_img=4, t_len=1, hi=128, wi=64, gn_groups=32)       # 48 channels per group
+    assert getattr(y2, "_uav_gn", None) is None
+    cw3 = ops.pack_conv(h16(128, 64, 1, 1, 1, dev=dev, scale=0.1, gen=g), torch.zeros(128), device=dev)
+    y3 = ops.conv_gemm(x2, cw3, n_img=4, t_len=1, hi=128, wi=64, gn_groups=32)       # 128 outputs: n_pad = 128 -> 128x128 kernel
+    assert getattr(y3, "_uav_gn", None) is None

@@ -45,6 +45,7 @@ struct ConvArgs {
     long long M;
     int korder, tile_order;
     unsigned ntiles;
+    float* gn_ws; int gn_groups, gn_cpg_log2; long long gn_chunks;     // fused GroupNorm statistics (see conv_gn_store)
 };
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
@@ -73,14 +74,123 @@ UAV_DEVINL float2_t unpack_h2(uint32_t u) {
     return float2_t{(float)h[0], (float)h[1]};
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused GroupNorm statistics (UAV_CONV_GN_STATS): the epilogue already holds, per lane, the final fp32 values of one
+// pixel row; the consumer's GroupNorm needs (sum, sum of squares) per group of `cpg` consecutive channels over all rows of
+// an instance.  A wave reduces its 64-row x 128-channel tile to one (sum, sumsq) pair per group it covers and writes
+// them to gn_ws[(which * groups + g) * chunks + chunk], chunk = first row / 64 — `uav_groupnorm_finalize_partials`
+// (norm.hip) then reads chunk-contiguous runs.  Fixed reduction order, no atomics: deterministic.
+// DPP sum over the 32 lanes of each half-wave (lanes 0-31 / 32-63); the total is valid in lanes 16-31 / 48-63.
+UAV_DEVINL float half_sum32(float v) {
+    int x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true));    // row_half_mirror
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true));    // row_mirror
+    x = __builtin_bit_cast(int, v);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false));   // row_bcast15 -> rows 1, 3
+    return v;
+}
+UAV_DEVINL float both_halves(float v) {        // v(lane) + v(lane ^ 32)
+    uint32_t a = __builtin_bit_cast(uint32_t, v), b = a;
+    swap_pair(a, b);
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+// Accumulator granularity GNM (template parameter of the fast epilogues; 0 = statistics off): the lane keeps one
+// (sum, sumsq) pair per column tile ni and per NG = 4 / 2 / 1 register-quad classes — GNM 1: per quad g (groups of 4 or 8
+// channels), 2: per quad pair (16), 3: per column tile (32, 64, 128) — so wide groups cost 8-16 registers, not 32.
+template <int GNM> struct GnAcc { static constexpr int NG = GNM == 1 ? 4 : GNM == 2 ? 2 : 1; };
+__host__ __device__ inline int gn_mode_of(int cpg_log2) { return cpg_log2 <= 3 ? 1 : cpg_log2 == 4 ? 2 : 3; }
+
+// st/sq[ni][k]: this lane's sums over its pixels (mi) of channels nw0 + ni*32 + 8g + 4*hi32 + (0..3), g in class k.
+// CL = log2(channels per group), 2..7.  After the half-wave reductions every lane 16..31 of a half holds the totals;
+// lane 16+i keeps value i, so ONE store instruction per statistic leaves the wave (vector memory instructions, not
+// VALU, are what the epilogue is short of).
+template <int NI, int MI, int GNM, int CL>
+UAV_DEVINL void conv_gn_store_cl(const ConvArgs& p, float (&st)[NI][GnAcc<GNM>::NG], float (&sq)[NI][GnAcc<GNM>::NG],
+                                 long long mw0, int nw0, int l32, int hi32) {
+    constexpr int NG = GnAcc<GNM>::NG;
+    constexpr int NV = CL <= 4 ? NI * NG : CL == 5 ? NI : CL == 6 ? (NI + 1) / 2 : 1;
+    float a[NV], b[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { a[i] = 0.f; b[i] = 0.f; }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int i = CL <= 4 ? ni * NG + k : CL == 5 ? ni : CL == 6 ? (ni >> 1) : 0;
+            a[i] += st[ni][k]; b[i] += sq[ni][k];
+        }
+    float vs = 0.f, vq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        float s = half_sum32(a[i]), q = half_sum32(b[i]);
+        if (CL >= 3) { s = both_halves(s); q = both_halves(q); }
+        if (l32 == 16 + i) { vs = s; vq = q; }
+    }
+    // CL == 2: quad 2g + hi32 of tile ni is its own group -> group (nw0 >> 2) + 2i + hi32, both halves write;
+    // CL >= 3: group (nw0 >> CL) + i, the upper half writes
+    const int i = l32 - 16;
+    const int grp = CL == 2 ? (nw0 >> 2) + 2 * i + hi32 : (nw0 >> CL) + i;
+    const bool writer = i >= 0 && i < NV && (CL == 2 || hi32 == 1) && grp < p.gn_groups;
+    if (writer) {
+        float* ws_s = p.gn_ws + (long long)grp * p.gn_chunks + mw0 / (MI * 32);
+        ws_s[0] = vs;
+        ws_s[(long long)p.gn_groups * p.gn_chunks] = vq;
+    }
+}
+template <int NI, int MI, int GNM>
+UAV_DEVINL void conv_gn_store(const ConvArgs& p, float (&st)[NI][GnAcc<GNM>::NG], float (&sq)[NI][GnAcc<GNM>::NG],
+                              long long mw0, int nw0, int l32, int hi32) {
+    if constexpr (GNM == 1) {
+        if (p.gn_cpg_log2 == 2) conv_gn_store_cl<NI, MI, GNM, 2>(p, st, sq, mw0, nw0, l32, hi32);
+        else conv_gn_store_cl<NI, MI, GNM, 3>(p, st, sq, mw0, nw0, l32, hi32);
+    } else if constexpr (GNM == 2) {
+        conv_gn_store_cl<NI, MI, GNM, 4>(p, st, sq, mw0, nw0, l32, hi32);
+    } else {
+        // groups of 32 / 64 / 128 channels = 1 / 2 / 4 column tiles: one reduction of the per-tile sums, the wider groups
+        // are sums of those (one code path; cl is wave-uniform)
+        static_assert(NI == 4, "wave tile of 128 channels");
+        const int cl = p.gn_cpg_log2;
+        float s[NI], q[NI];
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) { s[ni] = both_halves(half_sum32(st[ni][0])); q[ni] = both_halves(half_sum32(sq[ni][0])); }
+        const float s01 = s[0] + s[1], s23 = s[2] + s[3], q01 = q[0] + q[1], q23 = q[2] + q[3];
+        const int i = l32 - 16;
+        float vs, vq;
+        if (cl == 5) { vs = i == 0 ? s[0] : i == 1 ? s[1] : i == 2 ? s[2] : s[3]; vq = i == 0 ? q[0] : i == 1 ? q[1] : i == 2 ? q[2] : q[3]; }
+        else if (cl == 6) { vs = i == 0 ? s01 : s23; vq = i == 0 ? q01 : q23; }
+        else { vs = s01 + s23; vq = q01 + q23; }
+        const int nv = 4 >> (cl - 5);
+        const int grp = (nw0 >> cl) + i;
+        if (i >= 0 && i < nv && hi32 == 1 && grp < p.gn_groups) {
+            float* ws_s = p.gn_ws + (long long)grp * p.gn_chunks + mw0 / (MI * 32);
+            ws_s[0] = vs;
+            ws_s[(long long)p.gn_groups * p.gn_chunks] = vq;
+        }
+    }
+}
+
 // Fast paths: the whole wave tile lies inside M and N, fp16 output, 16-B aligned rows, one time-embedding row for the
 // tile.  No predicates and no flag tests inside -> ONE basic block, so the scheduler issues every bias / residual load
 // up front instead of load -> wait -> store per 16-B piece (the generic path below has ~130 s_waitcnt and ~270 branches;
 // on the K = 512 linears the epilogue was 35-40 % of the kernel time, `tools/ab_conv.sh` DBG=6).  Same arithmetic
 // order as the generic path: ((acc + bias) + rowbias) + residual, then * out_scale.
-template <int NI, int MI, bool RES, bool BIAS, bool RB>
+template <int NI, int MI, bool RES, bool BIAS, bool RB, int GNM>
 UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32,
                                    const float* rbrow) {
+    constexpr bool GN = GNM != 0;
+    constexpr int NG = GnAcc<GNM>::NG;
+    float gst[GN ? NI : 1][NG], gsq[GN ? NI : 1][NG];    // GroupNorm partial sums of the values stored (fp32, before rounding)
+    if (GN) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int k = 0; k < NG; ++k) { gst[ni][k] = 0.f; gsq[ni][k] = 0.f; }
+    }
     char* orow[MI];
     const char* rrow[MI];
 #pragma unroll
@@ -94,6 +204,9 @@ UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], 
     const float osc = p.out_scale;
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
+        // statistics instances: keep the loads of the second half of the tile behind the first half's stores — hoisting
+        // all of them on top of the statistics accumulators does not fit the 256-register budget (scratch traffic)
+        if (GN && ni == NI / 2) { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); }
         float4_t bq[4], rq[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -136,25 +249,45 @@ UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], 
                         v[0] += r0[0]; v[1] += r0[1]; v[2] += r1[0]; v[3] += r1[1];
                     }
                     uint32_t* d = q == 0 ? A : B;
-                    d[0] = pack_h2(v[0] * osc, v[1] * osc);
-                    d[1] = pack_h2(v[2] * osc, v[3] * osc);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= osc;
+                    d[0] = pack_h2(v[0], v[1]);
+                    d[1] = pack_h2(v[2], v[3]);
+                    if (GN) {
+                        constexpr int sh = GNM == 1 ? 0 : GNM == 2 ? 1 : 2;
+                        gst[GN ? ni : 0][g >> sh] += (v[0] + v[1]) + (v[2] + v[3]);
+                        gsq[GN ? ni : 0][g >> sh] += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+                    }
                 }
                 swap_pair(A[0], B[0]); swap_pair(A[1], B[1]);
                 uint4_t o = {A[0], A[1], B[0], B[1]};
                 *(uint4_t*)(orow[mi] + (ni * 32 + 16 * gp) * 2) = o;
             }
     }
+    if constexpr (GN) conv_gn_store<NI, MI, GNM>(p, gst, gsq, mw0, nw0, l32, hi32);
 }
 
 // fp32-output fast path (VAE decoder in fp32-stream mode: conv outputs, residual stream and GroupNorm inputs stay fp32,
 // only the MFMA operands are fp16).  A lane owns pixel m and, per register quad g, 4 consecutive channels: one float4
 // (16-B) store per quad straight from the accumulators, one float4 load for an fp32 residual; no half-wave exchange.
 // Same arithmetic order as the fp16 paths: ((acc + bias) + residual) * out_scale.
-template <int NI, int MI, bool RES>
+template <int NI, int MI, bool RES, int GNM>
 UAV_DEVINL void conv_epilogue_f32_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32) {
     const float osc = p.out_scale;
+    constexpr bool GN = GNM != 0;
+    constexpr int NG = GnAcc<GNM>::NG;
+    float gst[GN ? NI : 1][NG], gsq[GN ? NI : 1][NG];
+    if (GN) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int k = 0; k < NG; ++k) { gst[ni][k] = 0.f; gsq[ni][k] = 0.f; }
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
+        // statistics instances: keep the loads of the second half of the tile behind the first half's stores — hoisting
+        // all of them on top of the statistics accumulators does not fit the 256-register budget (scratch traffic)
+        if (GN && ni == NI / 2) { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); }
         float4_t bq[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) bq[g] = *(const float4_t*)(p.bias + nw0 + ni * 32 + 8 * g + 4 * hi32);
@@ -178,9 +311,15 @@ UAV_DEVINL void conv_epilogue_f32_fast(const ConvArgs& p, float16_t (&acc)[NI][M
                     o[j] = v * osc;
                 }
                 *(float4_t*)(orow + 8 * g) = o;
+                if (GN) {
+                    constexpr int sh = GNM == 1 ? 0 : GNM == 2 ? 1 : 2;
+                    gst[GN ? ni : 0][g >> sh] += (o[0] + o[1]) + (o[2] + o[3]);
+                    gsq[GN ? ni : 0][g >> sh] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+                }
             }
         }
     }
+    if constexpr (GN) conv_gn_store<NI, MI, GNM>(p, gst, gsq, mw0, nw0, l32, hi32);
 }
 
 // GEGLU fast path (same preconditions; no residual / rowbias by contract): value/gate tile pairs (2b, 2b+1).
@@ -226,16 +365,42 @@ UAV_DEVINL void conv_epilogue_geglu_fast(const ConvArgs& p, float16_t (&acc)[NI]
     }
 }
 
-template <int NI, int MI>
+// GNK != 0: the kernel instance that also reduces GroupNorm statistics (accumulator granularity GNK, see GnAcc).  The
+// host only launches it when every wave tile inside M x N qualifies for a fast path (conv_gn_cpg_log2), so nothing else
+// is instantiated there: the statistics variants stay out of the plain kernels, whose register allocation (no scratch) is
+// the one measured in DESIGN.md.
+template <int NI, int MI, int GNK = 0>
 UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32) {
+    if constexpr (GNK != 0) {
+        if (mw0 >= p.M || nw0 >= p.n) return;                   // wave tile outside the output: nothing to store or count
+        if (p.flags & UAV_CONV_OUT_F32) {
+            if (p.residual) conv_epilogue_f32_fast<NI, MI, true, GNK>(p, acc, mw0, nw0, l32, hi32);
+            else conv_epilogue_f32_fast<NI, MI, false, GNK>(p, acc, mw0, nw0, l32, hi32);
+            return;
+        }
+        const float* rbrow = p.rowbias ? p.rowbias + (long long)((int)(mw0 / p.rows_per_batch)) * p.rowbias_stride : nullptr;
+#define UAV_EPI(RES, BIAS, RB) conv_epilogue_fast<NI, MI, RES, BIAS, RB, GNK>(p, acc, mw0, nw0, l32, hi32, rbrow)
+        switch ((p.residual ? 4 : 0) | (p.bias ? 2 : 0) | (rbrow ? 1 : 0)) {
+            case 0: UAV_EPI(false, false, false); break;
+            case 1: UAV_EPI(false, false, true); break;
+            case 2: UAV_EPI(false, true, false); break;
+            case 3: UAV_EPI(false, true, true); break;
+            case 4: UAV_EPI(true, false, false); break;
+            case 5: UAV_EPI(true, false, true); break;
+            case 6: UAV_EPI(true, true, false); break;
+            default: UAV_EPI(true, true, true); break;
+        }
+#undef UAV_EPI
+        return;
+    }
     const bool geglu = p.flags & UAV_CONV_GEGLU;
     const bool of32 = p.flags & UAV_CONV_OUT_F32;
     const bool rf32 = p.flags & UAV_CONV_RES_F32;
     const unsigned actf = p.flags & (UAV_CONV_GELU | UAV_CONV_QUICK_GELU);      // activation: generic path only (tiny GEMMs)
     if (of32 && !actf && !geglu && p.bias && !p.rowbias && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n && !(p.out_stride & 3) &&
         (!p.residual || (rf32 && !(p.res_stride & 3)))) {
-        if (p.residual) conv_epilogue_f32_fast<NI, MI, true>(p, acc, mw0, nw0, l32, hi32);
-        else conv_epilogue_f32_fast<NI, MI, false>(p, acc, mw0, nw0, l32, hi32);
+        if (p.residual) conv_epilogue_f32_fast<NI, MI, true, 0>(p, acc, mw0, nw0, l32, hi32);
+        else conv_epilogue_f32_fast<NI, MI, false, 0>(p, acc, mw0, nw0, l32, hi32);
         return;
     }
     // wave-uniform fast-path test
@@ -254,7 +419,7 @@ UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long 
             rbrow = p.rowbias + (long long)b0 * p.rowbias_stride;
         }
         if (uniform) {
-#define UAV_EPI(RES, BIAS, RB) conv_epilogue_fast<NI, MI, RES, BIAS, RB>(p, acc, mw0, nw0, l32, hi32, rbrow)
+#define UAV_EPI(RES, BIAS, RB) conv_epilogue_fast<NI, MI, RES, BIAS, RB, 0>(p, acc, mw0, nw0, l32, hi32, rbrow)
             const int sel = (p.residual ? 4 : 0) | (p.bias ? 2 : 0) | (rbrow ? 1 : 0);
             switch (sel) {
                 case 0: UAV_EPI(false, false, false); break;
@@ -844,7 +1009,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
 //     path works while the matrix pipe does, and M0 (LDS destination) is written by s_add right before each.
 // Stage hand-over is unchanged (2 stages, vmcnt(0) + barrier per k-step), so the numerics and the tile walk are
 // bit-identical to the round-1 kernel (tests/test_fullsize_gpu.py compares them).
-template <int V>
+template <int V, int GNK = 0>
 __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1046,10 +1211,56 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
 #undef COMPUTE_ADDR
     // the MFMAs issued last may still be in flight and the compiler cannot see them (see conv_gemm256_kernel)
     asm volatile("s_nop 15\ns_nop 15" ::: "memory");
-    conv_epilogue<4, 2>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);
+    conv_epilogue<4, 2, GNK>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);
 }
 
 }  // namespace
+
+namespace {
+struct ConvEnv { int korder, tile_order, force_tile, dbg, persist, dmav; };
+const ConvEnv& conv_env() {
+    // Environment switches (development A/B only) are read once through a thread-safe magic static.
+    static const ConvEnv env = [] {
+        auto geti = [](const char* k, int d) { const char* e = getenv(k); return e ? atoi(e) : d; };
+        return ConvEnv{geti("UAV_CONV_KORDER", 1), geti("UAV_CONV_TILE_ORDER", 1), geti("UAV_CONV_TILE", 0),
+                       geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0), geti("UAV_CONV_DMAV", 1)};
+    }();
+    return env;
+}
+// tile selection: the 256x256 kernel needs n_pad % 256 == 0 and enough tiles to fill 256 CUs
+bool conv_uses_big_tile(const uav_conv_params* q) {
+    const bool small = (q->c1 == 8 && q->c2 == 0);
+    const long long M = (long long)q->n_img * q->ho * q->wo;
+    const long long grid256 = ((M + LM - 1) / LM) * (q->n_pad / LN);
+    const int force_tile = conv_env().force_tile;
+    return !small && (q->n_pad % LN == 0) && (force_tile >= 256 || (force_tile != 128 && grid256 >= 224));
+}
+// Fused GroupNorm statistics are produced by the fast epilogues of the 256x256 kernel only: every wave tile (64 rows x
+// 128 channels) must lie inside M x N and qualify for a fast path, and a group must not straddle wave tiles.
+int conv_gn_cpg_log2(const uav_conv_params* q) {
+    if (q->gn_groups <= 0 || (q->n % q->gn_groups)) return -1;
+    const int cpg = q->n / q->gn_groups;
+    int cl = -1;
+    for (int k = 2; k <= 7; ++k) if (cpg == (1 << k)) cl = k;
+    if (cl < 0) return -1;
+    const long long M = (long long)q->n_img * q->ho * q->wo;
+    if (!conv_uses_big_tile(q) || (M % 64) || (q->n % 128)) return -1;
+    if (q->flags & (UAV_CONV_GEGLU | UAV_CONV_GELU | UAV_CONV_QUICK_GELU)) return -1;
+    const bool of32 = q->flags & UAV_CONV_OUT_F32, rf32 = q->flags & UAV_CONV_RES_F32;
+    if (of32) {
+        if (!q->bias || q->rowbias || (q->out_stride & 3) || (q->residual && (!rf32 || (q->res_stride & 3)))) return -1;
+    } else {
+        if (rf32 || (q->out_stride & 7) || (q->residual && (q->res_stride & 7))) return -1;
+        if (q->rowbias && (q->rows_per_batch % 64)) return -1;
+    }
+    return cl;
+}
+}  // namespace
+
+extern "C" int uav_conv_gemm_gn_chunk_rows(const uav_conv_params* q) {
+    if (!q || q->n_pad <= 0 || q->gn_groups <= 0) return 0;
+    return conv_gn_cpg_log2(q) >= 0 ? 64 : 0;
+}
 
 extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     if (!q || !q->a1 || !q->w || !q->out || !q->zero_page) return UAV_EINVAL;
@@ -1085,27 +1296,25 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     a.zero_page = (const char*)q->zero_page;
     a.M = (long long)q->n_img * q->ho * q->wo;
     if (a.M <= 0 || a.M >= (1ll << 31)) return UAV_ESHAPE;
-    // One-time setup.  Environment switches (development A/B only) are read once through a thread-safe magic static;
-    // the dynamic-LDS attribute of the 256x256 kernels and the CU count are PER DEVICE (std::call_once per device index),
-    // so a second GPU, or a second host thread driving the library (bench --clips-per-step), never launches before the
-    // attribute is in place.
-    struct ConvEnv { int korder, tile_order, force_tile, dbg, persist, dmav; };
-    static const ConvEnv env = [] {
-        auto geti = [](const char* k, int d) { const char* e = getenv(k); return e ? atoi(e) : d; };
-        return ConvEnv{geti("UAV_CONV_KORDER", 1), geti("UAV_CONV_TILE_ORDER", 1), geti("UAV_CONV_TILE", 0),
-                       geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0), geti("UAV_CONV_DMAV", 1)};
-    }();
+    a.gn_ws = nullptr; a.gn_groups = 0; a.gn_cpg_log2 = 0; a.gn_chunks = 0;
+    if (q->gn_partials) {
+        const int cl = conv_gn_cpg_log2(q);
+        if (cl < 0) return UAV_ESHAPE;             // ask uav_conv_gemm_gn_chunk_rows() first
+        a.gn_ws = (float*)q->gn_partials; a.gn_groups = q->gn_groups; a.gn_cpg_log2 = cl; a.gn_chunks = a.M / 64;
+    }
+    // One-time setup.  The dynamic-LDS attribute of the 256x256 kernels and the CU count are PER DEVICE (std::call_once
+    // per device index), so a second GPU, or a second host thread driving the library (bench --clips-per-step), never
+    // launches before the attribute is in place.
+    const ConvEnv& env = conv_env();
     a.korder = env.korder;
     a.tile_order = env.tile_order;
     const long long mtiles = (a.M + BM - 1) / BM;
     const long long grid = mtiles * (q->n_pad / BN);
     if (grid >= (1ll << 31)) return UAV_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
-    // tile selection: the 256x256 kernel needs n_pad % 256 == 0 and enough tiles to fill 256 CUs
     const long long mtiles256 = (a.M + LM - 1) / LM;
     const long long grid256 = mtiles256 * (q->n_pad / LN);
-    const int force_tile = env.force_tile;
-    const bool big = !small && (q->n_pad % LN == 0) && (force_tile >= 256 || (force_tile != 128 && grid256 >= 224));
+    const bool big = conv_uses_big_tile(q);
     if (big) {
         constexpr int MAXDEV = 64;
         static std::once_flag dev_once[MAXDEV];
@@ -1118,7 +1327,8 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
                                  (const void*)conv_gemm256_kernel<4>, (const void*)conv_gemm256_kernel<5>,
                                  (const void*)conv_gemm256_kernel<6>, (const void*)conv_gemm256_kernel<0, 1>,
                                  (const void*)conv_gemm256i_kernel<1>, (const void*)conv_gemm256i_kernel<2>,
-                                 (const void*)conv_gemm256i_kernel<3>};
+                                 (const void*)conv_gemm256i_kernel<3>, (const void*)conv_gemm256i_kernel<1, 1>,
+                                 (const void*)conv_gemm256i_kernel<1, 2>, (const void*)conv_gemm256i_kernel<1, 3>};
             for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
             hipDeviceProp_t prop;
             dev_ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
@@ -1126,7 +1336,12 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         const long long ncu = dev_ncu[dev];
         const int dbg = env.dbg, persist = env.persist;
         a.ntiles = (unsigned)grid256;
-        if (dbg == 1) hipLaunchKernelGGL(conv_gemm256_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+        if (a.gn_ws) {                     // statistics-reducing instances of the production kernel (env A/B switches do not apply)
+            const int gnm = gn_mode_of(a.gn_cpg_log2);
+            if (gnm == 1) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 1>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+            else if (gnm == 2) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 2>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+            else hipLaunchKernelGGL((conv_gemm256i_kernel<1, 3>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+        } else if (dbg == 1) hipLaunchKernelGGL(conv_gemm256_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 2) hipLaunchKernelGGL(conv_gemm256_kernel<2>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 4) hipLaunchKernelGGL(conv_gemm256_kernel<4>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 3) hipLaunchKernelGGL(conv_gemm256_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);

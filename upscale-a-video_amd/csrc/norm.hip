@@ -143,6 +143,38 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
         for (int ch = c_real + tid; ch < c; ch += 256) { scale[(long long)inst * c + ch] = 0.f; shift[(long long)inst * c + ch] = 0.f; }
 }
 
+// Same result from the partials a conv epilogue wrote (conv_gemm.hip: conv_gn_store): [2][groups][chunks_total], the
+// instance's chunks are contiguous, so the reads are coalesced; fp64 tree as above.
+__global__ __launch_bounds__(1024) void gn_finalize_partials_kernel(const float* __restrict__ ws, long long chunks_total,
+                                                                    long long chunks, int c, int groups, long long rows_per_inst,
+                                                                    float eps, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float* __restrict__ scale,
+                                                                    float* __restrict__ shift) {
+    __shared__ double rs[1024], rq[1024];
+    const int g = blockIdx.x, inst = blockIdx.y, tid = threadIdx.x;
+    const int cpg = c / groups;
+    const float* ps = ws + (long long)g * chunks_total + (long long)inst * chunks;
+    const float* pq = ps + (long long)groups * chunks_total;
+    double a = 0.0, b = 0.0;
+    for (long long k = tid; k < chunks; k += 1024) { a += ps[k]; b += pq[k]; }
+    rs[tid] = a; rq[tid] = b;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
+        __syncthreads();
+    }
+    const double n = (double)rows_per_inst * cpg;
+    const double mean = rs[0] / n;
+    double var = rq[0] / n - mean * mean; if (var < 0.0) var = 0.0;
+    const float fm = (float)mean, fr = (float)(1.0 / sqrt(var + (double)eps));
+    for (int j = tid; j < cpg; j += 1024) {
+        const int ch = g * cpg + j;
+        const float ga = gamma ? gamma[ch] : 1.f, be = beta ? beta[ch] : 0.f;
+        scale[(long long)inst * c + ch] = ga * fr;
+        shift[(long long)inst * c + ch] = be - fm * fr * ga;
+    }
+}
+
 template <bool F32>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc s, long long rows_per_inst, int chunks,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
@@ -270,6 +302,20 @@ extern "C" int uav_groupnorm_scale_shift(const void* x1, const void* x2, int32_t
 #undef GN_PARTIAL
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(groups, n_inst), dim3(256), 0, st, (const float*)workspace, chunks, c, c_real,
                        groups, (long long)rows_per_inst, eps, gamma, beta, scale_out, shift_out);
+    return uav_launch_status();
+}
+
+extern "C" int uav_groupnorm_finalize_partials(const float* partials, int64_t chunks_total, int32_t chunk_rows, int32_t c,
+                                               int32_t n_inst, int64_t rows_per_inst, int32_t groups, float eps,
+                                               const float* gamma, const float* beta, float* scale_out, float* shift_out,
+                                               void* stream) {
+    if (!partials || !scale_out || !shift_out) return UAV_EINVAL;
+    if (c <= 0 || groups <= 0 || groups > 2048 || (c % groups) || n_inst <= 0 || n_inst > 65535 || rows_per_inst <= 0 ||
+        chunk_rows <= 0 || (rows_per_inst % chunk_rows) || (int64_t)n_inst * (rows_per_inst / chunk_rows) != chunks_total)
+        return UAV_ESHAPE;
+    hipLaunchKernelGGL(gn_finalize_partials_kernel, dim3(groups, n_inst), dim3(1024), 0, (hipStream_t)stream, partials,
+                       (long long)chunks_total, (long long)(rows_per_inst / chunk_rows), c, groups, (long long)rows_per_inst,
+                       eps, gamma, beta, scale_out, shift_out);
     return uav_launch_status();
 }
 

@@ -251,7 +251,7 @@ class Transformer3DModel(ModelMixin, ConfigMixin, E.EngineModule):
         tok = ops.linear(n, E.packed_conv(self, "proj_in", self.proj_in))
         for blk in self.transformer_blocks:
             tok = blk.run(tok, g, ehs_rows, n_text)
-        return ops.linear(tok, E.packed_conv(self, "proj_out", self.proj_out), residual=res)
+        return ops.linear(tok, E.packed_conv(self, "proj_out", self.proj_out), residual=res, gn_groups=self.norm.num_groups)
 
     def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, return_dict=True):
         rows, g = E.to_rows(hidden_states, c_pad=self.in_channels)

@@ -35,12 +35,14 @@ class InflatedConv3d(nn.Conv2d, E.EngineModule):
     """Per-frame 2-D convolution on a video tensor (reference resnet.py:94-101)."""
 
     def run(self, x, g: E.Geom, *, x2=None, residual=None, out_scale=1.0, upsample=False, out_f32=False, rowbias=None,
-            out_hw=None, out=None):
+            out_hw=None, out=None, gn_groups=None):
+        """gn_groups: the output is (probably) normalised next by a GroupNorm of that many groups — the epilogue then
+        reduces its statistics partials where it can (ops.conv_gemm); a wrong guess only costs the unused partials."""
         cw = E.packed_conv(self, "w", self)
         return ops.conv_gemm(x, cw, a2=x2, n_img=g.n_img, t_len=g.t, hi=g.h, wi=g.w, stride=self.stride[0],
                              pad=(0, self.padding[0], self.padding[1]), upsample=upsample, residual=residual,
                              out_scale=out_scale, out_f32=out_f32, rowbias=rowbias, rows_per_batch=g.rows_per_batch,
-                             out_hw=out_hw, out=out)
+                             out_hw=out_hw, out=out, gn_groups=gn_groups)
 
     def out_geom(self, g: E.Geom, upsample=False):
         if upsample:
@@ -57,11 +59,11 @@ class InflatedConv3d(nn.Conv2d, E.EngineModule):
 class Conv3dK11(nn.Conv3d, E.EngineModule):
     """nn.Conv3d container (temporal (k,1,1) and 3x3x3 kernels) executed by the implicit GEMM."""
 
-    def run(self, x, g: E.Geom, *, residual=None, out_scale=1.0, rowbias=None, out_f32=False):
+    def run(self, x, g: E.Geom, *, residual=None, out_scale=1.0, rowbias=None, out_f32=False, gn_groups=None):
         cw = E.packed_conv(self, "w", self)
         return ops.conv_gemm(x, cw, n_img=g.n_img, t_len=g.t, hi=g.h, wi=g.w, stride=1, pad=tuple(self.padding),
                              residual=residual, out_scale=out_scale, rowbias=rowbias, rows_per_batch=g.rows_per_batch,
-                             out_f32=out_f32)
+                             out_f32=out_f32, gn_groups=gn_groups)
 
 
 class Upsample3D(E.EngineModule):
@@ -85,7 +87,7 @@ class Upsample3D(E.EngineModule):
         s32 = x.dtype == torch.float32           # fp32 residual stream (VAE decoder): x is also this conv's operand
         x = ops.cast_f16(x)
         if output_size is None or tuple(output_size[-2:]) == (2 * g.h, 2 * g.w):
-            return conv.run(x, g, upsample=True, out_f32=s32), g.with_hw(2 * g.h, 2 * g.w)
+            return conv.run(x, g, upsample=True, out_f32=s32, gn_groups=E.GN_GROUPS_HINT), g.with_hw(2 * g.h, 2 * g.w)
         # Forced size (reference resnet.py:147-150, used when H, W are not multiples of 2^num_upsamplers,
         # unet_video.py:443-445,541-542): F.interpolate(size=..., mode="nearest"), i.e. src = floor(dst * in / out)
         # in fp32.  Rare path (odd intermediate sizes): the resized rows are materialised by an index gather and
@@ -93,7 +95,7 @@ class Upsample3D(E.EngineModule):
         ho, wo = int(output_size[-2]), int(output_size[-1])
         idx = self._nearest_rows(g, ho, wo, x.device)
         g2 = g.with_hw(ho, wo)
-        return conv.run(x.index_select(0, idx), g2, out_f32=s32), g2
+        return conv.run(x.index_select(0, idx), g2, out_f32=s32, gn_groups=E.GN_GROUPS_HINT), g2
 
     def _nearest_rows(self, g, ho, wo, device):
         key = (g.n_img, g.h, g.w, ho, wo, str(device))
@@ -133,8 +135,8 @@ class Downsample3D(E.EngineModule):
             # reference pads (0,1,0,1) then convolves with pad 0 (resnet.py:188-192): the right /
             # bottom taps that fall outside read zeros in the gather, no padded copy is made
             g2 = g.with_hw((g.h + 1 - 3) // 2 + 1, (g.w + 1 - 3) // 2 + 1)
-            return self.conv.run(x, g, out_hw=(g2.h, g2.w)), g2
-        return self.conv.run(x, g), self.conv.out_geom(g)
+            return self.conv.run(x, g, out_hw=(g2.h, g2.w), gn_groups=E.GN_GROUPS_HINT), g2
+        return self.conv.run(x, g, gn_groups=E.GN_GROUPS_HINT), self.conv.out_geom(g)
 
     def forward(self, hidden_states):
         rows, g = E.to_rows(hidden_states, c_pad=self.channels)
@@ -175,7 +177,7 @@ class _ResnetBase(E.EngineModule):
         h = E.group_norm(self, "norm1", self.norm1, x, n_inst=g.b, rows_per_inst=g.rows_per_batch, silu=True, x2=x2,
                          c_real=c_real)
         rb = _temb_rows(self, temb) if (temb is not None and self.time_emb_proj is not None) else None
-        h = self.conv1.run(h, g, rowbias=rb, out_f32=s32)
+        h = self.conv1.run(h, g, rowbias=rb, out_f32=s32, gn_groups=self.norm2.num_groups)
         h = E.group_norm(self, "norm2", self.norm2, h, n_inst=g.b, rows_per_inst=g.rows_per_batch, silu=True)
         if self.conv_shortcut is not None:
             xs = ops.cast_f16(x)                  # the shortcut conv reads the stream as an MFMA operand
@@ -187,7 +189,9 @@ class _ResnetBase(E.EngineModule):
             if s32 and x.dtype != torch.float32:
                 raise ops._lib.UavError("fp32 stream requested for an fp16 identity shortcut")
             res = x
-        return self.conv2.run(h, g, residual=res, out_scale=1.0 / self.output_scale_factor, out_f32=s32)
+        # the block's output is the stream the next block normalises (with this block's group count, as a rule)
+        return self.conv2.run(h, g, residual=res, out_scale=1.0 / self.output_scale_factor, out_f32=s32,
+                              gn_groups=self.norm2.num_groups)
 
     def forward(self, input_tensor, temb=None):
         cin = self.in_channels
@@ -241,7 +245,7 @@ class ResnetBlock3D_plus(ResnetBlock3D):
         out = super().run(x, g, temb, x2=x2, c_real=c_real, stream_f32=stream_f32)
         h = E.group_norm(self, "norm_3d", self.norm_3d, out, n_inst=g.b, rows_per_inst=g.rows_per_batch, silu=True)
         return self.conv_3d.run(h, g, residual=out, out_scale=1.0 / self.output_scale_factor,
-                                out_f32=out.dtype == torch.float32)
+                                out_f32=out.dtype == torch.float32, gn_groups=self.norm_3d.num_groups)
 
 
 class Fuse_sft_block(E.EngineModule):

@@ -44,7 +44,7 @@ class TemporalModule3D(E.EngineModule):
         h = self.resblocks_3d_spatial.run(h, g, temb)
         if w != 1.0:
             raise NotImplementedError("w != 1 is never used by the pipeline")
-        return self.shift_conv.run(h, g, residual=x)
+        return self.shift_conv.run(h, g, residual=x, gn_groups=E.GN_GROUPS_HINT)
 
     def forward(self, hidden_states, w=1, encoder_hidden_states=None, timesteps=None, temb=None, attention_mask=None):
         rows, g = E.to_rows(hidden_states, c_pad=self.in_channels)

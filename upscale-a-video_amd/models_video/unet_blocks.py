@@ -220,7 +220,8 @@ class AttentionBlock(E.EngineModule):
         o = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], bq=g.n_img, lq=g.hw, lk=g.hw, heads=self.num_heads,
                           head_dim=d, scale=1.0 / (d ** 0.5), q_stride=3 * c, k_stride=3 * c, v_stride=3 * c)
         return ops.linear(o, E.packed_conv(self, "proj", self.proj_attn), residual=x,
-                          out_scale=1.0 / self.rescale_output_factor, out_f32=x.dtype == torch.float32)
+                          out_scale=1.0 / self.rescale_output_factor, out_f32=x.dtype == torch.float32,
+                          gn_groups=self.group_norm.num_groups)
 
 
 class _MidBase(nn.Module):

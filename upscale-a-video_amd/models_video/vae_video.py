@@ -125,7 +125,7 @@ class Decoder(E.EngineModule):
     def run(self, z, g, img=None, w_lr=1.0, stream_f32=False):
         """z: latent rows [..][8] (after post_quant_conv); img: LR frame rows [..][8] (3 real channels).
         stream_f32: conv outputs / residual stream / GroupNorm inputs in fp32 (see _ResnetBase.run)."""
-        x = self.conv_in.run(z, g, out_f32=stream_f32)
+        x = self.conv_in.run(z, g, out_f32=stream_f32, gn_groups=E.GN_GROUPS_HINT)
         if self.condition_img:
             if img is None:
                 raise AssertionError("input img condition when condition_img is True.")

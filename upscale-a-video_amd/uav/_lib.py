@@ -30,6 +30,7 @@ class ConvParams(C.Structure):
         ("pad_t", i32), ("pad_h", i32), ("pad_w", i32), ("upsample", i32),
         ("n", i32), ("n_pad", i32), ("k_pad", i32),
         ("out_scale", f32), ("flags", u32), ("zero_page", c_p),
+        ("gn_partials", c_p), ("gn_groups", i32),
     ]
 
 
@@ -45,6 +46,8 @@ SIGNATURES = {
     "uav_version": (C.c_int, []),
     "uav_device_check": (C.c_int, [C.c_int, C.c_char_p]),
     "uav_conv_gemm_f16": (C.c_int, [C.POINTER(ConvParams), c_p]),
+    "uav_conv_gemm_gn_chunk_rows": (C.c_int, [C.POINTER(ConvParams)]),
+    "uav_groupnorm_finalize_partials": (C.c_int, [c_p, i64, i32, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p]),
     "uav_groupnorm_workspace_bytes": (i64, [i32, i32]),
     "uav_groupnorm_scale_shift": (C.c_int, [c_p, c_p, i32, i32, i32, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
     "uav_groupnorm_apply": (C.c_int, [c_p, c_p, i32, i32, i32, i32, i64, c_p, c_p, i32, c_p, c_p]),

@@ -160,6 +160,12 @@ def f16_param(mod: EngineModule, name, tensor):
     return mod._cache().get(("f16", name), build, (tensor,))
 
 
+# Group count a conv assumes for the GroupNorm that (probably) consumes its output when the caller cannot name that
+# consumer (up / down samplers, TemporalModule3D.shift_conv, the decoder's conv_in): every GroupNorm of the released
+# configs has 32 groups (norm_num_groups / resnet_groups).  A miss only leaves the partials unused (ops.conv_gemm).
+GN_GROUPS_HINT = 32
+
+
 def group_norm(mod: EngineModule, name, gn: nn.GroupNorm, x, *, n_inst, rows_per_inst, silu, x2=None, c_real=None):
     g = f32_param(mod, name + ".g", gn.weight)
     b = f32_param(mod, name + ".b", gn.bias)

@@ -8,6 +8,7 @@ the output buffers.  Activations are channels-last fp16 matrices [rows][C], rows
 import ctypes as C
 import functools
 import math
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -181,8 +182,12 @@ def pack_conv(weight, bias=None, geglu=False, device=None, n_store_align=4):
 
 def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None,
               rowbias=None, rows_per_batch=0, residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None,
-              persistent=False, act=None):
-    """out[M][n_out] = scale*(conv(a1|a2, W) + bias + rowbias[m//rows_per_batch] + residual)."""
+              persistent=False, act=None, gn_groups=None):
+    """out[M][n_out] = scale*(conv(a1|a2, W) + bias + rowbias[m//rows_per_batch] + residual).
+
+    gn_groups: the output feeds a GroupNorm of that many groups — when the launch qualifies
+    (`uav_conv_gemm_gn_chunk_rows`) the epilogue also reduces the statistics partials and the returned tensor carries
+    them (`GnPartials`, attribute `_uav_gn`); `groupnorm_scale_shift` then skips its pass over the tensor."""
     lib = _lib.load()
     _req(a1, HALF, "a1")
     c1 = a1.shape[-1]
@@ -233,8 +238,22 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
     p.pad_t = pt; p.pad_h = ph; p.pad_w = pw; p.upsample = 1 if upsample else 0
     p.n = wt.n; p.n_pad = wt.n_pad; p.k_pad = wt.k_pad
     p.out_scale = out_scale; p.flags = flags; p.zero_page = _p(zero_page(a1.device))
+    gn = None
+    if gn_groups and FUSE_GN_STATS:
+        p.gn_groups = int(gn_groups)
+        rows = lib.uav_conv_gemm_gn_chunk_rows(C.byref(p))
+        if rows > 0:
+            gn = GnPartials(torch.empty((2, int(gn_groups), m // rows), dtype=torch.float32, device=a1.device), rows,
+                            int(gn_groups), n_out)
+            p.gn_partials = _p(gn.ws)
+        else:
+            p.gn_groups = 0
     ev = PROFILER.begin("conv_gemm")
     _lib.check(lib.uav_conv_gemm_f16(C.byref(p), _stream()), "uav_conv_gemm_f16")
+    if gn is not None:
+        _gn_attach(out, gn)
+    elif getattr(out, "_uav_gn", None) is not None:      # caller-supplied buffer rewritten without statistics
+        out._uav_gn = None
     # algorithmic work: 2*M*N*K over the LOGICAL taps x input channels (no padding counted)
     PROFILER.end(ev, "conv_gemm" if not PROFILER.detail else
                  f"conv_gemm cin={wt.cin} n={wt.n} k={wt.kt}x{wt.kh}x{wt.kw} M={m}{' geglu' if wt.geglu else ''}{' up' if upsample else ''}{' s2' if stride == 2 else ''}",
@@ -255,14 +274,42 @@ def _factor_rows(m):
     raise _lib.UavError("unreachable")
 
 
-def linear(x, wt: ConvW, *, residual=None, out_scale=1.0, rowbias=None, rows_per_batch=0, out_f32=False, act=None):
+def linear(x, wt: ConvW, *, residual=None, out_scale=1.0, rowbias=None, rows_per_batch=0, out_f32=False, act=None,
+           gn_groups=None):
     """nn.Linear over token rows x[M][K] (a 1x1 'conv': every row is one pixel)."""
     n_img, hi = _factor_rows(x.shape[0])
     return conv_gemm(x, wt, n_img=n_img, t_len=1, hi=hi, wi=1, residual=residual, out_scale=out_scale,
-                     rowbias=rowbias, rows_per_batch=rows_per_batch, out_f32=out_f32, act=act)
+                     rowbias=rowbias, rows_per_batch=rows_per_batch, out_f32=out_f32, act=act, gn_groups=gn_groups)
 
 
 # ------------------------------------------------------------------------------------------------
+# GroupNorm statistics produced by the conv that wrote the tensor (uav_conv_params.gn_partials).  The partials ride on
+# the tensor OBJECT the conv returned: a view, a copy or an in-place update of it (`_version` moves) does not carry them,
+# and the GroupNorm then runs its own statistics pass.
+FUSE_GN_STATS = os.environ.get("UAV_FUSE_GN_STATS", "1") != "0"
+
+
+class GnPartials:
+    __slots__ = ("ws", "rows", "groups", "c", "version")
+
+    def __init__(self, ws, rows, groups, c):
+        self.ws, self.rows, self.groups, self.c, self.version = ws, rows, groups, c, None
+
+
+def _gn_attach(t, gn):
+    gn.version = t._version
+    t._uav_gn = gn
+
+
+def _gn_partials_of(x, groups, c, rows_per_inst):
+    gn = getattr(x, "_uav_gn", None)
+    if gn is None or gn.version != x._version or gn.groups != groups or gn.c != c or x.shape[-1] != c:
+        return None
+    if rows_per_inst % gn.rows:
+        return None
+    return gn
+
+
 def _gn_dtype(x1, x2):
     """GroupNorm inputs are fp16 rows, or fp32 rows (fp32 residual stream of the VAE decoder); both sources alike."""
     if x1.dtype not in (HALF, torch.float32):
@@ -283,6 +330,17 @@ def groupnorm_scale_shift(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps
         c_real = c
     scale = torch.empty((n_inst, c), dtype=torch.float32, device=x1.device)
     shift = torch.empty_like(scale)
+    gn = _gn_partials_of(x1, groups, c, rows_per_inst) if (x2 is None and c_real == c) else None
+    if gn is not None:
+        chunks_total = gn.ws.shape[-1]
+        if chunks_total * gn.rows != n_inst * rows_per_inst:
+            raise _lib.UavError("groupnorm: statistics partials do not cover the tensor")
+        ev = PROFILER.begin("groupnorm_stats")
+        rc = lib.uav_groupnorm_finalize_partials(_p(gn.ws), chunks_total, gn.rows, c, n_inst, rows_per_inst, groups, eps,
+                                                 _p(gamma), _p(beta), _p(scale), _p(shift), _stream())
+        _lib.check(rc, "uav_groupnorm_finalize_partials")
+        PROFILER.end(ev, "groupnorm_finalize_fused", 0.0, 4.0 * gn.ws.numel())
+        return scale, shift
     ws_bytes = lib.uav_groupnorm_workspace_bytes(n_inst, c)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x1.device)
     ev = PROFILER.begin("groupnorm_stats")
