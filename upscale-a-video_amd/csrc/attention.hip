@@ -402,11 +402,15 @@ template <int I> UAV_DEVINL void o5w_mfma(const half8_t& va, const half8_t& pb) 
     asm volatile("s_nop 1\n v_mfma_f32_32x32x16_f16 a[%c2:%c3], %0, %1, a[%c2:%c3]" :: "v"(va), "v"(pb), "i"(16 * I), "i"(16 * I + 15) : O5W_CLOBBERS);
 }
 // S^T accumulation in VGPRs BY CONSTRAINT: left to itself hipcc put this chain into a[0:15] — on top of O^T tile 0.
-UAV_DEVINL void o5w_mfma_s0(float16_t& acc, const half8_t& a, const half8_t& b) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b));
+// S^T chain.  `pending` = LDS reads issued after this step's K fragment (s_waitcnt lgkmcnt takes an immediate).
+UAV_DEVINL void o5w_kread(half8_t& kf, unsigned addr, int off) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kf) : "v"(addr), "n"(off));
 }
-UAV_DEVINL void o5w_mfma_s(float16_t& acc, const half8_t& a, const half8_t& b) {
-    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+UAV_DEVINL void o5w_mfma_s0(float16_t& acc, const half8_t& a, const half8_t& b, int pending) {
+    asm volatile("s_waitcnt lgkmcnt(%3)\n v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc) : "v"(a), "v"(b), "n"(pending));
+}
+UAV_DEVINL void o5w_mfma_s(float16_t& acc, const half8_t& a, const half8_t& b, int pending) {
+    asm volatile("s_waitcnt lgkmcnt(%3)\n v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b), "n"(pending));
 }
 template <int N> UAV_DEVINL void o5w_zero1() { asm volatile("v_accvgpr_write_b32 a%c0, 0" :: "i"(N) : O5W_CLOBBERS); }
 template <int N> UAV_DEVINL void o5w_scale1(float f) {
@@ -421,18 +425,30 @@ template <int B, int... N> UAV_DEVINL void o5w_read16(float (&o)[16], std::integ
 
 constexpr int SMEM5W = 2 * K5_BYTES + 2 * V5_BYTES;      // 64 KiB K + 72 KiB V^T = 136 KiB
 
-template <int I> UAV_DEVINL void o5w_pv_tile(const char* vt, int l32, int hi, const half8_t (&pf)[2]) {
-    const char* vrow = vt + (I * 32 + l32) * VT_STRIDE + hi * 8;
+// O^T += V^T P^T over the 16 d-tiles.  The P.V MFMAs are volatile asm (named accumulators), i.e. barriers for the
+// scheduler: a V^T fragment read placed right before its MFMA is waited for in full.  The reads are therefore written
+// VPF tiles AHEAD of their use in source order (ring of VPF fragment pairs, 8 VGPRs each); the compiler's counted
+// lgkmcnt keeps VPF-1 tiles of reads in flight behind every MFMA pair.
+constexpr int VPF = 3;
+UAV_DEVINL void o5w_v_frag(half8_t (&vf)[2], const char* vt, int tile, int l32, int hi) {
+    const char* vrow = vt + (tile * 32 + l32) * VT_STRIDE + hi * 8;
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
         half4_t a = *(const half4_t*)(vrow + s2 * 32);
         half4_t c = *(const half4_t*)(vrow + s2 * 32 + 16);
-        half8_t vf = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
-        o5w_mfma<I>(vf, pf[s2]);
+        vf[s2] = half8_t{a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
     }
 }
+template <int I> UAV_DEVINL void o5w_pv_tile(half8_t (&ring)[VPF][2], const char* vt, int l32, int hi, const half8_t (&pf)[2]) {
+    o5w_mfma<I>(ring[I % VPF][0], pf[0]);
+    o5w_mfma<I>(ring[I % VPF][1], pf[1]);
+    if (I + VPF < 16) o5w_v_frag(ring[I % VPF], vt, I + VPF, l32, hi);
+}
 template <int... I> UAV_DEVINL void o5w_pv_all(const char* vt, int l32, int hi, const half8_t (&pf)[2], std::integer_sequence<int, I...>) {
-    (o5w_pv_tile<I>(vt, l32, hi, pf), ...);
+    half8_t ring[VPF][2];
+#pragma unroll
+    for (int i = 0; i < VPF; ++i) o5w_v_frag(ring[i], vt, i, l32, hi);
+    (o5w_pv_tile<I>(ring, vt, l32, hi, pf), ...);
 }
 template <int I> UAV_DEVINL void o5w_store_tile(char* optr, int hi, float inv) {
     float o[16];
@@ -466,31 +482,44 @@ __global__ __launch_bounds__(256, 1) void attn512w_kernel(AttnArgs p) {
 #pragma unroll
     for (int s = 0; s < 32; ++s) qf[s] = *(const half8_t*)(qptr + (16 * s + 8 * hi) * 2);
 
+    const unsigned ks_lds = (unsigned)(size_t)(lptr_t)Ks + l32 * 1024;         // LDS address of this lane's key row, stage 0
+    unsigned kx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) kx[j] = (unsigned)(((2 * j + hi) ^ (l32 & 15)) << 4);
+
     o5w_zero_all(std::make_integer_sequence<int, 256>{});
     float m_run = -INFINITY, l_run = 0.f;
     const int nt = (p.lk + KV - 1) / KV;
 
+    // Global addresses as (wave-uniform 64-bit base in SGPRs) + (32-bit per-lane offset): the per-lane 64-bit pointers
+    // of all 16 loads of a tile were ~32 loop-invariant VGPRs the Q fragments (128) and the prefetch rings have no room for.
+    unsigned kvo[4];                                        // swizzled 16-B slot of this lane inside key row (4j + wave)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) kvo[j] = (unsigned)((lane ^ ((j * 4 + wave) & 15)) * 16);
     auto issue_k = [&](int stage, int t) {                  // one 1-KiB key row per wave-instruction, 8 rows per wave
         char* dst = Ks + stage * K5_BYTES;
 #pragma unroll
         for (int ps = 0; ps < 8; ++ps) {
             const int row = ps * 4 + wave;
-            const int sl = lane ^ (row & 15);
-            const int key = t * KV + row;
-            const char* g = key < p.lk ? kbase + ((long long)key * p.k_stride + sl * 8) * 2 : p.zero_page;
-            __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + (ps * 256 + wave * 64) * 16), 16, 0, 0);
+            const int key = t * KV + row;                   // wave-uniform
+            const bool ok = key < p.lk;
+            const char* base = ok ? kbase + (long long)key * p.k_stride * 2 : p.zero_page;
+            const unsigned off = ok ? kvo[ps & 3] : 0u;
+            __builtin_amdgcn_global_load_lds((gptr_t)(base + off), (lptr_t)(dst + (ps * 256 + wave * 64) * 16), 16, 0, 0);
         }
     };
     half8_t vst[2][4];                                      // two (4 keys x 8 dims) units per thread
+    const int vkg = tid & 7;                                // unit = u*256 + tid: key group unit & 7, dim vector unit >> 3
+    const unsigned vvo = (unsigned)((vkg * 4 * (int)p.v_stride + (tid >> 3) * 8) * 2);
     auto load_v = [&](int t) {
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int unit = u * 256 + tid, kg = unit & 7, dv = unit >> 3;
+        for (int i = 0; i < 4; ++i) {
+            const char* base = vbase + (long long)(t * KV + i) * p.v_stride * 2;       // wave-uniform
+            const bool ok = t * KV + vkg * 4 + i < p.lk;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int key = t * KV + kg * 4 + i;
+            for (int u = 0; u < 2; ++u) {
                 half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
-                vst[u][i] = key < p.lk ? *(const half8_t*)(vbase + ((long long)key * p.v_stride + dv * 8) * 2) : z;
+                vst[u][i] = ok ? *(const half8_t*)(base + vvo + u * 512) : z;
             }
         }
     };
@@ -513,16 +542,31 @@ __global__ __launch_bounds__(256, 1) void attn512w_kernel(AttnArgs p) {
         store_v(t & 1);                                     // V^T buffer t&1 was last read two tiles ago
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                    // the only barrier of the tile
-        if (t + 1 < nt) { issue_k((t + 1) & 1, t + 1); load_v(t + 1); }
+        if (t + 1 < nt) issue_k((t + 1) & 1, t + 1);
 
-        const char* kst = Ks + (t & 1) * K5_BYTES + l32 * 1024;
-        const int ksw = l32 & 15;
+        // S^T = K Q^T: 32 chained MFMAs, one K fragment each.  The fragment reads run KPF steps ahead of their MFMA and
+        // both are asm so that the wait is the exact count (the compiler's own bookkeeping put a full lgkmcnt(0) in front
+        // of every fourth MFMA).  Fragment (key l32, dims 16s + 8hi ..) sits in 16-B slot (2s + hi) ^ (l32 & 15) of the key's
+        // 1-KiB row: the XOR only touches the low 4 bits, so slot = 16 * (s >> 3) + ((2 (s & 7) + hi) ^ ksw) — 8 per-lane
+        // addresses and an immediate offset instead of 32 per-lane addresses.
+        const unsigned kb = ks_lds + (t & 1) * K5_BYTES;
+        unsigned ka[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) ka[j] = kb + kx[j];
         float16_t sacc;
+        constexpr int KPF = 8;                                  // K fragments in flight ahead of the MFMA chain
+        half8_t kf[KPF];
+#pragma unroll
+        for (int s = 0; s < KPF; ++s) o5w_kread(kf[s], ka[s & 7], (s >> 3) * 256);
 #pragma unroll
         for (int s = 0; s < 32; ++s) {
-            half8_t kf = *(const half8_t*)(kst + (((2 * s + hi) ^ ksw) << 4));
-            if (s == 0) o5w_mfma_s0(sacc, kf, qf[0]); else o5w_mfma_s(sacc, kf, qf[s]);
+            const int pending = (32 - s < KPF ? 32 - s : KPF) - 1;      // reads issued after this step's fragment
+            if (s == 0) o5w_mfma_s0(sacc, kf[0], qf[0], pending); else o5w_mfma_s(sacc, kf[s % KPF], qf[s], pending);
+            if (s + KPF < 32) o5w_kread(kf[s % KPF], ka[(s + KPF) & 7], ((s + KPF) >> 3) * 256);
         }
+        // next tile's V rows (register-staged for the transposing LDS write at the top of the next iteration): issued
+        // here, not beside the K DMA, so that their 32 VGPRs are not live through the S phase next to Q, the K ring and S^T
+        if (t + 1 < nt) load_v(t + 1);
         asm volatile("s_nop 15" : "+v"(sacc));                // XDL write -> VALU read of the scores (hipcc cannot see the MFMAs)
         const int key0 = t * KV + 4 * hi;
         float mx = -INFINITY;
@@ -563,11 +607,11 @@ __global__ __launch_bounds__(256, 1) void attn512w_kernel(AttnArgs p) {
 }
 
 int launch_attn512(const AttnArgs& a, hipStream_t s) {
-    // one wave per SIMD (attn512w) pays once the grid fills the chip more than twice over: +9.6 % at L = 102 400, -5 % at
-    // L = 25 600 (200 workgroups on 256 CUs), profiles/r02_ab_attn512_one_wave_per_simd_run12.log; UAV_ATTN512=0|1 forces a kernel
-    static const int variant = [] { const char* e = getenv("UAV_ATTN512"); return e ? atoi(e) : -1; }();
-    const long long wgs = (long long)((a.lq + 127) / 128) * a.bq;
-    if (variant == 1 || (variant < 0 && wgs >= 512)) {
+    // one wave per SIMD (attn512w) is the production kernel at every size since its fragment reads run ahead of the MFMAs:
+    // 658 vs 407 TFLOP/s at L = 102 400, 428 vs 339 at L = 25 600 (200 workgroups on 256 CUs),
+    // profiles/r02_ab_attn512_fragment_prefetch_run26.log; UAV_ATTN512=0 keeps the round-1 pair-split kernel reachable for A/B
+    static const int variant = [] { const char* e = getenv("UAV_ATTN512"); return e ? atoi(e) : 1; }();
+    if (variant != 0) {
         static UavDynLds ldsw;
         if (int rc = uav_set_dyn_lds(ldsw, (const void*)attn512w_kernel, SMEM5W)) return rc;
         hipLaunchKernelGGL(attn512w_kernel, dim3((a.lq + 127) / 128, 1, a.bq), dim3(256), SMEM5W, s, a);
