@@ -233,7 +233,7 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
             skips1.extend(outs)
             x1 = self.down_temp_blocks[0].run(x1, g1, emb1)
             skips = [(torch.cat([s_, s_]), E.Geom(2, sg.t, sg.h, sg.w)) for (s_, sg) in skips1]
-            x, g = torch.cat([x1, x1]), E.Geom(2, g1.t, g1.h, g1.w)
+            x, g = ops.duplicate_rows(x1), E.Geom(2, g1.t, g1.h, g1.w)
             first = 1
         else:
             x = self.conv_in.run(x, g)

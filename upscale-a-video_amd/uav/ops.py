@@ -310,6 +310,17 @@ def _gn_partials_of(x, groups, c, rows_per_inst):
     return gn
 
 
+def duplicate_rows(t):
+    """[t; t] along the row axis (classifier-free guidance: one evaluation of the text-free head serves both batch
+    entries).  Statistics partials riding on `t` are duplicated with it, so the GroupNorm that follows sees exactly what
+    it would have seen after evaluating the head on the duplicated batch."""
+    out = torch.cat([t, t])
+    gn = getattr(t, "_uav_gn", None)
+    if gn is not None and gn.version == t._version:
+        _gn_attach(out, GnPartials(torch.cat([gn.ws, gn.ws], dim=-1), gn.rows, gn.groups, gn.c))
+    return out
+
+
 def _gn_dtype(x1, x2):
     """GroupNorm inputs are fp16 rows, or fp32 rows (fp32 residual stream of the VAE decoder); both sources alike."""
     if x1.dtype not in (HALF, torch.float32):
