@@ -20,7 +20,7 @@ rd = (c["TCC_EA0_RDREQ_sum"] - c.get("TCC_EA0_RDREQ_32B_sum", 0)) * 128 + c.get(
 wr = c.get("TCC_EA0_WRREQ_64B_sum", 0) * 64 + (c["TCC_EA0_WRREQ_sum"] - c.get("TCC_EA0_WRREQ_64B_sum", 0)) * 32
 out = {"command": "rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum -- "
                   "python bench.py --no-cpu-baseline --no-kernel-events --warmup 0 --steps 1",
-       "kernels": "conv_gemm_kernel<*>, conv_gemm256_kernel<0>", "launches": launches, "counters": c,
+       "kernels": "conv_gemm_kernel<*>, conv_gemm256i_kernel<1, *> (all fp16 implicit-GEMM launches)", "launches": launches, "counters": c,
        "read_bytes_per_launch": rd / launches, "write_bytes_per_launch": wr / launches,
        "hbm_bytes_per_launch": (rd + wr) / launches}
 json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_conv_traffic.json"), "w"), indent=1)
