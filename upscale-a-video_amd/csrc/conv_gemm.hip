@@ -1214,267 +1214,16 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
     conv_epilogue<4, 2, GNK>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);
 }
 
-// ---------------------------------------------------------------------------------------------
-// 256x256 tile with a HALOED X image (UAV_CONV_HALO): for (., 3)-wide kernels at stride 1 the three dx taps of one
-// (channel block, dt, dy) read the same pixels shifted by one, so the block keeps ONE image of 258 pixel rows
-// (flattened output pixels m0-1 .. m0+256 at that dt, dy) in LDS for three k-steps instead of fetching three shifted
-// 256-row tiles: -67 % of the X stream, -33 % of all LDS-DMA bytes and instructions of the layer.  A wave reads the X
-// fragment of pixel m at tap dx from image row (m - m0 + dx) — 128 bytes further per dx, with that row's swizzle phase —
-// and the lanes whose pixel sits on the left (dx = 0) / right (dx = 2) image edge point their fragment address at a row
-// of zeros instead (the neighbour in the flattened order belongs to another image row).  Those zero rows come for free:
-// the image is 258 rows = four 64-row DMA pieces + a 1-KiB tail piece (wave 0) whose last 6 rows read the zero page.
-// Everything else — W stream, k order (tap-innermost), hand-scheduled k-step, epilogues — is conv_gemm256i_kernel<1>,
-// so the results are bit-identical to it (tools/conv_digest.py).
-constexpr int HX_ROWS = 264;                        // 258 image rows + the 6 zero rows of the tail piece
-constexpr int HX_BYTES = HX_ROWS * 128;             // 33 792 B per image buffer
-constexpr int HSMEM = 2 * LA_BYTES + 2 * HX_BYTES;  // 2 W stages + 2 X images = 133 120 B
-
-template <int GNK = 0>
-__global__ __launch_bounds__(512, 2) void conv_gemm256h_kernel(ConvArgs p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hi32 = lane >> 5, l32 = lane & 31;
-
-    const unsigned n_tiles = p.n_pad / LN;
-    const int slot_log = (tid & 7) ^ ((tid >> 4) & 7);
-    const int rbase = tid >> 3;                          // 0..63
-    const int hw_o = p.ho * p.wo;
-
-    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
-    unsigned mt = tile / n_tiles;
-    const unsigned nt = tile - mt * n_tiles;
-    if (p.kt > 1 && p.tile_order) {                      // frame-fastest tile order for temporal taps (conv_gemm256_kernel)
-        const unsigned hw_ = (unsigned)hw_o;
-        if (hw_ % LM == 0) {
-            const unsigned S_ = hw_ / LM, per_clip_ = S_ * (unsigned)p.t_len;
-            const unsigned c_ = mt / per_clip_, r_ = mt - c_ * per_clip_;
-            const unsigned sp_ = r_ / (unsigned)p.t_len, t_ = r_ - sp_ * (unsigned)p.t_len;
-            mt = c_ * per_clip_ + t_ * S_ + sp_;
-        }
-    }
-    const long long m0 = (long long)mt * LM;
-    const int n0 = nt * LN;
-
-    // image rows this thread fetches: r = ps*64 + rbase (ps 0..3) and, in wave 0's tail piece, r = 256 + (lane >> 3);
-    // image row r holds flattened output pixel q = m0 - 1 + r
-    int rimg[5], rtl[5], rys[5], rxs[5];
-#pragma unroll
-    for (int ps = 0; ps < 5; ++ps) {
-        const int r = ps < 4 ? ps * 64 + rbase : 256 + (lane >> 3);
-        const long long q = m0 - 1 + r;
-        const bool ok_ = q >= 0 && q < p.M && r < 258;
-        const int qq = ok_ ? (int)q : 0;
-        const int im_ = qq / hw_o; const int rem_ = qq - im_ * hw_o;
-        const int yo_ = rem_ / p.wo; const int xo_ = rem_ - yo_ * p.wo;
-        rimg[ps] = im_ - p.pad_t; rtl[ps] = im_ % p.t_len - p.pad_t;
-        rys[ps] = ok_ ? yo_ - p.pad_h : -(1 << 28); rxs[ps] = xo_;
-    }
-    const int cin = p.c1 + p.c2;
-    const int ntaps = p.kt * p.kh * 3;
-    const int nk = p.k_pad / BK;
-    const int nimg = nk / 3;
-    const char* wtile = p.w + (long long)n0 * p.k_pad * 2;
-    const long long wps = 64ll * p.k_pad * 2;
-    const unsigned woff = (unsigned)(((long long)rbase * p.k_pad + slot_log * 8) * 2);
-
-    // ---- wave tile, fragment addressing ---------------------------------------------------------------
-    const int wn = wave & 1, wm = wave >> 1;
-    bool edgeL[2], edgeR[2];                             // this lane's two pixels (mi = 0, 1) on the left / right image edge
-#pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
-        const long long m_ = m0 + wm * 64 + mi * 32 + l32;
-        const int mm_ = m_ < p.M ? (int)m_ : 0;
-        const int xo_ = mm_ % p.wo;
-        edgeL[mi] = xo_ == 0; edgeR[mi] = xo_ == p.wo - 1;
-    }
-    float16_t acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const int sw = (l32 >> 1) & 7;
-    const unsigned ldsb = (unsigned)(size_t)(lptr_t)smem;
-    const unsigned ldsX = ldsb + 2 * LA_BYTES;           // image buffer b at ldsX + b * HX_BYTES
-    const unsigned bW = ldsb + (wn * 128 + l32) * 128;   // + stage * LA_BYTES + ni * 4096
-    unsigned so[4];
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) so[kk] = ((kk * 2 + hi32) ^ sw) << 4;
-    const unsigned xrow = (unsigned)((wm * 64 + l32) * 128);      // + dx * 128 + mi * 4096 inside the image
-
-    // ---- X piece addressing ------------------------------------------------------------------------------
-    int xkc = 0, xdt = 0, xdy = 0;                       // wave-uniform: (channel block, dt, dy) of the image being fetched
-#define HXADDR(PS, G)                                                                                        \
-    {                                                                                                        \
-        const bool first = xkc < p.c1;                                                                       \
-        const char* xsrc = first ? p.a1 : p.a2;                                                              \
-        const int xcs = first ? p.c1 : p.c2;                                                                 \
-        const int xcoff = (first ? xkc : xkc - p.c1) + slot_log * 8;                                         \
-        const int tt = rtl[PS] + xdt, yv = rys[PS] + xdy;                                                    \
-        const bool ok = ((unsigned)tt < (unsigned)p.t_len) & ((unsigned)yv < (unsigned)p.hi);                \
-        const int px = ((rimg[PS] + xdt) * p.hi + yv) * p.wi + rxs[PS];                                      \
-        const long long d = (xsrc - p.zero_page) + ((long long)px * xcs + xcoff) * 2;                        \
-        G = p.zero_page + (ok ? d : 0ll);                                                                    \
-    }
-#define HNEXT_IMAGE() { if (++xdy == p.kh) { xdy = 0; if (++xdt == p.kt) { xdt = 0; xkc += BK; } } }
-    int ktap = 0, kc = 0;                                // W: tap / channel offset of the NEXT stage to address (tap-innermost)
-    long long wkb;
-#define HNEXT_W() { wkb = ((long long)ktap * cin + kc) * 2; if (++ktap == ntaps) { ktap = 0; kc += BK; } }
-
-    // LDS-DMA slots.  M0 carries the wave-uniform LDS destination; it is compiler-reserved: saved and restored.
-#define HDX(I) "s_cmp_lg_u32 %[px" #I "], 0\n" "s_cbranch_scc0 .Lhx%=_" #I "\n" "s_mov_b32 m0, %[lx" #I "]\n" "s_nop 0\n" \
-               "global_load_lds_dwordx4 %[gx" #I "], off\n" ".Lhx%=_" #I ":\n"
-#define HDW(I, OFF) "s_cbranch_vccz .Lhw%=_" #I "\n" "s_add_u32 m0, %[ldsn], " #OFF "\n" "s_nop 0\n" "global_load_lds_dwordx4 %[woff], %[gw" #I "]\n" ".Lhw%=_" #I ":\n"
-#define HXA HDX(a)
-#define HXB HDX(b)
-#define HW0 HDW(0, 0)
-#define HW1 HDW(1, 8192)
-#define HW2 HDW(2, 16384)
-#define HW3 HDW(3, 24576)
-#define NO ""
-
-    // ---- prologue: image 0 (5 pieces) and W stage 0 ---------------------------------------------------------
-    {
-        const char* g0; const char* g1; const char* g2; const char* g3; const char* g4;
-        HXADDR(0, g0) HXADDR(1, g1) HXADDR(2, g2) HXADDR(3, g3) HXADDR(4, g4)
-        HNEXT_IMAGE()
-        HNEXT_W()
-        const char* gw0 = wtile + wkb; const char* gw1 = gw0 + wps; const char* gw2 = gw1 + wps; const char* gw3 = gw2 + wps;
-        const unsigned ldsn = ldsb + wave * 1024;
-        const unsigned lx = ldsX + wave * 1024;
-        const unsigned tail = __builtin_amdgcn_readfirstlane(wave == 0 ? 1u : 0u);
-        unsigned m0s;
-        asm volatile("s_mov_b32 %[m0s], m0\n"
-                     "s_mov_b32 m0, %[lx]\n s_nop 0\n global_load_lds_dwordx4 %[g0], off\n"
-                     "s_add_u32 m0, %[lx], 8192\n s_nop 0\n global_load_lds_dwordx4 %[g1], off\n"
-                     "s_add_u32 m0, %[lx], 16384\n s_nop 0\n global_load_lds_dwordx4 %[g2], off\n"
-                     "s_add_u32 m0, %[lx], 24576\n s_nop 0\n global_load_lds_dwordx4 %[g3], off\n"
-                     "s_cmp_lg_u32 %[tail], 0\n s_cbranch_scc0 .Lht%=\n"
-                     "s_add_u32 m0, %[lx], 32768\n s_nop 0\n global_load_lds_dwordx4 %[g4], off\n"
-                     ".Lht%=:\n"
-                     "s_mov_b32 m0, %[ldsn]\n s_nop 0\n global_load_lds_dwordx4 %[woff], %[gw0]\n"
-                     "s_add_u32 m0, %[ldsn], 8192\n s_nop 0\n global_load_lds_dwordx4 %[woff], %[gw1]\n"
-                     "s_add_u32 m0, %[ldsn], 16384\n s_nop 0\n global_load_lds_dwordx4 %[woff], %[gw2]\n"
-                     "s_add_u32 m0, %[ldsn], 24576\n s_nop 0\n global_load_lds_dwordx4 %[woff], %[gw3]\n"
-                     "s_mov_b32 m0, %[m0s]\n"
-                     : [m0s] "=&s"(m0s)
-                     : [g0] "v"(g0), [g1] "v"(g1), [g2] "v"(g2), [g3] "v"(g3), [g4] "v"(g4), [woff] "v"(woff),
-                       [gw0] "s"(gw0), [gw1] "s"(gw1), [gw2] "s"(gw2), [gw3] "s"(gw3), [ldsn] "s"(ldsn), [lx] "s"(lx), [tail] "s"(tail)
-                     : "memory", "scc");
-    }
-    if (nk > 1) HNEXT_W()
-    // pieces issued in k-step 0 (d = 0): rows 0..127 of image 1
-    const char* gxa; const char* gxb;
-    HXADDR(0, gxa) HXADDR(1, gxb)
-
-#define RD(D, A, OFF) "ds_read_b128 %[" #D "], %[" #A "] offset:" #OFF "\n"
-#define RDSET(S, A, XA, XB) RD(w##S##0, A, 0) RD(x##S##0, XA, 0) RD(x##S##1, XB, 0) RD(w##S##1, A, 4096) RD(w##S##2, A, 8192) RD(w##S##3, A, 12288)
-#define MF(C, A, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #A "], %[" #B "], %[" #C "]\n"
-#define WT(N) "s_waitcnt lgkmcnt(" #N ")\n"
-#define MFSETD(S, N0, N1, N2, N3, N4, SA, SB, SC, SD)                                          \
-    WT(N0) MF(c00, w##S##0, x##S##0) WT(N1) MF(c01, w##S##0, x##S##1) SA                       \
-    WT(N2) MF(c10, w##S##1, x##S##0) MF(c11, w##S##1, x##S##1) SB                              \
-    WT(N3) MF(c20, w##S##2, x##S##0) MF(c21, w##S##2, x##S##1) SC                              \
-    WT(N4) MF(c30, w##S##3, x##S##0) MF(c31, w##S##3, x##S##1) SD
-
-    int cur = 0;                                         // W stage of this k-step
-    int d = 0, img = 0;                                  // dx index of this k-step, image it reads
-    int xi = 1;                                          // image whose pieces are in flight (its coordinates are xkc, xdt, xdy)
-    for (int ks = 0; ks < nk; ++ks) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        // fragment addresses of this k-step
-        const unsigned wb = bW + cur * LA_BYTES;
-        const unsigned aw0 = wb + so[0], aw1 = wb + so[1], aw2 = wb + so[2], aw3 = wb + so[3];
-        const unsigned xim = ldsX + (img & 1) * HX_BYTES;
-        const unsigned key = (unsigned)((l32 + d) >> 1) & 7u;
-        const unsigned rowb = xim + xrow + d * 128;
-        const unsigned zrow = xim + 258 * 128 + hi32 * 16;
-        const bool e0 = d == 0 ? edgeL[0] : d == 2 ? edgeR[0] : false;
-        const bool e1 = d == 0 ? edgeL[1] : d == 2 ? edgeR[1] : false;
-        unsigned xa[4], xb[4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const unsigned sx = ((kk * 2 + hi32) ^ key) << 4;
-            xa[kk] = e0 ? zrow + kk * 32 : rowb + sx;
-            xb[kk] = e1 ? zrow + kk * 32 : rowb + 4096 + sx;
-        }
-        half8_t w00, w01, w02, w03, x00, x01, w10, w11, w12, w13, x10, x11;
-        const char* gw0 = wtile + wkb; const char* gw1 = gw0 + wps; const char* gw2 = gw1 + wps; const char* gw3 = gw2 + wps;
-        const unsigned ldsn = ldsb + (cur ^ 1) * LA_BYTES + wave * 1024;
-        const unsigned dodma = __builtin_amdgcn_readfirstlane(ks + 1 < nk ? 1u : 0u);
-        // X slots of this k-step: d = 0 -> pieces 0, 1; d = 1 -> pieces 2, 3; d = 2 -> the tail piece (wave 0 only)
-        const unsigned xbuf = ldsX + (xi & 1) * HX_BYTES + wave * 1024;
-        const bool more = xi < nimg;
-        const unsigned pxa = __builtin_amdgcn_readfirstlane((more && (d < 2 || wave == 0)) ? 1u : 0u);
-        const unsigned pxb = __builtin_amdgcn_readfirstlane((more && d < 2) ? 1u : 0u);
-        const unsigned lxa = __builtin_amdgcn_readfirstlane(xbuf + (d == 0 ? 0u : d == 1 ? 16384u : 32768u));
-        const unsigned lxb = __builtin_amdgcn_readfirstlane(xbuf + (d == 0 ? 8192u : 24576u));
-        unsigned m0s;
-        asm volatile("s_mov_b32 %[m0s], m0\n" "s_cmp_lg_u32 %[dodma], 0\n" "s_cselect_b64 vcc, -1, 0\n"
-                     "s_waitcnt lgkmcnt(0)\n" RDSET(0, aw0, xa0, xb0) RDSET(1, aw1, xa1, xb1) HXA HXB
-                     MFSETD(0, 10, 9, 8, 7, 6, HW0, HW1, HW2, HW3) RDSET(0, aw2, xa2, xb2)
-                     MFSETD(1, 10, 9, 8, 7, 6, NO, NO, NO, NO) RDSET(1, aw3, xa3, xb3)
-                     MFSETD(0, 10, 9, 8, 7, 6, NO, NO, NO, NO) MFSETD(1, 4, 3, 2, 1, 0, NO, NO, NO, NO)
-                     "s_mov_b32 m0, %[m0s]\n"
-                     : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]),
-                       [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]), [c30] "+v"(acc[3][0]), [c31] "+v"(acc[3][1]),
-                       [w00] "=&v"(w00), [w01] "=&v"(w01), [w02] "=&v"(w02), [w03] "=&v"(w03), [x00] "=&v"(x00), [x01] "=&v"(x01),
-                       [w10] "=&v"(w10), [w11] "=&v"(w11), [w12] "=&v"(w12), [w13] "=&v"(w13), [x10] "=&v"(x10), [x11] "=&v"(x11),
-                       [m0s] "=&s"(m0s)
-                     : [aw0] "v"(aw0), [aw1] "v"(aw1), [aw2] "v"(aw2), [aw3] "v"(aw3),
-                       [xa0] "v"(xa[0]), [xa1] "v"(xa[1]), [xa2] "v"(xa[2]), [xa3] "v"(xa[3]),
-                       [xb0] "v"(xb[0]), [xb1] "v"(xb[1]), [xb2] "v"(xb[2]), [xb3] "v"(xb[3]),
-                       [gxa] "v"(gxa), [gxb] "v"(gxb), [woff] "v"(woff),
-                       [gw0] "s"(gw0), [gw1] "s"(gw1), [gw2] "s"(gw2), [gw3] "s"(gw3), [ldsn] "s"(ldsn), [dodma] "s"(dodma),
-                       [pxa] "s"(pxa), [pxb] "s"(pxb), [lxa] "s"(lxa), [lxb] "s"(lxb)
-                     : "memory", "scc", "vcc");
-        // bookkeeping + addresses of the NEXT k-step's DMA pieces (VALU beside the matrix pipe's drain)
-        if (ks + 2 < nk) HNEXT_W()
-        cur ^= 1;
-        if (++d == 3) { d = 0; ++img; ++xi; HNEXT_IMAGE() }
-        if (xi < nimg) {
-            if (d == 0) { HXADDR(0, gxa) HXADDR(1, gxb) }
-            else if (d == 1) { HXADDR(2, gxa) HXADDR(3, gxb) }
-            else { HXADDR(4, gxa) }
-        }
-    }
-#undef RD
-#undef RDSET
-#undef MF
-#undef WT
-#undef MFSETD
-#undef HDX
-#undef HDW
-#undef HXA
-#undef HXB
-#undef HW0
-#undef HW1
-#undef HW2
-#undef HW3
-#undef NO
-#undef HXADDR
-#undef HNEXT_IMAGE
-#undef HNEXT_W
-    asm volatile("s_nop 15\ns_nop 15" ::: "memory");     // the last MFMAs may still be in flight (see conv_gemm256_kernel)
-    conv_epilogue<4, 2, GNK>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);
-}
-
 }  // namespace
 
 namespace {
-struct ConvEnv { int korder, tile_order, force_tile, dbg, persist, dmav, halo; };
+struct ConvEnv { int korder, tile_order, force_tile, dbg, persist, dmav; };
 const ConvEnv& conv_env() {
     // Environment switches (development A/B only) are read once through a thread-safe magic static.
     static const ConvEnv env = [] {
         auto geti = [](const char* k, int d) { const char* e = getenv(k); return e ? atoi(e) : d; };
         return ConvEnv{geti("UAV_CONV_KORDER", 1), geti("UAV_CONV_TILE_ORDER", 1), geti("UAV_CONV_TILE", 0),
-                       geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0), geti("UAV_CONV_DMAV", 1),
-                       geti("UAV_CONV_HALO", 0)};
+                       geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0), geti("UAV_CONV_DMAV", 1)};
     }();
     return env;
 }
@@ -1581,25 +1330,13 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
                                  (const void*)conv_gemm256i_kernel<3>, (const void*)conv_gemm256i_kernel<1, 1>,
                                  (const void*)conv_gemm256i_kernel<1, 2>, (const void*)conv_gemm256i_kernel<1, 3>};
             for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
-            const void* hfns[] = {(const void*)conv_gemm256h_kernel<0>, (const void*)conv_gemm256h_kernel<1>,
-                                  (const void*)conv_gemm256h_kernel<2>, (const void*)conv_gemm256h_kernel<3>};
-            for (const void* f : hfns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, HSMEM);
             hipDeviceProp_t prop;
             dev_ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
         });
         const long long ncu = dev_ncu[dev];
         const int dbg = env.dbg, persist = env.persist;
         a.ntiles = (unsigned)grid256;
-        // haloed X image: (., 3)-wide kernels at stride 1 with symmetric width padding, tap-innermost K order
-        const bool halo = env.halo && dbg == 0 && q->kw == 3 && q->pad_w == 1 && q->stride == 1 && !q->upsample &&
-                          q->wo == q->wi && a.korder == 1;
-        if (halo) {
-            const int gnm = a.gn_ws ? gn_mode_of(a.gn_cpg_log2) : 0;
-            if (gnm == 0) hipLaunchKernelGGL(conv_gemm256h_kernel<0>, dim3((unsigned)grid256), dim3(512), HSMEM, s, a);
-            else if (gnm == 1) hipLaunchKernelGGL(conv_gemm256h_kernel<1>, dim3((unsigned)grid256), dim3(512), HSMEM, s, a);
-            else if (gnm == 2) hipLaunchKernelGGL(conv_gemm256h_kernel<2>, dim3((unsigned)grid256), dim3(512), HSMEM, s, a);
-            else hipLaunchKernelGGL(conv_gemm256h_kernel<3>, dim3((unsigned)grid256), dim3(512), HSMEM, s, a);
-        } else if (a.gn_ws) {              // statistics-reducing instances of the production kernel (env A/B switches do not apply)
+        if (a.gn_ws) {                     // statistics-reducing instances of the production kernel (env A/B switches do not apply)
             const int gnm = gn_mode_of(a.gn_cpg_log2);
             if (gnm == 1) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 1>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
             else if (gnm == 2) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 2>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
