@@ -93,6 +93,11 @@ typedef struct {
      * the statistics pass over `out`.  NULL / 0: off (uav_conv_gemm_f32 ignores both). */
     void*        gn_partials;
     int32_t      gn_groups;
+    /* Strided output rows (the four sub-pixel phases of "nearest 2x, then 3x3 conv", resnet.py:144-158, each a 2x2 conv on
+     * the low-resolution input — 16 instead of 36 multiply-adds per output pixel and channel pair): with out_map_w > 0
+     * output row m = Y*out_map_w + x (x < out_map_w) is stored at row Y*out_map_sy + x*out_map_sx + out_map_off of `out`
+     * instead of row m.  residual and gn_partials must be NULL, no GEGLU.  0: rows in order. */
+    int32_t      out_map_w, out_map_sy, out_map_sx, out_map_off;
 } uav_conv_params;
 
 int uav_conv_gemm_f16(const uav_conv_params* p, void* stream);

@@ -23,7 +23,8 @@ def _h(x):
 
 # ---------------------------------------------------------------------------------------------------------------------
 def conv_gemm(a1, wt, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None, rowbias=None, rows_per_batch=0,
-              residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None, persistent=False, act=None, gn_groups=None):
+              residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None, persistent=False, act=None, gn_groups=None,
+              out_map=None):
     c1 = a1.shape[-1]
     c2 = 0 if a2 is None else a2.shape[-1]
     assert c1 + c2 == wt.cin_p, (c1, c2, wt.cin_p)
@@ -70,6 +71,11 @@ def conv_gemm(a1, wt, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=Fals
         y = y + residual.float()[:, : y.shape[1]]
     y = y * out_scale
     res = y if out_f32 else _h(y)
+    if out_map is not None:                  # strided output rows (sub-pixel phases of the upsampling convs)
+        w_, sy, sx, off = out_map
+        mm = torch.arange(res.shape[0])
+        out[(mm // w_) * sy + (mm % w_) * sx + off, : res.shape[1]] = res
+        return out
     if out is not None:                      # the kernel writes n_out columns of a possibly wider row (out_stride)
         out[:, : res.shape[1]].copy_(res)
         return out

@@ -380,6 +380,9 @@ def test_cabi_rejects_bad_arguments_without_touching_the_gpu():
     assert gn_rows(rowbias=P, rows_per_batch=100, rowbias_stride=512) == 0          # a wave tile would straddle batches
     assert gn_rows(flags=1, n=1024, n_pad=1024) == 0                                # GEGLU
     assert conv(**{**big, 'gn_partials': P, 'gn_groups': 48}) == ESHAPE                       # request that cannot be honoured
+    assert gn_rows(out_map_w=64, out_map_sy=256, out_map_sx=2) == 0                 # strided output rows: no chunk runs
+    assert conv(out_map_w=8, out_map_sy=32, out_map_sx=2, residual=P, res_stride=128) == ESHAPE   # row map excludes a residual
+    assert conv(out_map_w=8, out_map_sy=32, out_map_sx=0) == ESHAPE and conv(out_map_w=-1) == ESHAPE
     assert lib.uav_groupnorm_finalize_partials(None, 8, 64, 64, 1, 512, 32, 1e-5, None, None, P, P, None) == EINVAL
     assert lib.uav_groupnorm_finalize_partials(P, 8, 64, 64, 1, 500, 32, 1e-5, None, None, P, P, None) == ESHAPE   # rows % 64
     assert lib.uav_groupnorm_finalize_partials(P, 9, 64, 64, 1, 512, 32, 1e-5, None, None, P, P, None) == ESHAPE   # chunk count
@@ -399,6 +402,38 @@ def test_cabi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.uav_temporal_attention_f16(P, P, 1, 9, 16, 512, 8, 0.125, P, P, 32, P, None) == ESHAPE
     assert lib.uav_resize_bilinear_f32(None, P, 1, 4, 4, 8, 8, 1.0, 1.0, None) == EINVAL
     assert lib.uav_version() > 0
+
+
+def test_upsample_phase_weights_identity():
+    """"nearest 2x, then 3x3 conv (pad 1)" == four 2x2 sub-pixel phase convs (ops.upsample_phase_weights), exactly in exact
+    arithmetic: checked in fp64 against F.interpolate + F.conv2d, borders included, and through the CPU stand-in of the
+    kernel with its strided output rows (the call Upsample3D.run makes)."""
+    import torch.nn.functional as F
+    from uav import ops
+    import cpu_ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 5, 7, generator=g, dtype=torch.float64)
+    w = torch.randn(8, 64, 3, 3, generator=g, dtype=torch.float64)
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), w, padding=1)
+    ph = ops.upsample_phase_weights(w.float())
+    out = torch.zeros_like(ref)
+    for py in range(2):
+        for px in range(2):
+            xp = F.pad(x, (1 - px, px, 1 - py, py))                      # left/right, top/bottom: taps past the edge are zero
+            out[:, :, py::2, px::2] = F.conv2d(xp, ph[py][px].double())
+    assert (out - ref).abs().max().item() < 1e-5
+    # the stand-in of the kernel call (fp16 rows in, fp32 rows out)
+    rows = x.permute(0, 2, 3, 1).reshape(-1, 64).half()
+    o = torch.zeros(2 * 10 * 14, 8)
+    for py in range(2):
+        for px in range(2):
+            cw = ops.pack_conv(ph[py][px], None, n_store_align=4)
+            cpu_ops.conv_gemm(rows, cw, n_img=2, t_len=1, hi=5, wi=7, pad=(0, 1 - py, 1 - px), out_hw=(5, 7), out_f32=True,
+                              out=o, out_map=(7, 28, 2, py * 14 + px))
+    ref16 = F.conv2d(F.interpolate(rows.float().reshape(2, 5, 7, 64).permute(0, 3, 1, 2), scale_factor=2.0, mode="nearest"),
+                     w.float(), padding=1)
+    got = o.reshape(2, 10, 14, 8).permute(0, 3, 1, 2)
+    assert ((got - ref16).norm() / ref16.norm()).item() < 2e-3             # fp16 rounding of the packed phase weights
 
 
 def test_geglu_packing_order():

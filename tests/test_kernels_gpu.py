@@ -492,3 +492,31 @@ def test_conv_fused_groupnorm_statistics_not_offered(ops, dev):
     cw3 = ops.pack_conv(h16(128, 64, 1, 1, 1, dev=dev, scale=0.1, gen=g), torch.zeros(128), device=dev)
     y3 = ops.conv_gemm(x2, cw3, n_img=4, t_len=1, hi=128, wi=64, gn_groups=32)       # 128 outputs: n_pad = 128 -> 128x128 kernel
     assert getattr(y3, "_uav_gn", None) is None
+
+
+# ------------------------------------------------------------------------------------------------
+# "nearest 2x + 3x3 conv" as four 2x2 sub-pixel phase convs with strided output rows (uav_conv_params.out_map_*)
+@pytest.mark.parametrize("cin,cout,n_img,t_len,h,w,f32", [(64, 128, 2, 1, 9, 11, False), (128, 256, 4, 2, 48, 40, False),
+                                                           (256, 256, 6, 3, 64, 64, True)])
+def test_upsample_as_subpixel_phase_convs(ops, dev, cin, cout, n_img, t_len, h, w, f32):
+    """Same result as the fused-gather upsampling conv (rel-L2 < 1e-3: only the fp16 rounding of the summed taps differs)
+    and as the torch reference F.interpolate(nearest) + conv2d (< 2e-3 fp16 / 1e-3 fp32 rows out); small, tail and
+    256x256-tile shapes."""
+    g = torch.Generator().manual_seed(cin + h)
+    x4 = h16(n_img, cin, h, w, dev=dev, gen=g)
+    wt = h16(cout, cin, 3, 3, dev=dev, scale=(9 * cin) ** -0.5, gen=g)
+    bias = torch.randn(cout, generator=g).to(dev)
+    ref = F.conv2d(F.interpolate(x4, scale_factor=2.0, mode="nearest"), wt, bias, padding=1)
+    rows = to_rows(x4)
+    fused = ops.conv_gemm(rows, ops.pack_conv(wt[:, :, None], bias, device=dev), n_img=n_img, t_len=t_len, hi=h, wi=w,
+                          upsample=True, out_f32=f32)
+    ph = ops.upsample_phase_weights(wt)
+    out = torch.full((n_img * 4 * h * w, cout), float("nan"), dtype=torch.float32 if f32 else torch.float16, device=dev)
+    for py in range(2):
+        for px in range(2):
+            ops.conv_gemm(rows, ops.pack_conv(ph[py][px], bias, device=dev), n_img=n_img, t_len=t_len, hi=h, wi=w,
+                          pad=(0, 1 - py, 1 - px), out_hw=(h, w), out_f32=f32, out=out, out_map=(w, 4 * w, 2, py * 2 * w + px))
+    assert bool(torch.isfinite(out).all()), "a phase left output rows unwritten"
+    y = from_rows(out, n_img, 2 * h, 2 * w)
+    assert rel_l2(y, ref) < (1e-3 if f32 else 2e-3)
+    assert rel_l2(out, fused) < 1e-3

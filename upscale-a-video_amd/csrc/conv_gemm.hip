@@ -46,7 +46,16 @@ struct ConvArgs {
     int korder, tile_order;
     unsigned ntiles;
     float* gn_ws; int gn_groups, gn_cpg_log2; long long gn_chunks;     // fused GroupNorm statistics (see conv_gn_store)
+    int omw, omsy, omsx, omoff;                                        // strided output rows (uav_conv_params.out_map_*)
 };
+
+// Output row of GEMM row m: m itself, or the strided placement of a sub-pixel phase (one integer division per lane and row
+// block, only on the launches that ask for it).
+UAV_DEVINL long long out_row(const ConvArgs& p, long long m) {
+    if (!p.omw) return m;
+    const int mi = (int)m, Y = mi / p.omw, x = mi - Y * p.omw;
+    return (long long)Y * p.omsy + (long long)x * p.omsx + p.omoff;
+}
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -196,7 +205,7 @@ UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], 
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
         const long long m = mw0 + mi * 32 + l32;
-        orow[mi] = p.out + (m * p.out_stride + nw0 + 8 * hi32) * 2;
+        orow[mi] = p.out + (out_row(p, m) * p.out_stride + nw0 + 8 * hi32) * 2;
         rrow[mi] = RES ? p.residual + (m * p.res_stride + nw0 + 8 * hi32) * 2 : nullptr;
     }
     const float* bptr = BIAS ? p.bias + nw0 + 4 * hi32 : nullptr;
@@ -294,7 +303,7 @@ UAV_DEVINL void conv_epilogue_f32_fast(const ConvArgs& p, float16_t (&acc)[NI][M
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const long long m = mw0 + mi * 32 + l32;
-            float* orow = (float*)p.out + m * p.out_stride + nw0 + ni * 32 + 4 * hi32;
+            float* orow = (float*)p.out + out_row(p, m) * p.out_stride + nw0 + ni * 32 + 4 * hi32;
             const float* rrow = RES ? (const float*)p.residual + m * p.res_stride + nw0 + ni * 32 + 4 * hi32 : nullptr;
             float4_t R[4];
             if (RES) {
@@ -440,6 +449,7 @@ UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long 
         const long long m = mw0 + mi * 32 + l32;
         const bool mok = m < p.M;
         const long long mc = mok ? m : 0;
+        const long long mo = out_row(p, mc);
         const float* rb = p.rowbias ? p.rowbias + (long long)((int)mc / p.rows_per_batch) * p.rowbias_stride : nullptr;
         if (geglu) {
             // packed rows come in blocks of [32 value | 32 gate]: tile pair (2b, 2b+1)
@@ -519,7 +529,7 @@ UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long 
                     swap_pair(A[0], B[0]); swap_pair(A[1], B[1]);
                     if (mok) {
                         uint4_t v = {A[0], A[1], B[0], B[1]};
-                        *(uint4_t*)(p.out + ((long long)m * p.out_stride + nl) * 2) = v;
+                        *(uint4_t*)(p.out + (mo * p.out_stride + nl) * 2) = v;
                     }
                 } else {
 #pragma unroll
@@ -560,10 +570,10 @@ UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long 
                         for (int j = 0; j < 4; ++j) v[j] *= p.out_scale;
                         if (of32) {
                             float4_t o = {v[0], v[1], v[2], v[3]};
-                            *(float4_t*)(p.out + ((long long)m * p.out_stride + n) * 4) = o;
+                            *(float4_t*)(p.out + (mo * p.out_stride + n) * 4) = o;
                         } else {
                             half4_t o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                            *(half4_t*)(p.out + ((long long)m * p.out_stride + n) * 2) = o;
+                            *(half4_t*)(p.out + (mo * p.out_stride + n) * 2) = o;
                         }
                     }
                 }
@@ -1238,7 +1248,7 @@ bool conv_uses_big_tile(const uav_conv_params* q) {
 // Fused GroupNorm statistics are produced by the fast epilogues of the 256x256 kernel only: every wave tile (64 rows x
 // 128 channels) must lie inside M x N and qualify for a fast path, and a group must not straddle wave tiles.
 int conv_gn_cpg_log2(const uav_conv_params* q) {
-    if (q->gn_groups <= 0 || (q->n % q->gn_groups)) return -1;
+    if (q->gn_groups <= 0 || (q->n % q->gn_groups) || q->out_map_w) return -1;     // chunks are runs of consecutive output rows
     const int cpg = q->n / q->gn_groups;
     int cl = -1;
     for (int k = 2; k <= 7; ++k) if (cpg == (1 << k)) cl = k;
@@ -1296,6 +1306,13 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     a.zero_page = (const char*)q->zero_page;
     a.M = (long long)q->n_img * q->ho * q->wo;
     if (a.M <= 0 || a.M >= (1ll << 31)) return UAV_ESHAPE;
+    a.omw = 0; a.omsy = 0; a.omsx = 0; a.omoff = 0;
+    if (q->out_map_w > 0) {
+        if (q->residual || q->gn_partials || (q->flags & UAV_CONV_GEGLU) || q->out_map_sy < 0 || q->out_map_sx <= 0 ||
+            q->out_map_off < 0)
+            return UAV_ESHAPE;
+        a.omw = q->out_map_w; a.omsy = q->out_map_sy; a.omsx = q->out_map_sx; a.omoff = q->out_map_off;
+    } else if (q->out_map_w < 0) return UAV_ESHAPE;
     a.gn_ws = nullptr; a.gn_groups = 0; a.gn_cpg_log2 = 0; a.gn_chunks = 0;
     if (q->gn_partials) {
         const int cl = conv_gn_cpg_log2(q);

@@ -16,11 +16,18 @@ compute is the HIP kernel library libuav_hip.so:
 Modules run on channels-last fp16 rows `[B*T*H*W][C]` (`run(...)`); `forward(...)` keeps the
 reference's (B,C,T,H,W) tensor signature for API parity and converts at the edge.
 """
+import os
+
 import torch
 import torch.nn as nn
 
 from uav import engine as E
 from uav import ops
+
+
+# "nearest 2x + 3x3 conv" as four 2x2 sub-pixel phase convs (2.25x fewer multiply-adds; ops.upsample_phase_weights).
+# UAV_PHASE_UPSAMPLE=0 keeps the fused-gather form (upsampling folded into the 3x3 conv's addressing).
+PHASE_UPSAMPLE = os.environ.get("UAV_PHASE_UPSAMPLE", "1") != "0"
 
 
 def _temb_rows(mod, temb):
@@ -87,7 +94,18 @@ class Upsample3D(E.EngineModule):
         s32 = x.dtype == torch.float32           # fp32 residual stream (VAE decoder): x is also this conv's operand
         x = ops.cast_f16(x)
         if output_size is None or tuple(output_size[-2:]) == (2 * g.h, 2 * g.w):
-            return conv.run(x, g, upsample=True, out_f32=s32, gn_groups=E.GN_GROUPS_HINT), g.with_hw(2 * g.h, 2 * g.w)
+            g2 = g.with_hw(2 * g.h, 2 * g.w)
+            if not PHASE_UPSAMPLE or tuple(conv.kernel_size) != (3, 3) or tuple(conv.padding) != (1, 1):
+                return conv.run(x, g, upsample=True, out_f32=s32, gn_groups=E.GN_GROUPS_HINT), g2
+            # four 2x2 convs on the low-resolution rows, each writing its sub-pixel phase of the output in place
+            cws = E.packed_upsample_phases(conv, "w", conv)
+            out = torch.empty((g2.rows, self.out_channels), dtype=torch.float32 if s32 else torch.float16, device=x.device)
+            for py in range(2):
+                for px in range(2):
+                    ops.conv_gemm(x, cws[py][px], n_img=g.n_img, t_len=g.t, hi=g.h, wi=g.w, pad=(0, 1 - py, 1 - px),
+                                  out_hw=(g.h, g.w), out_f32=s32, rows_per_batch=g.rows_per_batch, out=out,
+                                  out_map=(g.w, 4 * g.w, 2, py * 2 * g.w + px))
+            return out, g2
         # Forced size (reference resnet.py:147-150, used when H, W are not multiples of 2^num_upsamplers,
         # unet_video.py:443-445,541-542): F.interpolate(size=..., mode="nearest"), i.e. src = floor(dst * in / out)
         # in fp32.  Rare path (odd intermediate sizes): the resized rows are materialised by an index gather and

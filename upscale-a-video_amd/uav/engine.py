@@ -134,6 +134,15 @@ def packed_conv(mod: EngineModule, name, conv: nn.Module, geglu=False):
     return mod._cache().get(("conv", name), build, (conv.weight, conv.bias))
 
 
+def packed_upsample_phases(mod: EngineModule, name, conv: nn.Module):
+    """The four 2x2 sub-pixel phase convs of an upsampler's 3x3 conv, packed ([py][px], see ops.upsample_phase_weights)."""
+    def build():
+        dev = _dev(conv.weight)
+        ph = ops.upsample_phase_weights(conv.weight)
+        return [[ops.pack_conv(ph[py][px], conv.bias, device=dev) for px in range(2)] for py in range(2)]
+    return mod._cache().get(("up_phases", name), build, (conv.weight, conv.bias))
+
+
 def packed_cat(mod: EngineModule, name, linears):
     """Fused projection: rows of several bias-free nn.Linear weights concatenated (q|k|v)."""
     def build():

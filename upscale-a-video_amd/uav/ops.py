@@ -180,14 +180,36 @@ def pack_conv(weight, bias=None, geglu=False, device=None, n_store_align=4):
     return ConvW(wp.to(dev), None if bp is None else bp.to(dev), n, n_pad, k_pad, i, cin_p, kt, kh, kw, geglu)
 
 
+def upsample_phase_weights(weight):
+    """Sub-pixel form of "nearest 2x upsampling, then 3x3 conv with padding 1" (reference resnet.py:144-158): output pixel
+    (2y + py, 2x + px) only ever sees the 2x2 input pixels (y - 1 + py .., x - 1 + px ..), because two of the three taps
+    of each axis fall on the same input pixel.  Returns the four (O, I, 2, 2) fp32 weights indexed [py][px]; phase
+    (py, px) is a 2x2 conv with top / left padding (1 - py, 1 - px) and zero taps past the bottom / right edge.  Same
+    result in exact arithmetic with 16 instead of 36 multiply-adds per output element; the tap sums are formed in fp32
+    before the single fp16 rounding of the packed weights."""
+    w = weight.detach().float()
+    if w.dim() != 4 or tuple(w.shape[-2:]) != (3, 3):
+        raise _lib.UavError("upsample_phase_weights expects (O, I, 3, 3)")
+    rows = [torch.stack([w[:, :, 0], w[:, :, 1] + w[:, :, 2]], dim=2),        # py = 0: rows y-1, y
+            torch.stack([w[:, :, 0] + w[:, :, 1], w[:, :, 2]], dim=2)]        # py = 1: rows y, y+1
+    out = []
+    for r in rows:                                                            # r: (O, I, 2, 3)
+        out.append([torch.stack([r[..., 0], r[..., 1] + r[..., 2]], dim=3),   # px = 0: cols x-1, x
+                    torch.stack([r[..., 0] + r[..., 1], r[..., 2]], dim=3)])  # px = 1: cols x, x+1
+    return out
+
+
 def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None,
               rowbias=None, rows_per_batch=0, residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None,
-              persistent=False, act=None, gn_groups=None):
+              persistent=False, act=None, gn_groups=None, out_map=None):
     """out[M][n_out] = scale*(conv(a1|a2, W) + bias + rowbias[m//rows_per_batch] + residual).
 
     gn_groups: the output feeds a GroupNorm of that many groups — when the launch qualifies
     (`uav_conv_gemm_gn_chunk_rows`) the epilogue also reduces the statistics partials and the returned tensor carries
-    them (`GnPartials`, attribute `_uav_gn`); `groupnorm_scale_shift` then skips its pass over the tensor."""
+    them (`GnPartials`, attribute `_uav_gn`); `groupnorm_scale_shift` then skips its pass over the tensor.
+
+    out_map = (w, sy, sx, off) with `out`: GEMM row m = Y*w + x lands in row Y*sy + x*sx + off of `out` (sub-pixel phases
+    of the upsampling convs, `upsample_phase_weights`)."""
     lib = _lib.load()
     _req(a1, HALF, "a1")
     c1 = a1.shape[-1]
@@ -211,6 +233,8 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
         raise _lib.UavError(f"a1 has {a1.numel()} elements, expected {n_img}*{hi}*{wi}*{c1}")
     m = n_img * ho * wo
     n_out = wt.n_out
+    if out_map is not None and (out is None or residual is not None):
+        raise _lib.UavError("out_map needs a caller-supplied `out` and no residual")
     if out is None:
         out = torch.empty((m, n_out), dtype=torch.float32 if out_f32 else HALF, device=a1.device)
     flags = (_lib.CONV_GEGLU if wt.geglu else 0) | (_lib.CONV_OUT_F32 if out_f32 else 0) | (_lib.CONV_PERSISTENT if persistent else 0)
@@ -238,8 +262,12 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
     p.pad_t = pt; p.pad_h = ph; p.pad_w = pw; p.upsample = 1 if upsample else 0
     p.n = wt.n; p.n_pad = wt.n_pad; p.k_pad = wt.k_pad
     p.out_scale = out_scale; p.flags = flags; p.zero_page = _p(zero_page(a1.device))
+    if out_map is not None:
+        p.out_map_w, p.out_map_sy, p.out_map_sx, p.out_map_off = (int(v) for v in out_map)
+        if (m // out_map[0] - 1) * out_map[1] + (out_map[0] - 1) * out_map[2] + out_map[3] >= out.shape[0]:
+            raise _lib.UavError("out_map places rows past the end of `out`")
     gn = None
-    if gn_groups and FUSE_GN_STATS:
+    if gn_groups and FUSE_GN_STATS and out_map is None:
         p.gn_groups = int(gn_groups)
         rows = lib.uav_conv_gemm_gn_chunk_rows(C.byref(p))
         if rows > 0:
