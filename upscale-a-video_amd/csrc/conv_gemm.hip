@@ -1061,13 +1061,24 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
         rys[ps] = ok_ ? yo_ * p.stride - p.pad_h : -(1 << 28); rxs[ps] = xo_ * p.stride - p.pad_w;
     }
     const int cin = p.c1 + p.c2;
-    const int ntaps = p.kt * p.kh * p.kw;
-    const int nk = p.k_pad / BK;
+    // Temporal taps that fall outside the clip for EVERY row of the tile are skipped instead of multiplied with zeros
+    // (a (3,1,1) conv on 8 frames spends 2 of its 24 tap-frames that way, a (5,1,1) conv 6 of 40, the decoder's 3x3x3
+    // conv on a 3-frame chunk 2 of 9): when a frame is a whole number of m-tiles, all rows of this tile share the frame
+    // t, and the valid dt are the contiguous range [dt_lo, dt_hi).  Adding the skipped zeros would not change a bit.
+    int dt_lo = 0, dt_hi = p.kt;
+    if (p.kt > 1 && p.korder && hw_o % LM == 0 && m0 < p.M) {
+        const int t_ = (int)(m0 / hw_o) % p.t_len;
+        dt_lo = p.pad_t - t_ > 0 ? p.pad_t - t_ : 0;
+        dt_hi = p.t_len + p.pad_t - t_ < p.kt ? p.t_len + p.pad_t - t_ : p.kt;
+    }
+    const int tap_lo = dt_lo * p.kh * p.kw;
+    const int ntaps = dt_hi * p.kh * p.kw;               // one past the last tap this tile multiplies
+    const int nk = (cin / BK) * (ntaps - tap_lo) + (p.k_pad - p.kt * p.kh * p.kw * cin) / BK;
     // W operand: scalar base of piece ps at K offset kb = wtile + ps*wps + kb, per-lane constant byte offset woff
     const char* wtile = p.w + (long long)n0 * p.k_pad * 2;
     const long long wps = 64ll * p.k_pad * 2;
     const unsigned woff = (unsigned)(((long long)rbase * p.k_pad + slot_log * 8) * 2);
-    int kdt = 0, kdy = 0, kdx = 0, ktap = 0, kc = 0;     // wave-uniform: tap / channel offset of the NEXT stage to address
+    int kdt = dt_lo, kdy = 0, kdx = 0, ktap = tap_lo, kc = 0;     // wave-uniform: tap / channel offset of the NEXT stage to address
     const char* gx0; const char* gx1; const char* gx2; const char* gx3;
     long long wkb;
 
@@ -1091,7 +1102,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
         if (p.korder) {                          /* tap-innermost K order (see conv_gemm_kernel) */          \
             ++ktap;                                                                                          \
             if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } }                           \
-            if (ktap == ntaps) { ktap = 0; kdt = 0; kdy = 0; kdx = 0; kc += BK; }                            \
+            if (ktap == ntaps) { ktap = tap_lo; kdt = dt_lo; kdy = 0; kdx = 0; kc += BK; }                   \
         } else {                                                                                             \
             kc += BK;                                                                                        \
             if (kc >= cin) { kc = 0; ++ktap; if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } } } \
