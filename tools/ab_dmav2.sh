@@ -1,3 +1,4 @@
+# NOTE: UAV_CONV_DMAV=4 (5-slot ring) only exists in commit 70468d9; the loops below now run the shipped variant only
 # in-call A/B: DMAV=1 (interleaved DMA, 2 stages) vs DMAV=4 (5-slot ring, counted vmcnt)
 mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; L=gpurun_out/ab_dmav2.log; : > $L
 for v in 1; do echo "== digest DMAV=$v" >> $L; UAV_CONV_DMAV=$v timeout 120 python $R/tools/conv_digest.py 2>&1 | grep -v amdgpu.ids >> $L; done

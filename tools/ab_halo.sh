@@ -1,3 +1,4 @@
+# NOTE: UAV_CONV_HALO only exists in commit 45fd3db (the haloed-X kernel was removed after this A/B); kept as the record of how profiles/r02_ab_conv_haloed_x_image_run31.log was produced
 # in-call A/B: haloed X image conv kernel (UAV_CONV_HALO=1) vs the shipped one — bit-identity digests, tests, micro-bench, e2e
 mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; L=gpurun_out/ab_halo.log; : > $L
 for v in 0 1; do echo "== digest HALO=$v (UAV_CONV_TILE=256)" >> $L; UAV_CONV_TILE=256 UAV_CONV_HALO=$v timeout 120 python $R/tools/conv_digest.py 2>&1 | grep -v amdgpu.ids >> $L; done

@@ -1,3 +1,4 @@
+# NOTE: UAV_CONV_HALO only exists in commit 45fd3db (the haloed-X kernel was removed after this A/B); kept as the record of how profiles/r02_ab_conv_haloed_x_image_run31.log was produced
 mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; L=gpurun_out/ab_halo2.log; : > $L
 for r in 1 2; do for v in 0 1; do
   echo "== bench_kernels HALO=$v round $r" >> $L

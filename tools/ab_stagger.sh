@@ -1,3 +1,4 @@
+# NOTE: UAV_CONV_STAGGER was a one-run experiment (no effect, profiles/r02_ab_conv_first_wave_stagger_run28.log); the switch is not in the tree
 # in-call A/B: first-wave stagger of the short-K conv launches (UAV_CONV_STAGGER = 1024-cycle sleep units per k-step)
 mkdir -p gpurun_out; R=$GRAFT_REPO_ROOT; L=gpurun_out/ab_stagger.log; : > $L
 for v in 0 1 2 3 5; do echo "== bench_kernels conv STAGGER=$v" >> $L
