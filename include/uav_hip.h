@@ -98,6 +98,10 @@ typedef struct {
      * output row m = Y*out_map_w + x (x < out_map_w) is stored at row Y*out_map_sy + x*out_map_sx + out_map_off of `out`
      * instead of row m.  residual and gn_partials must be NULL, no GEGLU.  0: rows in order. */
     int32_t      out_map_w, out_map_sy, out_map_sx, out_map_off;
+    /* Source 2 read batch-broadcast: a2 holds a2_images = n_img/2 images and images a2_images .. n_img-1 read the pixels
+     * of images 0 .. a2_images-1 (the skip tensors of the CFG-shared UNet head exist once, unet_blocks.py:563 concatenates
+     * them to both batch entries).  0: a2 has n_img images.  stride 1, no upsampling. */
+    int32_t      a2_images;
 } uav_conv_params;
 
 int uav_conv_gemm_f16(const uav_conv_params* p, void* stream);
@@ -119,6 +123,8 @@ int64_t uav_groupnorm_workspace_bytes(int32_t n_inst, int32_t c);
 int uav_groupnorm_scale_shift(const void* x1, const void* x2,
                               int32_t x_f32, /* 0: x rows are fp16, 1: fp32 (fp32 residual stream of the VAE decoder) */
                               int32_t c1, int32_t c2,
+                              int64_t x2_rows, /* 0: x2 has as many rows as x1; else x2 has x2_rows = half of them and is
+                                                  read batch-broadcast (row r >= x2_rows reads row r - x2_rows) */
                               int32_t c_real, /* real channels (<= c1+c2); padding gets scale=shift=0 */
                               int32_t n_inst, int64_t rows_per_inst, int32_t groups, float eps,
                               const float* gamma, const float* beta,
@@ -130,7 +136,7 @@ int uav_groupnorm_scale_shift(const void* x1, const void* x2,
 int uav_groupnorm_finalize_partials(const float* partials, int64_t chunks_total, int32_t chunk_rows, int32_t c,
                                     int32_t n_inst, int64_t rows_per_inst, int32_t groups, float eps,
                                     const float* gamma, const float* beta, float* scale_out, float* shift_out, void* stream);
-int uav_groupnorm_apply(const void* x1, const void* x2, int32_t x_f32, int32_t c1, int32_t c2,
+int uav_groupnorm_apply(const void* x1, const void* x2, int32_t x_f32, int32_t c1, int32_t c2, int64_t x2_rows,
                         int32_t n_inst, int64_t rows_per_inst,
                         const float* scale, const float* shift, int32_t silu,
                         void* y, void* stream);

@@ -32,6 +32,8 @@ def conv_gemm(a1, wt, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=Fals
     if pad is None:
         pad = (wt.kt // 2, wt.kh // 2, wt.kw // 2)
     pt, ph, pw = pad
+    if a2 is not None and a2.shape[0] * 2 == a1.shape[0]:                             # skip tensor read batch-broadcast
+        a2 = torch.cat([a2, a2])
     x = a1.float() if a2 is None else torch.cat([a1.float(), a2.float()], dim=-1)
     nb = n_img // t_len
     x = x.reshape(nb, t_len, hi, wi, wt.cin_p).permute(0, 4, 1, 2, 3)                 # (B, C, T, H, W)
@@ -93,6 +95,8 @@ def linear(x, wt, *, residual=None, out_scale=1.0, rowbias=None, rows_per_batch=
 
 # ---------------------------------------------------------------------------------------------------------------------
 def groupnorm(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps, silu, x2=None, c_real=None):
+    if x2 is not None and x2.shape[0] * 2 == x1.shape[0]:                             # skip tensor read batch-broadcast
+        x2 = torch.cat([x2, x2])
     x = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], dim=-1)
     c = x.shape[-1]
     c_real = c if c_real is None else c_real

@@ -520,3 +520,24 @@ def test_upsample_as_subpixel_phase_convs(ops, dev, cin, cout, n_img, t_len, h, 
     y = from_rows(out, n_img, 2 * h, 2 * w)
     assert rel_l2(y, ref) < (1e-3 if f32 else 2e-3)
     assert rel_l2(out, fused) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------
+# second source read batch-broadcast (uav_conv_params.a2_images, x2_rows of the GroupNorm entry points)
+@pytest.mark.parametrize("h,w,k3", [(48, 40, (1, 1, 1)), (24, 20, (1, 3, 3)), (96, 96, (1, 1, 1))])
+def test_second_source_batch_broadcast(ops, dev, h, w, k3):
+    """A skip tensor that exists once for both batch entries gives bit-identical results to its duplicated copy:
+    GroupNorm statistics + apply over (x | skip) and a conv over the two sources (128x128 and 256x256 tile kernels)."""
+    g = torch.Generator().manual_seed(h + k3[2])
+    bsz, t_len, c1, c2, cout = 2, 2, 128, 64, 256
+    rows = bsz * t_len * h * w
+    x = torch.randn(rows, c1, generator=g).half().to(dev)
+    skip1 = torch.randn(rows // 2, c2, generator=g).half().to(dev)
+    skip2 = torch.cat([skip1, skip1])
+    gamma = (1 + 0.1 * torch.randn(c1 + c2, generator=g)).to(dev); beta = (0.1 * torch.randn(c1 + c2, generator=g)).to(dev)
+    kw = dict(n_inst=bsz, rows_per_inst=t_len * h * w, groups=32, eps=1e-6, silu=True)
+    assert torch.equal(ops.groupnorm(x, gamma, beta, x2=skip1, **kw), ops.groupnorm(x, gamma, beta, x2=skip2, **kw))
+    wt = h16(cout, c1 + c2, *k3, dev=dev, scale=((c1 + c2) * k3[1] * k3[2]) ** -0.5, gen=g)
+    cw = ops.pack_conv(wt, torch.randn(cout, generator=g), device=dev)
+    ckw = dict(n_img=bsz * t_len, t_len=t_len, hi=h, wi=w)
+    assert torch.equal(ops.conv_gemm(x, cw, a2=skip1, **ckw), ops.conv_gemm(x, cw, a2=skip2, **ckw))

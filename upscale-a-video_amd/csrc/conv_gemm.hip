@@ -47,7 +47,12 @@ struct ConvArgs {
     unsigned ntiles;
     float* gn_ws; int gn_groups, gn_cpg_log2; long long gn_chunks;     // fused GroupNorm statistics (see conv_gn_store)
     int omw, omsy, omsx, omoff;                                        // strided output rows (uav_conv_params.out_map_*)
+    int a2_pix;                                                        // pixels of source 2 when it is read batch-broadcast (0: off)
 };
+
+// Source-2 pixel of GEMM pixel px: the skip tensors of the CFG-shared UNet head exist once and serve both batch entries
+// (uav_conv_params.a2_images), i.e. images a2_images .. 2*a2_images-1 read the pixels of images 0 .. a2_images-1.
+UAV_DEVINL int a2_wrap(const ConvArgs& p, int px) { return (p.a2_pix && px >= p.a2_pix) ? px - p.a2_pix : px; }
 
 // Output row of GEMM row m: m itself, or the strided placement of a sub-pixel phase (one integer division per lane and row
 // block, only on the launches that ask for it).
@@ -662,7 +667,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs p) {
             const int cs = first ? p.c1 : p.c2;                                                              \
             const int coff = (first ? kc : kc - p.c1) + slot_log * 8;                                        \
             _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                               \
-                const char* g = pix[ps] >= 0 ? src + ((long long)pix[ps] * cs + coff) * 2 : p.zero_page;     \
+                const int pxs = first ? pix[ps] : a2_wrap(p, pix[ps]);                                       \
+                const char* g = pix[ps] >= 0 ? src + ((long long)pxs * cs + coff) * 2 : p.zero_page;         \
                 dma16(g, sA + (ps * 256 + wave * 64) * 16);                                                  \
             }                                                                                                \
             wk = (long long)ktap * cin + kc;                                                                 \
@@ -825,7 +831,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
         const int xcs = first ? p.c1 : p.c2;                                                                 \
         const int xcoff = (first ? kc : kc - p.c1) + slot_log * 8;                                           \
         _Pragma("unroll") for (int ps = 0; ps < 4; ++ps) {                                                   \
-            const char* g = pix[ps] >= 0 ? xsrc + ((long long)pix[ps] * xcs + xcoff) * 2 : p.zero_page;      \
+            const int pxs = first ? pix[ps] : a2_wrap(p, pix[ps]);                                           \
+            const char* g = pix[ps] >= 0 ? xsrc + ((long long)pxs * xcs + xcoff) * 2 : p.zero_page;          \
             dma16(g, sA + (ps * 512 + wave * 64) * 16);                                                      \
         }                                                                                                    \
         const long long wk = (long long)ktap * cin + kc;                                                     \
@@ -1087,7 +1094,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
         const int tt = rtl[PS] + kdt, yv = rys[PS] + kdy, xv = rxs[PS] + kdx;                                \
         const bool ok = ((unsigned)tt < (unsigned)p.t_len) & ((unsigned)yv < (unsigned)ylim) &               \
                         ((unsigned)xv < (unsigned)xlim);                                                     \
-        const int px = ((rimg[PS] + kdt) * p.hi + (yv >> ups)) * p.wi + (xv >> ups);                         \
+        const int px0 = ((rimg[PS] + kdt) * p.hi + (yv >> ups)) * p.wi + (xv >> ups);                        \
+        const int px = first ? px0 : a2_wrap(p, px0);                                                        \
         const long long d = (xsrc - p.zero_page) + ((long long)px * xcs + xcoff) * 2;                        \
         G = p.zero_page + (ok ? d : 0ll);                                                                    \
     }
@@ -1317,6 +1325,11 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     a.zero_page = (const char*)q->zero_page;
     a.M = (long long)q->n_img * q->ho * q->wo;
     if (a.M <= 0 || a.M >= (1ll << 31)) return UAV_ESHAPE;
+    a.a2_pix = 0;
+    if (q->a2_images) {
+        if (q->a2_images < 0 || q->c2 <= 0 || q->n_img != 2 * q->a2_images || q->upsample || q->stride != 1) return UAV_ESHAPE;
+        a.a2_pix = q->a2_images * q->hi * q->wi;
+    }
     a.omw = 0; a.omsy = 0; a.omsx = 0; a.omoff = 0;
     if (q->out_map_w > 0) {
         if (q->residual || q->gn_partials || (q->flags & UAV_CONV_GEGLU) || q->out_map_sy < 0 || q->out_map_sx <= 0 ||

@@ -22,6 +22,7 @@ constexpr int GN_MAX_CHUNKS = 2048;
 
 struct GnSrc {
     const char* x1; const char* x2; int c1, c2;
+    long long rows2;      // 0, or the row count of x2 when it is read batch-broadcast (row r >= rows2 reads row r - rows2)
 };
 
 // 8 consecutive channels (vector index v inside the concatenated row) as fp32.  F32 = the rows are fp32 (fp32
@@ -31,7 +32,8 @@ UAV_DEVINL void gn_load8(const GnSrc& s, long long row, int v, float (&f)[8]) {
     const int v1 = s.c1 >> 3;
     const bool first = v < v1;
     const char* base = first ? s.x1 : s.x2;
-    const long long e = first ? row * s.c1 + (long long)v * 8 : row * s.c2 + (long long)(v - v1) * 8;
+    const long long row2 = (s.rows2 && row >= s.rows2) ? row - s.rows2 : row;
+    const long long e = first ? row * s.c1 + (long long)v * 8 : row2 * s.c2 + (long long)(v - v1) * 8;
     if (F32) {
         const float4_t a = *(const float4_t*)(base + e * 4), b = *(const float4_t*)(base + e * 4 + 16);
 #pragma unroll
@@ -278,7 +280,8 @@ extern "C" int64_t uav_groupnorm_workspace_bytes(int32_t n_inst, int32_t c) {
     return (int64_t)n_inst * (gn_variant() == 0 ? 512 : GN_MAX_CHUNKS) * c * 2 * 4;
 }
 
-extern "C" int uav_groupnorm_scale_shift(const void* x1, const void* x2, int32_t x_f32, int32_t c1, int32_t c2, int32_t c_real,
+extern "C" int uav_groupnorm_scale_shift(const void* x1, const void* x2, int32_t x_f32, int32_t c1, int32_t c2, int64_t x2_rows,
+                                         int32_t c_real,
                                          int32_t n_inst, int64_t rows_per_inst, int32_t groups, float eps,
                                          const float* gamma, const float* beta, float* scale_out, float* shift_out,
                                          void* workspace, int64_t workspace_bytes, void* stream) {
@@ -290,7 +293,8 @@ extern "C" int uav_groupnorm_scale_shift(const void* x1, const void* x2, int32_t
     const int chunks = gn_chunks(n_inst, rows_per_inst, c);
     if (workspace_bytes < (int64_t)n_inst * chunks * groups * 2 * 4) return UAV_EINVAL;
     if (groups > 2048) return UAV_ESHAPE;
-    GnSrc s{(const char*)x1, (const char*)x2, c1, c2};
+    if (x2_rows && (c2 <= 0 || x2_rows * 2 != (int64_t)n_inst * rows_per_inst)) return UAV_ESHAPE;
+    GnSrc s{(const char*)x1, (const char*)x2, c1, c2, (long long)x2_rows};
     hipStream_t st = (hipStream_t)stream;
     const int var = gn_variant();
 #define GN_PARTIAL(F, UU) hipLaunchKernelGGL((gn_partial_kernel<F, UU>), dim3(chunks, n_inst), dim3(256), 0, st, s, \
@@ -319,9 +323,9 @@ extern "C" int uav_groupnorm_finalize_partials(const float* partials, int64_t ch
     return uav_launch_status();
 }
 
-extern "C" int uav_groupnorm_apply(const void* x1, const void* x2, int32_t x_f32, int32_t c1, int32_t c2, int32_t n_inst,
-                                   int64_t rows_per_inst, const float* scale, const float* shift, int32_t silu, void* y,
-                                   void* stream) {
+extern "C" int uav_groupnorm_apply(const void* x1, const void* x2, int32_t x_f32, int32_t c1, int32_t c2, int64_t x2_rows,
+                                   int32_t n_inst, int64_t rows_per_inst, const float* scale, const float* shift, int32_t silu,
+                                   void* y, void* stream) {
     if (!x1 || !scale || !shift || !y) return UAV_EINVAL;
     const int c = c1 + c2;
     if (c1 <= 0 || c2 < 0 || (c1 % 8) || (c2 % 8) || c > 2048 || (c2 > 0 && !x2)) return UAV_ESHAPE;
@@ -331,7 +335,8 @@ extern "C" int uav_groupnorm_apply(const void* x1, const void* x2, int32_t x_f32
     long long want = 8192 / n_inst; if (want < 1) want = 1;
     if (chunks > want) chunks = want;
     if (chunks < 1) chunks = 1;
-    GnSrc s{(const char*)x1, (const char*)x2, c1, c2};
+    if (x2_rows && (c2 <= 0 || x2_rows * 2 != (int64_t)n_inst * rows_per_inst)) return UAV_ESHAPE;
+    GnSrc s{(const char*)x1, (const char*)x2, c1, c2, (long long)x2_rows};
     if (x_f32)
         hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((unsigned)chunks, n_inst), dim3(256), 0, (hipStream_t)stream, s,
                            (long long)rows_per_inst, (int)chunks, scale, shift, silu, (char*)y);

@@ -14,11 +14,16 @@ the host copy when one exists).
 from dataclasses import dataclass
 from typing import Optional, Tuple, Union
 
+import os
+
 import torch
 import torch.nn as nn
 
 from uav import engine as E
 from uav import ops
+
+# CFG-shared head: its skip tensors are kept once and read batch-broadcast (UAV_BROADCAST_SKIPS=0: duplicated with cat)
+BROADCAST_SKIPS = os.environ.get("UAV_BROADCAST_SKIPS", "1") != "0"
 
 from ._compat import BaseOutput, ConfigMixin, ModelMixin, register_to_config
 from .attention import RotaryEmbedding
@@ -232,7 +237,8 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
             x1, g1, outs = self.down_blocks[0].run(x1, g1, emb1, ehs_rows, n_text)
             skips1.extend(outs)
             x1 = self.down_temp_blocks[0].run(x1, g1, emb1)
-            skips = [(torch.cat([s_, s_]), E.Geom(2, sg.t, sg.h, sg.w)) for (s_, sg) in skips1]
+            # the skips stay single: their consumers (GroupNorm and convs with a second source) read them batch-broadcast
+            skips = [((s_ if BROADCAST_SKIPS else torch.cat([s_, s_])), E.Geom(2, sg.t, sg.h, sg.w)) for (s_, sg) in skips1]
             x, g = ops.duplicate_rows(x1), E.Geom(2, g1.t, g1.h, g1.w)
             first = 1
         else:

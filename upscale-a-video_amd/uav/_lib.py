@@ -32,6 +32,7 @@ class ConvParams(C.Structure):
         ("out_scale", f32), ("flags", u32), ("zero_page", c_p),
         ("gn_partials", c_p), ("gn_groups", i32),
         ("out_map_w", i32), ("out_map_sy", i32), ("out_map_sx", i32), ("out_map_off", i32),
+        ("a2_images", i32),
     ]
 
 
@@ -50,8 +51,8 @@ SIGNATURES = {
     "uav_conv_gemm_gn_chunk_rows": (C.c_int, [C.POINTER(ConvParams)]),
     "uav_groupnorm_finalize_partials": (C.c_int, [c_p, i64, i32, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p]),
     "uav_groupnorm_workspace_bytes": (i64, [i32, i32]),
-    "uav_groupnorm_scale_shift": (C.c_int, [c_p, c_p, i32, i32, i32, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
-    "uav_groupnorm_apply": (C.c_int, [c_p, c_p, i32, i32, i32, i32, i64, c_p, c_p, i32, c_p, c_p]),
+    "uav_groupnorm_scale_shift": (C.c_int, [c_p, c_p, i32, i32, i32, i64, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
+    "uav_groupnorm_apply": (C.c_int, [c_p, c_p, i32, i32, i32, i64, i32, i64, c_p, c_p, i32, c_p, c_p]),
     "uav_layernorm_f16": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, f32, c_p]),
     "uav_attention_f16": (C.c_int, [c_p, i64, c_p, i64, c_p, i64, c_p, i64, i32, i32, i32, i32, i32, i32, f32, i32, c_p, c_p]),
     "uav_temporal_attention_f16": (C.c_int, [c_p, c_p, i32, i32, i64, i32, i32, f32, c_p, c_p, i32, c_p, c_p]),

@@ -231,6 +231,12 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
         ho, wo = out_hw
     if a1.numel() != n_img * hi * wi * c1:
         raise _lib.UavError(f"a1 has {a1.numel()} elements, expected {n_img}*{hi}*{wi}*{c1}")
+    a2_images = 0
+    if a2 is not None and a2.numel() != n_img * hi * wi * c2:
+        # a skip tensor of the CFG-shared UNet head: it exists once and serves both batch entries (read batch-broadcast)
+        if n_img % 2 or a2.numel() * 2 != n_img * hi * wi * c2:
+            raise _lib.UavError(f"a2 has {a2.numel()} elements, expected {n_img}*{hi}*{wi}*{c2} (or half of it)")
+        a2_images = n_img // 2
     m = n_img * ho * wo
     n_out = wt.n_out
     if out_map is not None and (out is None or residual is not None):
@@ -262,6 +268,7 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
     p.pad_t = pt; p.pad_h = ph; p.pad_w = pw; p.upsample = 1 if upsample else 0
     p.n = wt.n; p.n_pad = wt.n_pad; p.k_pad = wt.k_pad
     p.out_scale = out_scale; p.flags = flags; p.zero_page = _p(zero_page(a1.device))
+    p.a2_images = a2_images
     if out_map is not None:
         p.out_map_w, p.out_map_sy, p.out_map_sx, p.out_map_off = (int(v) for v in out_map)
         if (m // out_map[0] - 1) * out_map[1] + (out_map[0] - 1) * out_map[2] + out_map[3] >= out.shape[0]:
@@ -349,6 +356,15 @@ def duplicate_rows(t):
     return out
 
 
+def _gn_x2_rows(x1, x2, rows):
+    """0, or the row count of a second source that exists once for both batch entries (read batch-broadcast)."""
+    if x2 is None or x2.shape[0] == rows:
+        return 0
+    if x2.shape[0] * 2 != rows:
+        raise _lib.UavError(f"groupnorm: second source has {x2.shape[0]} rows, expected {rows} (or half of it)")
+    return x2.shape[0]
+
+
 def _gn_dtype(x1, x2):
     """GroupNorm inputs are fp16 rows, or fp32 rows (fp32 residual stream of the VAE decoder); both sources alike."""
     if x1.dtype not in (HALF, torch.float32):
@@ -383,7 +399,8 @@ def groupnorm_scale_shift(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps
     ws_bytes = lib.uav_groupnorm_workspace_bytes(n_inst, c)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x1.device)
     ev = PROFILER.begin("groupnorm_stats")
-    rc = lib.uav_groupnorm_scale_shift(_p(x1), _p(x2), xf32, c1, c2, c_real, n_inst, rows_per_inst, groups, eps,
+    rc = lib.uav_groupnorm_scale_shift(_p(x1), _p(x2), xf32, c1, c2, _gn_x2_rows(x1, x2, n_inst * rows_per_inst), c_real,
+                                       n_inst, rows_per_inst, groups, eps,
                                        _p(gamma), _p(beta), _p(scale), _p(shift), _p(ws), ws_bytes, _stream())
     _lib.check(rc, "uav_groupnorm_scale_shift")
     PROFILER.end(ev, "groupnorm_stats", 0.0, (4.0 if xf32 else 2.0) * n_inst * rows_per_inst * c)
@@ -397,8 +414,8 @@ def groupnorm_apply(x1, scale, shift, *, n_inst, rows_per_inst, silu, x2=None):
     c2 = 0 if x2 is None else x2.shape[-1]
     y = torch.empty((n_inst * rows_per_inst, c1 + c2), dtype=HALF, device=x1.device)
     ev = PROFILER.begin("groupnorm_apply")
-    rc = lib.uav_groupnorm_apply(_p(x1), _p(x2), xf32, c1, c2, n_inst, rows_per_inst, _p(scale), _p(shift),
-                                 1 if silu else 0, _p(y), _stream())
+    rc = lib.uav_groupnorm_apply(_p(x1), _p(x2), xf32, c1, c2, _gn_x2_rows(x1, x2, n_inst * rows_per_inst), n_inst,
+                                 rows_per_inst, _p(scale), _p(shift), 1 if silu else 0, _p(y), _stream())
     _lib.check(rc, "uav_groupnorm_apply")
     PROFILER.end(ev, "groupnorm_apply", 0.0, (6.0 if xf32 else 4.0) * n_inst * rows_per_inst * (c1 + c2))
     return y
