@@ -524,7 +524,7 @@ def test_upsample_as_subpixel_phase_convs(ops, dev, cin, cout, n_img, t_len, h, 
 
 # ------------------------------------------------------------------------------------------------
 # second source read batch-broadcast (uav_conv_params.a2_images, x2_rows of the GroupNorm entry points)
-@pytest.mark.parametrize("h,w,k3", [(48, 40, (1, 1, 1)), (24, 20, (1, 3, 3)), (96, 96, (1, 1, 1))])
+@pytest.mark.parametrize("h,w,k3", [(48, 40, (1, 1, 1)), (24, 20, (1, 3, 3)), (160, 160, (1, 1, 1)), (128, 128, (1, 3, 3))])
 def test_second_source_batch_broadcast(ops, dev, h, w, k3):
     """A skip tensor that exists once for both batch entries gives bit-identical results to its duplicated copy:
     GroupNorm statistics + apply over (x | skip) and a conv over the two sources (128x128 and 256x256 tile kernels)."""
