@@ -372,6 +372,10 @@ def main():
                                "launches": d["launches"],
                                "avg_launch_us": d["seconds"] / d["launches"] * 1e6,
                                "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+                               "flops_counted": "2*M*N*taps*C_in of every launch as issued: the upsamplers run as four 2x2 "
+                                                "sub-pixel phase convs and count 16 of the reference's 36 multiply-adds per "
+                                                "output element (SURVEY's 5608.7 TFLOP/clip counts 36); out-of-clip temporal "
+                                                "taps are counted although the kernel skips them (1 % of the conv FLOPs)",
                                "kernel_time_share": share}
             # per kernel: MFMA-bound ones against the dense fp16 peak, HBM-bound ones (algorithmic bytes: every operand
             # read / written once) against the 8 TB/s HBM3E peak
