@@ -407,6 +407,33 @@ def test_cabi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.uav_version() > 0
 
 
+def test_fused_groupnorm_partials_bookkeeping():
+    """Host logic around the statistics a conv epilogue leaves on its output tensor (ops.GnPartials): they are honoured
+    only for the very tensor object and version the conv returned, for the matching group count / width and a row count
+    the 64-row chunks divide; duplicating the rows (CFG-shared head) duplicates them; a half-size second source is
+    recognised as batch-broadcast and anything else is an error."""
+    from uav import ops, _lib
+    y = torch.zeros(256, 64, dtype=torch.float16)
+    gn = ops.GnPartials(torch.arange(2 * 32 * 4, dtype=torch.float32).reshape(2, 32, 4), 64, 32, 64)
+    ops._gn_attach(y, gn)
+    assert ops._gn_partials_of(y, 32, 64, 128) is gn and ops._gn_partials_of(y, 32, 64, 256) is gn
+    assert ops._gn_partials_of(y, 16, 64, 128) is None            # other group count
+    assert ops._gn_partials_of(y, 32, 64, 96) is None             # instance not a whole number of chunks
+    assert ops._gn_partials_of(y[:128], 32, 64, 128) is None      # a view is another object
+    d = ops.duplicate_rows(y)
+    gd = ops._gn_partials_of(d, 32, 64, 256)
+    assert d.shape == (512, 64) and gd is not None and gd.ws.shape == (2, 32, 8)
+    assert torch.equal(gd.ws[..., :4], gn.ws) and torch.equal(gd.ws[..., 4:], gn.ws)
+    y.add_(1)                                                      # in-place update: stale
+    assert ops._gn_partials_of(y, 32, 64, 128) is None
+    assert getattr(ops.duplicate_rows(y), "_uav_gn", None) is None
+    x = torch.zeros(8, 64, dtype=torch.float16)
+    assert ops._gn_x2_rows(x, None, 8) == 0 and ops._gn_x2_rows(x, torch.zeros(8, 8), 8) == 0
+    assert ops._gn_x2_rows(x, torch.zeros(4, 8), 8) == 4
+    with pytest.raises(_lib.UavError):
+        ops._gn_x2_rows(x, torch.zeros(3, 8), 8)
+
+
 def test_upsample_phase_weights_identity():
     """"nearest 2x, then 3x3 conv (pad 1)" == four 2x2 sub-pixel phase convs (ops.upsample_phase_weights), exactly in exact
     arithmetic: checked in fp64 against F.interpolate + F.conv2d, borders included, and through the CPU stand-in of the
