@@ -60,6 +60,10 @@ CONV_CASES = [
     ("big_up_c64_n256", 64, 256, (1, 3, 3), 1, True, 2, 1, 9, 7),
     ("big_s2_c64_n512", 64, 512, (1, 3, 3), 2, False, 2, 2, 18, 14),
     ("big_1x1_c192_n512", 192, 512, (1, 1, 1), 1, False, 3, 1, 31, 9),
+    # a frame is a whole number of 256-row tiles and the grid is large: the 256x256 kernel skips the temporal taps that
+    # fall outside the 3-frame chunk for a whole tile (first / last frame) — decoder 3x3x3 conv and a (5,1,1) conv
+    ("frames_3x3x3_c64_n256", 64, 256, (3, 3, 3), 1, False, 6, 3, 112, 96),
+    ("frames_t5_c128_n256", 128, 256, (5, 1, 1), 1, False, 16, 8, 64, 64),
 ]
 
 
