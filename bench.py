@@ -134,18 +134,15 @@ def cpu_baseline(sample_hw=64, frames=8, max_threads=32):
 
 def self_launch(n):
     """Re-exec this script as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same args>`."""
-    import socket
     import subprocess
     have = torch.cuda.device_count()
     if have < n:
         print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: the launcher binds its own free rendezvous port (no bind-then-close race, ADVICE r2)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n}", os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
 
 
@@ -176,6 +173,10 @@ def main():
     ap.add_argument("--vae-fp16", action="store_true",
                     help="A/B switch: all-fp16 VAE decoder rows (round-1 behaviour, ~1e-3 rel-L2 vs the fp32 reference decode) "
                          "instead of the default fp32 residual stream (~6e-4); the mode timed is named in config.workload")
+    ap.add_argument("--unet-stream", choices=["f16", "f32"], default=None,
+                    help="residual-stream precision of the UNet (UNetVideoModel.stream_dtype): f16 = every stored tensor fp16, the "
+                         "arithmetic of the reference's `.half()` UNet; f32 = fp32 rows, fp32 latents between DDIM steps, fp16 MFMA "
+                         "operands.  Default: the engine's default (models_video/unet_video.py DEFAULT_STREAM); named in config.workload")
     ap.add_argument("--text-encoder", choices=["clip", "standin"], default="clip",
                     help="clip: ViT-H/14 text tower (random init) on the HIP kernels, run once per distinct prompt pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -216,6 +217,9 @@ def main():
     pipe = build_pipeline(dev, args.height, args.width, text_encoder=args.text_encoder,
                           vae_cfg=_cfg.VAE_VIDEO if args.video_vae else None)
     pipe.vae.stream_dtype = torch.float16 if args.vae_fp16 else torch.float32
+    if args.unet_stream is not None:
+        pipe.unet.stream_dtype = torch.float32 if args.unet_stream == "f32" else torch.float16
+    unet_f32 = pipe.unet.stream_f32()
     pipe.cfg_shared_input = not args.no_cfg_share
     pipe.shard_windows = args.shard_windows
     clip = synthetic_clip(args.frames, args.height, args.width, seed=0 if args.shard_windows else rank, dev=dev)
@@ -327,6 +331,8 @@ def main():
             "config": {"workload": f"configs[{3 if args.shard_windows else 4 if args.video_vae else 2 if args.propagation else 1}]"
                                    + (" (one spatial tile of a 540p clip)" if args.video_vae else "") + f": {args.frames}-frame {args.height}x{args.width}->{4 * args.height}x{4 * args.width}, "
                                    f"{args.ddim_steps} DDIM steps, guidance 6, noise_level 120, "
+                                   + ("UNet on an fp32 residual stream (fp16 MFMA operands, fp32 latents), " if unet_f32 else
+                                      "UNet on fp16 rows (the reference's .half() arithmetic), ")
                                    + ("CLIP ViT-H text tower on HIP kernels (one encode per distinct prompt pair), " if args.text_encoder == "clip" else "stand-in text embedding, ")
                                    + ("vae_video (" if args.video_vae else "vae_3d (")
                                    + ("all-fp16 decoder rows" if args.vae_fp16 else "fp32 residual stream, fp16 MFMA operands") + "), "
@@ -374,8 +380,8 @@ def main():
                                "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
                                "flops_counted": "2*M*N*taps*C_in of every launch as issued: the upsamplers run as four 2x2 "
                                                 "sub-pixel phase convs and count 16 of the reference's 36 multiply-adds per "
-                                                "output element (SURVEY's 5608.7 TFLOP/clip counts 36); out-of-clip temporal "
-                                                "taps are counted although the kernel skips them (1 % of the conv FLOPs)",
+                                                "output element (SURVEY's 5608.7 TFLOP/clip counts 36); temporal taps that fall "
+                                                "outside the clip (zero padding, skipped by the kernel) are NOT counted",
                                "kernel_time_share": share}
             # per kernel: MFMA-bound ones against the dense fp16 peak, HBM-bound ones (algorithmic bytes: every operand
             # read / written once) against the 8 TB/s HBM3E peak

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UAV_ABI_VERSION 3
+#define UAV_ABI_VERSION 4
 
 #define UAV_EINVAL   (-1)   /* bad argument (null pointer, size not supported) */
 #define UAV_EALIGN   (-2)   /* pointer / stride alignment requirement violated */
@@ -144,6 +144,9 @@ int uav_groupnorm_apply(const void* x1, const void* x2, int32_t x_f32, int32_t c
 /* ---- LayerNorm over the channel axis (nn.LayerNorm(dim), eps 1e-5: attention.py:457-494) */
 int uav_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta,
                       int64_t rows, int32_t c, float eps, void* stream);
+/* same, fp32 input rows (the UNet's fp32 residual stream, UNetVideoModel.stream_dtype); fp16 output (an MFMA operand) */
+int uav_layernorm_f32in(const float* x, void* y, const float* gamma, const float* beta,
+                        int64_t rows, int32_t c, float eps, void* stream);
 
 /* ---- K5/K6/K8: flash attention on MFMA ------------------------------------------------
  * Replaces CrossAttention._attention (attention.py:209-238: baddbmm + softmax + bmm) for
@@ -209,6 +212,16 @@ int uav_ddim_vt(const void* x0, const void* guided, const void* sample, void* pr
                 int64_t n, float coef_x0, float coef_dir, float eps_from_model,
                 float eps_from_sample, float eps_from_x0, int32_t clip, float clip_range,
                 void* stream);
+/* same two steps on fp32 latents / model outputs (UNetVideoModel.stream_dtype = float32: latents, the UNet output and the
+ * guided output stay fp32 between DDIM steps; nothing is rounded to fp16) */
+int uav_cfg_ddim_v0_f32(const float* eps_uncond, const float* eps_text, const float* sample,
+                        float* guided_out, float* x0_out, int64_t n, float guidance,
+                        float coef_sample, float coef_eps, int32_t clip, float clip_range,
+                        void* stream);
+int uav_ddim_vt_f32(const float* x0, const float* guided, const float* sample, float* prev_out,
+                    int64_t n, float coef_x0, float coef_dir, float eps_from_model,
+                    float eps_from_sample, float eps_from_x0, int32_t clip, float clip_range,
+                    void* stream);
 /* y = a*x + b*z  (add_noise: scheduling_ddim.py:524-545; window blend pipeline:630-634) */
 int uav_axpby_f16(const void* x, const void* z, void* y, int64_t n, float a, float b,
                   void* stream);

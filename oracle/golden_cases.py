@@ -137,4 +137,7 @@ FULL_CASES = {
     # BASELINE.json configs[0]: single 8-frame 128x128 -> 512x512 clip, 5 DDIM steps, no propagation
     "pipe_c1_full": dict(t=8, h=128, w=128, steps=5, guidance=6.0, noise_level=120, clip_seed=41,
                          prompt="best quality, extremely detailed", negative="blur, worst quality"),
+    # the FULL 30-step schedule of BASELINE configs[1] at the released width, 64x64 so the CPU reference finishes in minutes
+    "pipe_full30_64": dict(t=8, h=64, w=64, steps=30, guidance=6.0, noise_level=120, clip_seed=43,
+                           prompt="best quality, extremely detailed", negative="blur, worst quality"),
 }

@@ -78,7 +78,7 @@ class _TextEnc(torch.nn.Module):
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("UAV_GOLDEN_THREADS", "8")))
     ns = ref_stubs.import_reference()
     pin = {"reference_root": ref_stubs.REFERENCE_ROOT, "torch": torch.__version__, "cases": {}}
 
@@ -176,6 +176,7 @@ def main():
     make_pipe_half_golden(ns, pin)
     make_colorfix_golden(ns, pin)
     make_fullwidth_goldens(ns, pin)
+    make_full30_golden(ns, pin)
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
     print("wrote", GOLD)
 
@@ -511,6 +512,66 @@ def make_fullwidth_goldens(ns, pin):
     print("pipe_c1_full", pin["cases"]["pipe_c1_full"], flush=True)
 
 
+FULL30_KEEP = (1, 2, 3, 5, 10, 15, 20, 25, 30)      # DDIM steps (1-based) whose latents are stored
+
+
+def make_full30_golden(ns, pin):
+    """error growth over the FULL 30-step schedule at the released width.  The reference's own pipeline
+    (full-width UNet + vae_3d, 8 frames 64x64 -> 256x256, 30 DDIM steps, guidance 6, no propagation) on CPU, twice:
+      fp32      everything in fp32 (what every other fixture is)
+      half      the precision mix the CLI really runs (inference_upscale_a_video.py:101-118): UNet `.half()`, fp16 text
+                embeddings -> both randn draws, latents, CFG and DDIM in fp16; VAE decode in fp32 (pipeline:668-681)
+    The latents after the steps in FULL30_KEEP are recorded by wrapping `scheduler.step_vt` on the INSTANCE (the reference
+    code itself is untouched).  The half-vs-fp32 distance per step is the yardstick for any fp16 engine END TO END: it
+    is what the reference's own production path accumulates over the schedule."""
+    unet, usd, ucfg, vae, vsd, vcfg = _full_models(ns)
+    pc = FULL_CASES["pipe_full30_64"]
+    dim = ucfg["cross_attention_dim"]
+    clip = synth.synth_clip(1, pc["t"], pc["h"], pc["w"], seed=pc["clip_seed"])
+    out = {}
+    for mode in ("fp32", "half"):
+        tok = _Tok()
+        sch = ns.scheduling_ddim.DDIMScheduler(**SCHED)
+        trace = []
+        inner = sch.step_vt
+
+        def rec(*a, _inner=inner, **kw):
+            r = _inner(*a, **kw)
+            trace.append(r.prev_sample.detach().clone())
+            return r
+        sch.step_vt = rec
+        if mode == "half":
+            unet.half()
+        pipe = ns.pipeline.VideoUpscalePipeline(
+            text_encoder=_TextEnc(tok, dim, dtype=torch.float16 if mode == "half" else torch.float32), tokenizer=tok,
+            low_res_scheduler=ref_stubs.DDPMScheduler(beta_schedule="scaled_linear", beta_start=0.0001, beta_end=0.02),
+            scheduler=sch, vae=vae, unet=unet, propagator=None)
+        gen = torch.Generator().manual_seed(10)
+        t0 = time.time()
+        img, lat = pipe(pc["prompt"], image=clip, generator=gen, num_inference_steps=pc["steps"], guidance_scale=pc["guidance"],
+                        noise_level=pc["noise_level"], negative_prompt=pc["negative"], return_dict=False)
+        secs = time.time() - t0
+        if mode == "half":
+            unet.float()
+        assert len(trace) == pc["steps"]
+        out[mode] = dict(trace=trace, img=img, lat=lat, secs=secs)
+        print("pipe_full30_64", mode, "%.0f s" % secs, flush=True)
+    growth = [rel_l2(h_, f_) for h_, f_ in zip(out["half"]["trace"], out["fp32"]["trace"])]
+    unsat = out["fp32"]["img"].abs() < 0.999
+    pin["cases"]["pipe_full30_64"] = {
+        "reference_half_vs_fp32_latents_rel_l2_per_step": growth,
+        "reference_half_vs_fp32_image_rel_l2_unsaturated": rel_l2(out["half"]["img"][unsat], out["fp32"]["img"][unsat]),
+        "image_saturated_fraction": 1.0 - unsat.float().mean().item(),
+        "ref_seconds_fp32": out["fp32"]["secs"], "ref_seconds_half": out["half"]["secs"], "kept_steps": list(FULL30_KEEP)}
+    torch.save({"steps": list(FULL30_KEEP),
+                "latents_fp32": torch.stack([out["fp32"]["trace"][k - 1].float() for k in FULL30_KEEP]),
+                "latents_half": torch.stack([out["half"]["trace"][k - 1].half() for k in FULL30_KEEP]),
+                "images_fp32_sub2": out["fp32"]["img"][..., ::2, ::2].half().clone(),
+                "images_half_sub2": out["half"]["img"][..., ::2, ::2].half().clone()},
+               os.path.join(GOLD, "pipe_full30_64.pt"))
+    print("pipe_full30_64", pin["cases"]["pipe_full30_64"], flush=True)
+
+
 def make_pipe_half_golden(ns, pin):
     """The reference pipeline in the precision mix the CLI really runs (inference_upscale_a_video.py:101-118): UNet
     `.half()`, text-encoder dtype fp16 -> both randn draws, the latents, CFG, DDIM and the flow-guided propagation
@@ -560,13 +621,14 @@ def make_colorfix_golden(ns, pin):
 
 def only(section):
     """`python oracle/make_golden.py --raft | --unet`: regenerate one section's fixtures and PINNING.json entries."""
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get("UAV_GOLDEN_THREADS", "8")))
     ns = ref_stubs.import_reference()
     pin = json.load(open(os.path.join(GOLD, "PINNING.json")))
     {"raft": make_raft_goldens, "unet": make_unet_goldens, "tiles": make_tile_goldens, "pipe14": make_dup_tail_golden,
-     "vaewlr": make_vae_wlr_golden, "prophalf": make_prop_half_goldens, "pipehalf": make_pipe_half_golden, "colorfix": make_colorfix_golden, "full": make_fullwidth_goldens}[section](ns, pin)
+     "vaewlr": make_vae_wlr_golden, "prophalf": make_prop_half_goldens, "pipehalf": make_pipe_half_golden, "colorfix": make_colorfix_golden, "full": make_fullwidth_goldens,
+     "full30": make_full30_golden}[section](ns, pin)
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
-    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else only("tiles") if "--tiles" in sys.argv else only("pipe14") if "--pipe14" in sys.argv else only("vaewlr") if "--vaewlr" in sys.argv else only("colorfix") if "--colorfix" in sys.argv else only("pipehalf") if "--pipehalf" in sys.argv else only("prophalf") if "--prophalf" in sys.argv else only("full") if "--full" in sys.argv else main()
+    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else only("tiles") if "--tiles" in sys.argv else only("pipe14") if "--pipe14" in sys.argv else only("vaewlr") if "--vaewlr" in sys.argv else only("colorfix") if "--colorfix" in sys.argv else only("pipehalf") if "--pipehalf" in sys.argv else only("prophalf") if "--prophalf" in sys.argv else only("full30") if "--full30" in sys.argv else only("full") if "--full" in sys.argv else main()

@@ -182,24 +182,29 @@ def unpack_ncthw(src, *, c, n_batch, t_len, h, w, out_dtype=HALF, clamp=None):
     return x.to(out_dtype).contiguous()
 
 
+def _like(y, x):
+    """scheduler kernels: fp16 in -> fp16 out (rounded), fp32 in -> fp32 out (uav_*_f32 entry points)"""
+    return y.float() if x.dtype == torch.float32 else _h(y)
+
+
 def axpby(x, z, a, b):
-    return _h(a * x.float() + b * z.float())
+    return _like(a * x.float() + b * z.float(), x)
 
 
 def cfg_ddim_v0(eu, ec, sample, *, guidance, coef_sample, coef_eps, clip=False, clip_range=1.0):
     g = eu.float() if ec is None else eu.float() + guidance * (ec.float() - eu.float())
-    g = _h(g)
+    g = _like(g, sample)
     x0 = coef_sample * sample.float() + coef_eps * g.float()
     if clip:
         x0 = x0.clamp(-clip_range, clip_range)
-    return g, _h(x0)
+    return g, _like(x0, sample)
 
 
 def ddim_vt(x0, guided, sample, *, coef_x0, coef_dir, eps_from_model, eps_from_sample, eps_from_x0=0.0, clip=False,
             clip_range=1.0):
     a = x0.float().clamp(-clip_range, clip_range) if clip else x0.float()
     eps = eps_from_model * guided.float() + eps_from_sample * sample.float() + eps_from_x0 * a
-    return _h(coef_x0 * a + coef_dir * eps)
+    return _like(coef_x0 * a + coef_dir * eps, sample)
 
 
 def _warp(x, flow, mode):

@@ -203,7 +203,7 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/uav_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.uav_version() == 3
+    assert lib.uav_version() == 4
 
 
 # ---------------------------------------------------------------------------------------------

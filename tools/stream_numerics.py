@@ -1,0 +1,109 @@
+"""Offline (CPU) numerics of the UNet residual-stream precision: the product UNetVideoModel on the torch stand-ins of
+tests/cpu_ops.py (kernel contracts: fp32 arithmetic, every STORED fp16 tensor rounded) against the reference's fp32 output
+of the full-width fixture unet_full_t8_64.  Decides whether an fp16-operand / fp32-stream UNet reaches the stated 1e-3
+before any kernel work (VERDICT r2 next #1c).
+
+    python tools/stream_numerics.py [f16] [f32] [f32-branch16] [f32+gn] [f32+ln] [f32+proj] [f32+geglu] [f32+attn] [f32+tail]
+
+`f32+<class>`: sensitivity study — the fp32-stream mode with ONE class of fp16 MFMA operands left unrounded (not something
+a kernel can do; it shows where the remaining error comes from): gn / ln = GroupNorm / LayerNorm outputs, proj = q|k|v and
+text k|v projections, geglu = the feed-forward's gated activation, attn = attention outputs, tail = block outputs that are
+only read as operands (last ff-down of a transformer, TemporalModule3D's tail block).
+"""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in ("oracle", "tests", "upscale-a-video_amd"):
+    sys.path.insert(0, os.path.join(ROOT, p))
+import cpu_ops  # noqa: E402
+import golden_cases as GC  # noqa: E402
+import synth  # noqa: E402
+
+
+def rel_l2(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm()).item()
+
+
+class _FakeHalf(torch.Tensor):
+    """fp32 tensor that reports dtype float16: lets an UNROUNDED operand through the stand-ins' dtype asserts."""
+    @staticmethod
+    def __new__(cls, t):
+        return torch.Tensor._make_subclass(cls, t.float())
+
+    @property
+    def dtype(self):
+        return torch.float16
+
+
+def main():
+    import json
+    from models_video.unet_video import UNetVideoModel
+    from uav import engine as E
+    torch.set_num_threads(int(os.environ.get("UAV_THREADS", "4")))
+    from uav import configs
+    cfg = dict(configs.UNET_VIDEO)
+    unet = UNetVideoModel.from_config(dict(cfg)).eval()
+    unet.load_state_dict(synth.synth_state_dict(unet.state_dict(), seed=1234), strict=True)
+    gold = torch.load(os.path.join(ROOT, "tests", "golden", "unet_full_t8_64.pt"))
+    sample, low, ehs, ts, cl = GC.unet_inputs(*GC.FULL_CASES["unet_full_t8_64"], cfg["cross_attention_dim"])
+    modes = sys.argv[1:] or ["f16", "f32", "f32-branch16"]
+    cpu_ops.install()
+    from uav import ops
+    base = {k: getattr(ops, k) for k in ("groupnorm", "layernorm", "conv_gemm", "attention", "temporal_attention")}
+    real_h = cpu_ops._h
+    real_assert = None
+
+    def exact(fn):
+        def wrap(*a, **kw):
+            cpu_ops._h = lambda x: x.float()
+            try:
+                return fn(*a, **kw)
+            finally:
+                cpu_ops._h = real_h
+        return wrap
+
+    def conv_exact(kinds):
+        def wrap(a1, wt, **kw):
+            fp16_out = not kw.get("out_f32", False)
+            kind = None
+            if fp16_out:
+                kind = "geglu" if wt.geglu else ("tail" if kw.get("residual") is not None else "proj")
+            a1 = a1 if a1.dtype == torch.float16 else _FakeHalf(a1)
+            if kw.get("a2") is not None and kw["a2"].dtype != torch.float16:
+                kw["a2"] = _FakeHalf(kw["a2"])
+            if kind in kinds and kw.get("out") is None:
+                r = exact(base["conv_gemm"])(a1, wt, **kw)
+            else:
+                r = base["conv_gemm"](a1, wt, **kw)
+            return r.as_subclass(torch.Tensor) if isinstance(r, _FakeHalf) else r
+        return wrap
+    try:
+        for mode in modes:
+            unet.stream_dtype = torch.float32 if mode.startswith("f32") else torch.float16
+            E.BRANCH_F32 = mode != "f32-branch16"
+            keep = set(mode.split("+")[1:])
+            for k, f in base.items():
+                setattr(ops, k, f)
+            cpu_ops.conv_gemm = base["conv_gemm"]
+            if keep:
+                if "gn" in keep: ops.groupnorm = exact(base["groupnorm"])
+                if "ln" in keep: ops.layernorm = exact(base["layernorm"])
+                if "attn" in keep:
+                    ops.attention = exact(base["attention"]); ops.temporal_attention = exact(base["temporal_attention"])
+                ops.conv_gemm = cpu_ops.conv_gemm = conv_exact(keep)
+            t0 = time.time()
+            with torch.no_grad():
+                out = unet(sample.half(), ts, low.half(), encoder_hidden_states=ehs.half(), class_labels=cl).sample
+            print(f"{mode:14s} vs reference fp32 {rel_l2(out, gold['fp32']):.3e}   vs reference fp16 {rel_l2(out, gold['fp16']):.3e}"
+                  f"   (reference fp16 vs fp32 {rel_l2(gold['fp16'], gold['fp32']):.3e})   {time.time() - t0:.0f} s", flush=True)
+    finally:
+        cpu_ops.conv_gemm = base["conv_gemm"]
+        cpu_ops.restore()
+
+
+if __name__ == "__main__":
+    main()

@@ -193,7 +193,9 @@ UAV_DEVINL void conv_gn_store(const ConvArgs& p, float (&st)[NI][GnAcc<GNM>::NG]
 // up front instead of load -> wait -> store per 16-B piece (the generic path below has ~130 s_waitcnt and ~270 branches;
 // on the K = 512 linears the epilogue was 35-40 % of the kernel time, `tools/ab_conv.sh` DBG=6).  Same arithmetic
 // order as the generic path: ((acc + bias) + rowbias) + residual, then * out_scale.
-template <int NI, int MI, bool RES, bool BIAS, bool RB, int GNM>
+// RF32: the residual is an fp32 row (fp32 residual stream, fp16 result: a block output that is only read as an MFMA operand);
+// it is loaded in the accumulators' own layout (one float4 per register quad), no half-wave exchange.
+template <int NI, int MI, bool RES, bool BIAS, bool RB, int GNM, bool RF32 = false>
 UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32,
                                    const float* rbrow) {
     constexpr bool GN = GNM != 0;
@@ -211,7 +213,8 @@ UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], 
     for (int mi = 0; mi < MI; ++mi) {
         const long long m = mw0 + mi * 32 + l32;
         orow[mi] = p.out + (out_row(p, m) * p.out_stride + nw0 + 8 * hi32) * 2;
-        rrow[mi] = RES ? p.residual + (m * p.res_stride + nw0 + 8 * hi32) * 2 : nullptr;
+        rrow[mi] = !RES ? nullptr : RF32 ? p.residual + (m * p.res_stride + nw0 + 4 * hi32) * 4
+                                         : p.residual + (m * p.res_stride + nw0 + 8 * hi32) * 2;
     }
     const float* bptr = BIAS ? p.bias + nw0 + 4 * hi32 : nullptr;
     const float* rptr = RB ? rbrow + nw0 + 4 * hi32 : nullptr;
@@ -227,19 +230,26 @@ UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], 
             if (BIAS) bq[g] = *(const float4_t*)(bptr + ni * 32 + 8 * g);
             if (RB) rq[g] = *(const float4_t*)(rptr + ni * 32 + 8 * g);
         }
-        uint4_t R[MI][2];
-        if (RES) {
+        uint4_t R[(RES && !RF32) ? MI : 1][2];
+        float4_t RF[(RES && RF32) ? MI : 1][4];
+        if (RES && !RF32) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int gp = 0; gp < 2; ++gp) R[mi][gp] = *(const uint4_t*)(rrow[mi] + (ni * 32 + 16 * gp) * 2);
+        }
+        if (RES && RF32) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) RF[mi][g] = *(const float4_t*)(rrow[mi] + (ni * 32 + 8 * g) * 4);
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
                 uint32_t Rr[4] = {0, 0, 0, 0};
-                if (RES) {
+                if (RES && !RF32) {
                     Rr[0] = R[mi][gp][0]; Rr[1] = R[mi][gp][1]; Rr[2] = R[mi][gp][2]; Rr[3] = R[mi][gp][3];
                     swap_pair(Rr[0], Rr[2]); swap_pair(Rr[1], Rr[3]);     // -> Rr[0..1]: quad 2gp, Rr[2..3]: quad 2gp+1
                 }
@@ -258,9 +268,13 @@ UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], 
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] += rq[g][j];
                     }
-                    if (RES) {
+                    if (RES && !RF32) {
                         float2_t r0 = unpack_h2(Rr[2 * q]), r1 = unpack_h2(Rr[2 * q + 1]);
                         v[0] += r0[0]; v[1] += r0[1]; v[2] += r1[0]; v[3] += r1[1];
+                    }
+                    if (RES && RF32) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += RF[mi][g][j];
                     }
                     uint32_t* d = q == 0 ? A : B;
 #pragma unroll
@@ -285,8 +299,10 @@ UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], 
 // only the MFMA operands are fp16).  A lane owns pixel m and, per register quad g, 4 consecutive channels: one float4
 // (16-B) store per quad straight from the accumulators, one float4 load for an fp32 residual; no half-wave exchange.
 // Same arithmetic order as the fp16 paths: ((acc + bias) + residual) * out_scale.
-template <int NI, int MI, bool RES, int GNM>
-UAV_DEVINL void conv_epilogue_f32_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32) {
+// RB: one time-embedding row for the whole wave tile (conv1 of a ResNet block whose branch tensor stays fp32).
+template <int NI, int MI, bool RES, int GNM, bool RB = false>
+UAV_DEVINL void conv_epilogue_f32_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32,
+                                       const float* rbrow = nullptr) {
     const float osc = p.out_scale;
     constexpr bool GN = GNM != 0;
     constexpr int NG = GnAcc<GNM>::NG;
@@ -305,6 +321,11 @@ UAV_DEVINL void conv_epilogue_f32_fast(const ConvArgs& p, float16_t (&acc)[NI][M
         float4_t bq[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) bq[g] = *(const float4_t*)(p.bias + nw0 + ni * 32 + 8 * g + 4 * hi32);
+        float4_t rq[4];                                 // same order as the fp16 paths: ((acc + bias) + rowbias) + residual
+        if (RB) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rq[g] = *(const float4_t*)(rbrow + nw0 + ni * 32 + 8 * g + 4 * hi32);
+        }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
             const long long m = mw0 + mi * 32 + l32;
@@ -321,6 +342,7 @@ UAV_DEVINL void conv_epilogue_f32_fast(const ConvArgs& p, float16_t (&acc)[NI][M
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     float v = acc[ni][mi][4 * g + j] + bq[g][j];
+                    if (RB) v += rq[g][j];
                     if (RES) v += R[g][j];
                     o[j] = v * osc;
                 }
@@ -387,12 +409,17 @@ template <int NI, int MI, int GNK = 0>
 UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32) {
     if constexpr (GNK != 0) {
         if (mw0 >= p.M || nw0 >= p.n) return;                   // wave tile outside the output: nothing to store or count
+        const float* rbrow = p.rowbias ? p.rowbias + (long long)((int)(mw0 / p.rows_per_batch)) * p.rowbias_stride : nullptr;
         if (p.flags & UAV_CONV_OUT_F32) {
-            if (p.residual) conv_epilogue_f32_fast<NI, MI, true, GNK>(p, acc, mw0, nw0, l32, hi32);
+            if (rbrow) conv_epilogue_f32_fast<NI, MI, false, GNK, true>(p, acc, mw0, nw0, l32, hi32, rbrow);   // conv1: no residual
+            else if (p.residual) conv_epilogue_f32_fast<NI, MI, true, GNK>(p, acc, mw0, nw0, l32, hi32);
             else conv_epilogue_f32_fast<NI, MI, false, GNK>(p, acc, mw0, nw0, l32, hi32);
             return;
         }
-        const float* rbrow = p.rowbias ? p.rowbias + (long long)((int)(mw0 / p.rows_per_batch)) * p.rowbias_stride : nullptr;
+        if (p.flags & UAV_CONV_RES_F32) {               // fp32 stream in, fp16 operand out (host: bias, no rowbias)
+            conv_epilogue_fast<NI, MI, true, true, false, GNK, true>(p, acc, mw0, nw0, l32, hi32, nullptr);
+            return;
+        }
 #define UAV_EPI(RES, BIAS, RB) conv_epilogue_fast<NI, MI, RES, BIAS, RB, GNK>(p, acc, mw0, nw0, l32, hi32, rbrow)
         switch ((p.residual ? 4 : 0) | (p.bias ? 2 : 0) | (rbrow ? 1 : 0)) {
             case 0: UAV_EPI(false, false, false); break;
@@ -411,10 +438,22 @@ UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long 
     const bool of32 = p.flags & UAV_CONV_OUT_F32;
     const bool rf32 = p.flags & UAV_CONV_RES_F32;
     const unsigned actf = p.flags & (UAV_CONV_GELU | UAV_CONV_QUICK_GELU);      // activation: generic path only (tiny GEMMs)
-    if (of32 && !actf && !geglu && p.bias && !p.rowbias && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n && !(p.out_stride & 3) &&
+    if (of32 && !actf && !geglu && p.bias && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n && !(p.out_stride & 3) &&
         (!p.residual || (rf32 && !(p.res_stride & 3)))) {
-        if (p.residual) conv_epilogue_f32_fast<NI, MI, true, 0>(p, acc, mw0, nw0, l32, hi32);
-        else conv_epilogue_f32_fast<NI, MI, false, 0>(p, acc, mw0, nw0, l32, hi32);
+        if (!p.rowbias) {
+            if (p.residual) conv_epilogue_f32_fast<NI, MI, true, 0>(p, acc, mw0, nw0, l32, hi32);
+            else conv_epilogue_f32_fast<NI, MI, false, 0>(p, acc, mw0, nw0, l32, hi32);
+            return;
+        }
+        const int b0 = (int)(mw0 / p.rows_per_batch), b1 = (int)((mw0 + MI * 32 - 1) / p.rows_per_batch);
+        if (b0 == b1 && !p.residual) {
+            conv_epilogue_f32_fast<NI, MI, false, 0, true>(p, acc, mw0, nw0, l32, hi32, p.rowbias + (long long)b0 * p.rowbias_stride);
+            return;
+        }
+    }
+    if (!of32 && rf32 && !actf && !geglu && p.bias && !p.rowbias && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n &&
+        !(p.out_stride & 7) && !(p.res_stride & 3)) {
+        conv_epilogue_fast<NI, MI, true, true, false, 0, true>(p, acc, mw0, nw0, l32, hi32, nullptr);
         return;
     }
     // wave-uniform fast-path test
@@ -1277,9 +1316,12 @@ int conv_gn_cpg_log2(const uav_conv_params* q) {
     if (q->flags & (UAV_CONV_GEGLU | UAV_CONV_GELU | UAV_CONV_QUICK_GELU)) return -1;
     const bool of32 = q->flags & UAV_CONV_OUT_F32, rf32 = q->flags & UAV_CONV_RES_F32;
     if (of32) {
-        if (!q->bias || q->rowbias || (q->out_stride & 3) || (q->residual && (!rf32 || (q->res_stride & 3)))) return -1;
+        if (!q->bias || (q->out_stride & 3) || (q->residual && (!rf32 || (q->res_stride & 3)))) return -1;
+        if (q->rowbias && (q->residual || (q->rows_per_batch % 64))) return -1;
+    } else if (rf32) {                                          // fp32 residual, fp16 result
+        if (!q->bias || q->rowbias || (q->out_stride & 7) || (q->res_stride & 3)) return -1;
     } else {
-        if (rf32 || (q->out_stride & 7) || (q->residual && (q->res_stride & 7))) return -1;
+        if ((q->out_stride & 7) || (q->residual && (q->res_stride & 7))) return -1;
         if (q->rowbias && (q->rows_per_batch % 64)) return -1;
     }
     return cl;

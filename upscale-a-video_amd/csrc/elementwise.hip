@@ -101,15 +101,21 @@ __global__ __launch_bounds__(256) void unpack_ncthw_kernel(const SrcT* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cfg_ddim_v0_kernel(const half_t* __restrict__ eu, const half_t* __restrict__ ec,
-                                                          const half_t* __restrict__ x, half_t* __restrict__ g_out,
-                                                          half_t* __restrict__ x0_out, long long n, float guidance,
+// T = half_t: the reference's `.half()` arithmetic (the guided output is ROUNDED to fp16 before x0 is formed, as two
+// separate fp16 tensor ops would); T = float: fp32 latents / model outputs (UNet stream_dtype = float32), nothing is rounded.
+template <typename T>
+__global__ __launch_bounds__(256) void cfg_ddim_v0_kernel(const T* __restrict__ eu, const T* __restrict__ ec,
+                                                          const T* __restrict__ x, T* __restrict__ g_out,
+                                                          T* __restrict__ x0_out, long long n, float guidance,
                                                           float ca, float cb, int clip, float range) {
-    const long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
-    if (i >= n) return;
-    if (i + 8 <= n) {
-        half8_t u = *(const half8_t*)(eu + i), xv = *(const half8_t*)(x + i), c = u, g, x0;
-        if (ec) c = *(const half8_t*)(ec + i);
+    const long long i0 = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (i0 >= n) return;
+    const long long i1 = i0 + 8 <= n ? i0 + 8 : n;
+    if (sizeof(T) == 2 && i0 + 8 <= n) {
+        typedef half8_t V;
+        const V u = *(const V*)(eu + i0), xv = *(const V*)(x + i0);
+        V c = u, g, x0;
+        if (ec) c = *(const V*)(ec + i0);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float gu = (float)u[e];
@@ -119,22 +125,23 @@ __global__ __launch_bounds__(256) void cfg_ddim_v0_kernel(const half_t* __restri
             if (clip) v = fminf(fmaxf(v, -range), range);
             x0[e] = (half_t)v;
         }
-        *(half8_t*)(g_out + i) = g; *(half8_t*)(x0_out + i) = x0;
-    } else {
-        for (long long j = i; j < n; ++j) {
-            const float gu = (float)eu[j];
-            const float gg = ec ? gu + guidance * ((float)ec[j] - gu) : gu;
-            const half_t gh = (half_t)gg;
-            float v = ca * (float)x[j] + cb * (float)gh;
-            if (clip) v = fminf(fmaxf(v, -range), range);
-            g_out[j] = gh; x0_out[j] = (half_t)v;
-        }
+        *(V*)(g_out + i0) = g; *(V*)(x0_out + i0) = x0;
+        return;
+    }
+    for (long long j = i0; j < i1; ++j) {
+        const float gu = (float)eu[j];
+        const float gg = ec ? gu + guidance * ((float)ec[j] - gu) : gu;
+        const T gh = (T)gg;
+        float v = ca * (float)x[j] + cb * (float)gh;
+        if (clip) v = fminf(fmaxf(v, -range), range);
+        g_out[j] = gh; x0_out[j] = (T)v;
     }
 }
 
 // prev = cx0*x0 + cdir*(em*g + es*sample + e0*x0)
-__global__ __launch_bounds__(256) void ddim_vt_kernel(const half_t* __restrict__ x0, const half_t* __restrict__ g,
-                                                      const half_t* __restrict__ x, half_t* __restrict__ prev,
+template <typename T>
+__global__ __launch_bounds__(256) void ddim_vt_kernel(const T* __restrict__ x0, const T* __restrict__ g,
+                                                      const T* __restrict__ x, T* __restrict__ prev,
                                                       long long n, float cx0, float cdir, float em, float es, float e0,
                                                       int clip, float range) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(256) void ddim_vt_kernel(const half_t* __restrict__
     float a = (float)x0[i];
     if (clip) a = fminf(fmaxf(a, -range), range);
     const float eps = em * (float)g[i] + es * (float)x[i] + e0 * a;
-    prev[i] = (half_t)(cx0 * a + cdir * eps);
+    prev[i] = (T)(cx0 * a + cdir * eps);
 }
 
 __global__ __launch_bounds__(256) void axpby_kernel(const half_t* __restrict__ x, const half_t* __restrict__ z,
@@ -321,9 +328,18 @@ extern "C" int uav_cfg_ddim_v0(const void* eps_uncond, const void* eps_text, con
                                void* x0_out, int64_t n, float guidance, float coef_sample, float coef_eps, int32_t clip,
                                float clip_range, void* stream) {
     if (!eps_uncond || !sample || !guided_out || !x0_out || n <= 0) return UAV_EINVAL;
-    hipLaunchKernelGGL(cfg_ddim_v0_kernel, dim3(nblk(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(cfg_ddim_v0_kernel<half_t>, dim3(nblk(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream,
                        (const half_t*)eps_uncond, (const half_t*)eps_text, (const half_t*)sample, (half_t*)guided_out,
                        (half_t*)x0_out, (long long)n, guidance, coef_sample, coef_eps, clip, clip_range);
+    return uav_launch_status();
+}
+
+extern "C" int uav_cfg_ddim_v0_f32(const float* eps_uncond, const float* eps_text, const float* sample, float* guided_out,
+                                   float* x0_out, int64_t n, float guidance, float coef_sample, float coef_eps, int32_t clip,
+                                   float clip_range, void* stream) {
+    if (!eps_uncond || !sample || !guided_out || !x0_out || n <= 0) return UAV_EINVAL;
+    hipLaunchKernelGGL(cfg_ddim_v0_kernel<float>, dim3(nblk(n, 256 * 8)), dim3(256), 0, (hipStream_t)stream, eps_uncond,
+                       eps_text, sample, guided_out, x0_out, (long long)n, guidance, coef_sample, coef_eps, clip, clip_range);
     return uav_launch_status();
 }
 
@@ -331,9 +347,18 @@ extern "C" int uav_ddim_vt(const void* x0, const void* guided, const void* sampl
                            float coef_x0, float coef_dir, float eps_from_model, float eps_from_sample, float eps_from_x0,
                            int32_t clip, float clip_range, void* stream) {
     if (!x0 || !guided || !sample || !prev_out || n <= 0) return UAV_EINVAL;
-    hipLaunchKernelGGL(ddim_vt_kernel, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x0,
+    hipLaunchKernelGGL(ddim_vt_kernel<half_t>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, (const half_t*)x0,
                        (const half_t*)guided, (const half_t*)sample, (half_t*)prev_out, (long long)n, coef_x0, coef_dir,
                        eps_from_model, eps_from_sample, eps_from_x0, clip, clip_range);
+    return uav_launch_status();
+}
+
+extern "C" int uav_ddim_vt_f32(const float* x0, const float* guided, const float* sample, float* prev_out, int64_t n,
+                               float coef_x0, float coef_dir, float eps_from_model, float eps_from_sample, float eps_from_x0,
+                               int32_t clip, float clip_range, void* stream) {
+    if (!x0 || !guided || !sample || !prev_out || n <= 0) return UAV_EINVAL;
+    hipLaunchKernelGGL(ddim_vt_kernel<float>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)stream, x0, guided, sample,
+                       prev_out, (long long)n, coef_x0, coef_dir, eps_from_model, eps_from_sample, eps_from_x0, clip, clip_range);
     return uav_launch_status();
 }
 

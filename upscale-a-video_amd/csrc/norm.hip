@@ -208,8 +208,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc s, long long rows_p
     }
 }
 
-// LayerNorm: one wave per row, row held in registers (c <= 2048), two-pass mean/variance.
-template <int NV>
+// LayerNorm: one wave per row, row held in registers (c <= 2048), two-pass mean/variance.  F32: the rows are the fp32
+// residual stream (UNet stream_dtype = float32); the output is always the fp16 MFMA operand of the projection that follows.
+template <int NV, bool F32>
 __global__ __launch_bounds__(256) void layernorm_kernel(const char* __restrict__ x, char* __restrict__ y,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
                                                         long long rows, int c, float eps) {
@@ -218,15 +219,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const char* __restrict__
     const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long nwaves = (long long)gridDim.x * 4;
     for (long long row = wave_id; row < rows; row += nwaves) {
-        half8_t xv[NV];
+        float xv[NV][8];
         float s = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int v = lane + i * 64;
             if (v < cvec) {
-                xv[i] = *(const half8_t*)(x + (row * c + (long long)v * 8) * 2);
+                if (F32) {
+                    const float4_t a = *(const float4_t*)(x + (row * c + (long long)v * 8) * 4);
+                    const float4_t b = *(const float4_t*)(x + (row * c + (long long)v * 8) * 4 + 16);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) s += (float)xv[i][j];
+                    for (int j = 0; j < 4; ++j) { xv[i][j] = a[j]; xv[i][4 + j] = b[j]; }
+                } else {
+                    const half8_t h = *(const half8_t*)(x + (row * c + (long long)v * 8) * 2);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) xv[i][j] = (float)h[j];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s += xv[i][j];
             }
         }
         const float mean = wave_sum(s) / (float)c;
@@ -236,7 +246,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const char* __restrict__
             const int v = lane + i * 64;
             if (v < cvec) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { float d = (float)xv[i][j] - mean; q += d * d; }
+                for (int j = 0; j < 8; ++j) { float d = xv[i][j] - mean; q += d * d; }
             }
         }
         const float rstd = rsqrtf(wave_sum(q) / (float)c + eps);
@@ -248,7 +258,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const char* __restrict__
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int ch = v * 8 + j;
-                    o[j] = (half_t)(((float)xv[i][j] - mean) * rstd * gamma[ch] + beta[ch]);
+                    o[j] = (half_t)((xv[i][j] - mean) * rstd * gamma[ch] + beta[ch]);
                 }
                 *(half8_t*)(y + (row * c + (long long)v * 8) * 2) = o;
             }
@@ -346,16 +356,27 @@ extern "C" int uav_groupnorm_apply(const void* x1, const void* x2, int32_t x_f32
     return uav_launch_status();
 }
 
-extern "C" int uav_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t c,
-                                 float eps, void* stream) {
+static int layernorm_launch(const void* x, int x_f32, void* y, const float* gamma, const float* beta, int64_t rows, int32_t c,
+                            float eps, void* stream) {
     if (!x || !y || !gamma || !beta) return UAV_EINVAL;
     if (c <= 0 || (c % 8) || c > 2048 || rows <= 0) return UAV_ESHAPE;
     long long blocks = (rows + 3) / 4; if (blocks > 4096) blocks = 4096;
     const int nv = ((c >> 3) + 63) / 64;
     hipStream_t st = (hipStream_t)stream;
-#define LN_LAUNCH(NV) hipLaunchKernelGGL(layernorm_kernel<NV>, dim3((unsigned)blocks), dim3(256), 0, st, (const char*)x, \
-                                         (char*)y, gamma, beta, (long long)rows, c, eps)
-    if (nv == 1) LN_LAUNCH(1); else if (nv == 2) LN_LAUNCH(2); else if (nv == 3) LN_LAUNCH(3); else LN_LAUNCH(4);
+#define LN_LAUNCH(NV, F) hipLaunchKernelGGL((layernorm_kernel<NV, F>), dim3((unsigned)blocks), dim3(256), 0, st, (const char*)x, \
+                                            (char*)y, gamma, beta, (long long)rows, c, eps)
+    if (x_f32) { if (nv == 1) LN_LAUNCH(1, true); else if (nv == 2) LN_LAUNCH(2, true); else if (nv == 3) LN_LAUNCH(3, true); else LN_LAUNCH(4, true); }
+    else { if (nv == 1) LN_LAUNCH(1, false); else if (nv == 2) LN_LAUNCH(2, false); else if (nv == 3) LN_LAUNCH(3, false); else LN_LAUNCH(4, false); }
 #undef LN_LAUNCH
     return uav_launch_status();
+}
+
+extern "C" int uav_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t c,
+                                 float eps, void* stream) {
+    return layernorm_launch(x, 0, y, gamma, beta, rows, c, eps, stream);
+}
+
+extern "C" int uav_layernorm_f32in(const float* x, void* y, const float* gamma, const float* beta, int64_t rows, int32_t c,
+                                   float eps, void* stream) {
+    return layernorm_launch(x, 1, y, gamma, beta, rows, c, eps, stream);
 }

@@ -102,7 +102,8 @@ class CrossAttention(E.EngineModule):
             qkv = ops.linear(x, E.packed_cat(self, "qkv", [self.to_q, self.to_k, self.to_v]))
             o = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], bq=bq, lq=lq, lk=lq, heads=self.heads,
                               head_dim=self.dim_head, scale=self.scale, q_stride=3 * c, k_stride=3 * c, v_stride=3 * c)
-        return ops.linear(o, E.packed_conv(self, "out", self.to_out[0]), residual=residual)
+        return ops.linear(o, E.packed_conv(self, "out", self.to_out[0]), residual=residual,
+                          out_f32=residual.dtype == torch.float32)
 
     def project_text(self, ehs_rows):
         """K|V of the text tokens: [B*77][2C] (fused GEMM), computed once per prompt tensor."""
@@ -143,7 +144,8 @@ class TemporalAttention(CrossAttention):
         qkv = ops.linear(x, E.packed_cat(self, "qkv", [self.to_q, self.to_k, self.to_v]))
         o = ops.temporal_attention(qkv, n_batch=g.b, t_len=g.t, hw=g.hw, c=c, heads=self.heads, scale=self.scale,
                                    rope_cos=cos, rope_sin=sin, rot_dim=rot, bias=bias)
-        return ops.linear(o, E.packed_conv(self, "out", self.to_out[0]), residual=residual)
+        return ops.linear(o, E.packed_conv(self, "out", self.to_out[0]), residual=residual,
+                          out_f32=residual.dtype == torch.float32)
 
 
 class GEGLU(nn.Module):
@@ -162,9 +164,10 @@ class FeedForward(E.EngineModule):
         inner = int(dim * mult)
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim_out or dim)])
 
-    def run(self, x, residual):
+    def run(self, x, residual, out_f32=None):
         h = ops.linear(x, E.packed_conv(self, "up", self.net[0].proj, geglu=True))
-        return ops.linear(h, E.packed_conv(self, "down", self.net[2]), residual=residual)
+        return ops.linear(h, E.packed_conv(self, "down", self.net[2]), residual=residual,
+                          out_f32=(residual.dtype == torch.float32) if out_f32 is None else out_f32)
 
 
 class BasicTransformerBlock(E.EngineModule):
@@ -203,8 +206,9 @@ class BasicTransformerBlock(E.EngineModule):
         c.store[("textkv", tag)] = (ehs_rows, ehs_rows._version, kv, wstamp)
         return kv
 
-    def run(self, x, g: E.Geom, ehs_rows, n_text):
-        """x: tokens [B*T*HW][C] (rows ordered b,t,p); ehs_rows: [B*n_text][Cx] fp16."""
+    def run(self, x, g: E.Geom, ehs_rows, n_text, out_f32=None):
+        """x: tokens [B*T*HW][C] (rows ordered b,t,p), fp16 or fp32 (residual stream); ehs_rows: [B*n_text][Cx] fp16.
+        out_f32=False: the block's output is only read as an MFMA operand (proj_out) -> written in fp16."""
         bq, lq = g.n_img, g.hw
         n = E.layer_norm(self, "norm1", self.norm1, x)
         if self.only_cross_attention:
@@ -219,7 +223,7 @@ class BasicTransformerBlock(E.EngineModule):
         n = E.layer_norm(self, "norm_temporal", self.norm_temporal, x)
         x = self.attn_temporal.run_temporal(n, x, g)
         n = E.layer_norm(self, "norm3", self.norm3, x)
-        return self.ff.run(n, x)
+        return self.ff.run(n, x, out_f32)
 
 
 class Transformer3DModel(ModelMixin, ConfigMixin, E.EngineModule):
@@ -248,10 +252,13 @@ class Transformer3DModel(ModelMixin, ConfigMixin, E.EngineModule):
         x = self.resblock_temporal.run(x, g, None)
         res = x
         n = E.group_norm(self, "norm", self.norm, x, n_inst=g.n_img, rows_per_inst=g.hw, silu=False)   # per frame
-        tok = ops.linear(n, E.packed_conv(self, "proj_in", self.proj_in))
-        for blk in self.transformer_blocks:
-            tok = blk.run(tok, g, ehs_rows, n_text)
-        return ops.linear(tok, E.packed_conv(self, "proj_out", self.proj_out), residual=res, gn_groups=self.norm.num_groups)
+        s32 = res.dtype == torch.float32         # fp32 residual stream: the token stream is one too (LayerNorm inputs)
+        tok = ops.linear(n, E.packed_conv(self, "proj_in", self.proj_in), out_f32=s32)
+        last = len(self.transformer_blocks) - 1
+        for i, blk in enumerate(self.transformer_blocks):
+            tok = blk.run(tok, g, ehs_rows, n_text, out_f32=False if i == last else None)   # proj_out reads it as an operand
+        return ops.linear(tok, E.packed_conv(self, "proj_out", self.proj_out), residual=res, out_f32=s32,
+                          gn_groups=self.norm.num_groups)
 
     def forward(self, hidden_states, encoder_hidden_states=None, timestep=None, return_dict=True):
         rows, g = E.to_rows(hidden_states, c_pad=self.in_channels)

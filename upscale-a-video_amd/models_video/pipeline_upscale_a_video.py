@@ -271,11 +271,16 @@ class VideoUpscalePipeline(ConfigMixin):
                                                    prompt_embeds, negative_prompt_embeds)
         draw_dtype = prompt_embeds.dtype          # the reference draws both noises in prompt_embeds.dtype (:547,:573)
         prompt_embeds = prompt_embeds.to(torch.float16).contiguous()
+        # Latent precision between DDIM steps.  fp16 (default, the reference's `.half()` arithmetic: latents, UNet output,
+        # CFG and both scheduler halves are fp16 tensors there too), or fp32 when the UNet runs on an fp32 residual
+        # stream (UNetVideoModel.stream_dtype): the UNet's fp32 output rows, the guided output (CFG multiplies the
+        # rounding error of its two inputs by ~2*guidance), x0 and the latents then stay fp32 from step to step.
+        lat_dtype = torch.float32 if getattr(self.unet, "stream_f32", lambda: False)() else torch.float16
 
         # 4/5. LR frames: fp32 copy for the VAE conditioning, fp16 + noise for the UNet (:542-551)
         image_dec = image.clone().to(dtype=torch.float32, device=device)
-        image = image.to(dtype=torch.float16, device=device)
-        noise = randn_tensor(image.shape, generator=generator, device=device, dtype=draw_dtype).to(torch.float16)
+        image = image.to(dtype=lat_dtype, device=device)
+        noise = randn_tensor(image.shape, generator=generator, device=device, dtype=draw_dtype).to(lat_dtype)
         image = self.low_res_scheduler.add_noise(image, noise, torch.tensor([noise_level]))
         level = torch.tensor([noise_level if denoise_level is None else denoise_level], dtype=torch.long)
         # reference quirk kept: the single-window branch (T <= 8) conditions the UNet on `noise_level` even when a
@@ -289,7 +294,7 @@ class VideoUpscalePipeline(ConfigMixin):
         t_total, height, width = image.shape[2:]
         num_channels_latents = self.vae.config.latent_channels
         latents = self.prepare_latents_3d(1, num_channels_latents, t_total, height, width, draw_dtype, device,
-                                          generator, latents).to(torch.float16).contiguous()
+                                          generator, latents).to(lat_dtype).contiguous()
         if num_channels_latents + image.shape[1] != self.unet.config.in_channels:
             raise ValueError(f"Incorrect configuration settings! The config of `pipeline.unet`: {self.unet.config} expects"
                              f" {self.unet.config.in_channels} but received `num_channels_latents`: {num_channels_latents} +"
@@ -314,7 +319,7 @@ class VideoUpscalePipeline(ConfigMixin):
                     return self.unet(lin[:, :, se[0]:se[1]].contiguous(), t, image[:, :, se[0]:se[1]].contiguous(),
                                      encoder_hidden_states=prompt_embeds, class_labels=level,
                                      cfg_shared_input=do_cfg and self.cfg_shared_input).sample.contiguous()
-                like = ((lin.shape[0], latents.shape[1], uniq[0][1] - uniq[0][0]) + tuple(lin.shape[3:]), torch.float16, device)
+                like = ((lin.shape[0], latents.shape[1], uniq[0][1] - uniq[0][0]) + tuple(lin.shape[3:]), lat_dtype, device)
                 outs = dict(zip(uniq, D.sharded_map(uniq, eval_window, like=like) if self.shard_windows
                                 else map(eval_window, uniq)))
                 for (s, e) in wins:
@@ -336,8 +341,9 @@ class VideoUpscalePipeline(ConfigMixin):
             else:
                 guided, x0 = self.scheduler.cfg_step_v0(eps, None, 1.0, t, latents)
             if flows_bi is not None and i in propagation_steps:
-                x0 = self.propagator(x0, flows_f, flows_b, interpolation="nearest", mode="fuse", fuse_scale=0.5,
-                                     alpha1=0.001, alpha2=0.05).contiguous()
+                # the propagation kernel replays the reference's fp16 warp (bit-exact against it on half tensors)
+                x0 = self.propagator(x0.to(torch.float16), flows_f, flows_b, interpolation="nearest", mode="fuse",
+                                     fuse_scale=0.5, alpha1=0.001, alpha2=0.05).to(lat_dtype).contiguous()
             latents = self.scheduler.step_vt(x0, guided, t, latents).prev_sample
             if self.latents_trace is not None:        # test hook: per-step latents (error-vs-step curves)
                 self.latents_trace.append(latents.clone())

@@ -149,12 +149,14 @@ class Downsample3D(E.EngineModule):
         self.conv = conv
 
     def run(self, x, g: E.Geom):
+        s32 = x.dtype == torch.float32           # fp32 residual stream: x is this conv's MFMA operand, the output is stream
+        x = ops.cast_f16(x)
         if self.padding == 0:
             # reference pads (0,1,0,1) then convolves with pad 0 (resnet.py:188-192): the right /
             # bottom taps that fall outside read zeros in the gather, no padded copy is made
             g2 = g.with_hw((g.h + 1 - 3) // 2 + 1, (g.w + 1 - 3) // 2 + 1)
-            return self.conv.run(x, g, out_hw=(g2.h, g2.w), gn_groups=E.GN_GROUPS_HINT), g2
-        return self.conv.run(x, g, gn_groups=E.GN_GROUPS_HINT), self.conv.out_geom(g)
+            return self.conv.run(x, g, out_hw=(g2.h, g2.w), out_f32=s32, gn_groups=E.GN_GROUPS_HINT), g2
+        return self.conv.run(x, g, out_f32=s32, gn_groups=E.GN_GROUPS_HINT), self.conv.out_geom(g)
 
     def forward(self, hidden_states):
         rows, g = E.to_rows(hidden_states, c_pad=self.channels)
@@ -183,19 +185,22 @@ class _ResnetBase(E.EngineModule):
         self.use_in_shortcut = in_channels != out_channels if use_in_shortcut is None else use_in_shortcut
         self.conv_shortcut = make_shortcut(in_channels, out_channels) if self.use_in_shortcut else None
 
-    def run(self, x, g: E.Geom, temb=None, x2=None, c_real=None, stream_f32=None):
+    def run(self, x, g: E.Geom, temb=None, x2=None, c_real=None, stream_f32=None, out_f32=None):
         """x (and optional channel-concatenated x2): rows of in_channels; temb: fp32 [B][temb_ch].
+        out_f32=False: the block's OUTPUT is only ever read as an MFMA operand (TemporalModule3D's tail block feeds the
+        1x1 shift_conv), so it is written in fp16 even when the block runs on an fp32 stream.
 
         Stream dtype: with fp32 rows in (or `stream_f32=True`) the block keeps its conv outputs, the residual sum and
         the GroupNorm inputs in fp32 — only the MFMA operands (GroupNorm outputs) are fp16, i.e. ONE fp16 rounding per
         conv instead of three (conv out, residual sum, norm out).  The VAE decoder runs this way by default because
-        the reference decodes in fp32 (pipeline_upscale_a_video.py:668-681); the UNet keeps fp16 rows like the
-        reference's `.half()` UNet."""
+        the reference decodes in fp32 (pipeline_upscale_a_video.py:668-681); the UNet follows its `stream_dtype`
+        (unet_video.py)."""
         s32 = (x.dtype == torch.float32) if stream_f32 is None else bool(stream_f32)
+        o32 = s32 if out_f32 is None else bool(out_f32)
         h = E.group_norm(self, "norm1", self.norm1, x, n_inst=g.b, rows_per_inst=g.rows_per_batch, silu=True, x2=x2,
                          c_real=c_real)
         rb = _temb_rows(self, temb) if (temb is not None and self.time_emb_proj is not None) else None
-        h = self.conv1.run(h, g, rowbias=rb, out_f32=s32, gn_groups=self.norm2.num_groups)
+        h = self.conv1.run(h, g, rowbias=rb, out_f32=s32 and E.BRANCH_F32, gn_groups=self.norm2.num_groups)
         h = E.group_norm(self, "norm2", self.norm2, h, n_inst=g.b, rows_per_inst=g.rows_per_batch, silu=True)
         if self.conv_shortcut is not None:
             xs = ops.cast_f16(x)                  # the shortcut conv reads the stream as an MFMA operand
@@ -208,7 +213,7 @@ class _ResnetBase(E.EngineModule):
                 raise ops._lib.UavError("fp32 stream requested for an fp16 identity shortcut")
             res = x
         # the block's output is the stream the next block normalises (with this block's group count, as a rule)
-        return self.conv2.run(h, g, residual=res, out_scale=1.0 / self.output_scale_factor, out_f32=s32,
+        return self.conv2.run(h, g, residual=res, out_scale=1.0 / self.output_scale_factor, out_f32=o32,
                               gn_groups=self.norm2.num_groups)
 
     def forward(self, input_tensor, temb=None):
@@ -259,7 +264,7 @@ class ResnetBlock3D_plus(ResnetBlock3D):
         self.conv_3d = Conv3dK11(self.out_channels, self.out_channels, kernel_size=(3, 3, 3), stride=(1, 1, 1),
                                  padding=(1, 1, 1))
 
-    def run(self, x, g: E.Geom, temb=None, x2=None, c_real=None, stream_f32=None):
+    def run(self, x, g: E.Geom, temb=None, x2=None, c_real=None, stream_f32=None, out_f32=None):
         out = super().run(x, g, temb, x2=x2, c_real=c_real, stream_f32=stream_f32)
         h = E.group_norm(self, "norm_3d", self.norm_3d, out, n_inst=g.b, rows_per_inst=g.rows_per_batch, silu=True)
         return self.conv_3d.run(h, g, residual=out, out_scale=1.0 / self.output_scale_factor,

@@ -116,7 +116,7 @@ class DDIMScheduler(ConfigMixin):
 
     def step_v0(self, model_output, timestep, sample, eta: float = 0.0, use_clipped_model_output: bool = False,
                 generator=None, variance_noise=None, return_dict: bool = True):
-        _, x0 = self.cfg_step_v0(_h(model_output), None, 1.0, timestep, _h(sample))
+        _, x0 = self.cfg_step_v0(_c(model_output, sample), None, 1.0, timestep, _c(sample))
         x0 = x0.to(sample.dtype)
         return DDIMSchedulerOutput(pred_original_sample=x0) if return_dict else (x0,)
 
@@ -125,7 +125,7 @@ class DDIMScheduler(ConfigMixin):
         if eta != 0.0 or use_clipped_model_output:
             raise NotImplementedError("the pipeline always steps with eta = 0")
         c0, cd, em, es, e0 = self.vt_coefficients(timestep)
-        prev = ops.ddim_vt(_h(v0), _h(model_output), _h(sample), coef_x0=c0, coef_dir=cd, eps_from_model=em,
+        prev = ops.ddim_vt(_c(v0, sample), _c(model_output, sample), _c(sample), coef_x0=c0, coef_dir=cd, eps_from_model=em,
                            eps_from_sample=es, eps_from_x0=e0, clip=bool(self.config.clip_sample),
                            clip_range=float(self.config.clip_sample_range)).to(sample.dtype)
         return DDIMSchedulerOutput(prev_sample=prev) if return_dict else (prev,)
@@ -138,7 +138,7 @@ class DDIMScheduler(ConfigMixin):
 
     def add_noise(self, original_samples, noise, timesteps):
         a = float(self.alphas_cumprod[int(torch.as_tensor(timesteps).reshape(-1)[0])])
-        return ops.axpby(_h(original_samples), _h(noise), a ** 0.5, (1.0 - a) ** 0.5).to(original_samples.dtype)
+        return ops.axpby(_c(original_samples), _c(noise, original_samples), a ** 0.5, (1.0 - a) ** 0.5).to(original_samples.dtype)
 
     def __len__(self):
         return self.config.num_train_timesteps
@@ -146,6 +146,14 @@ class DDIMScheduler(ConfigMixin):
 
 def _h(t):
     return t.contiguous() if t.dtype == torch.float16 else t.half().contiguous()
+
+
+def _c(t, like=None):
+    """Scheduler operand: fp32 tensors stay fp32 (high-precision latents, UNet stream_dtype = float32), everything else
+    is fp16 like the reference's half pipeline; `like` forces the dtype of the step's sample."""
+    dt = (like.dtype if like is not None else t.dtype)
+    dt = torch.float32 if dt == torch.float32 else torch.float16
+    return t.to(dt).contiguous()
 
 
 class DDPMScheduler(ConfigMixin):
@@ -160,4 +168,4 @@ class DDPMScheduler(ConfigMixin):
 
     def add_noise(self, original_samples, noise, timesteps):
         a = float(self.alphas_cumprod[int(torch.as_tensor(timesteps).reshape(-1)[0])])
-        return ops.axpby(_h(original_samples), _h(noise), a ** 0.5, (1.0 - a) ** 0.5).to(original_samples.dtype)
+        return ops.axpby(_c(original_samples), _c(noise, original_samples), a ** 0.5, (1.0 - a) ** 0.5).to(original_samples.dtype)

@@ -5,6 +5,7 @@
 forward: ResnetBlock3DCNN (5,1,1)+(3,1,1) with temb -> ResnetBlock3D 3x3+3x3 with temb ->
 1x1 `shift_conv` -> input + h; the final add rides in the shift_conv GEMM epilogue.
 """
+import torch
 import torch.nn as nn
 
 from uav import engine as E
@@ -40,11 +41,12 @@ class TemporalModule3D(E.EngineModule):
             p.detach().zero_()
 
     def run(self, x, g: E.Geom, temb=None, w=1.0):
+        s32 = x.dtype == torch.float32           # fp32 residual stream (UNetVideoModel.stream_dtype)
         h = self.resblocks_3d_temporal.run(x, g, temb)
-        h = self.resblocks_3d_spatial.run(h, g, temb)
+        h = self.resblocks_3d_spatial.run(h, g, temb, out_f32=False)      # only read as shift_conv's MFMA operand
         if w != 1.0:
             raise NotImplementedError("w != 1 is never used by the pipeline")
-        return self.shift_conv.run(h, g, residual=x, gn_groups=E.GN_GROUPS_HINT)
+        return self.shift_conv.run(h, g, residual=x, out_f32=s32, gn_groups=E.GN_GROUPS_HINT)
 
     def forward(self, hidden_states, w=1, encoder_hidden_states=None, timesteps=None, temb=None, attention_mask=None):
         rows, g = E.to_rows(hidden_states, c_pad=self.in_channels)

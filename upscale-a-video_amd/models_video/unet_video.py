@@ -24,6 +24,7 @@ from uav import ops
 
 # CFG-shared head: its skip tensors are kept once and read batch-broadcast (UAV_BROADCAST_SKIPS=0: duplicated with cat)
 BROADCAST_SKIPS = os.environ.get("UAV_BROADCAST_SKIPS", "1") != "0"
+DEFAULT_STREAM = "f16"
 
 from ._compat import BaseOutput, ConfigMixin, ModelMixin, register_to_config
 from .attention import RotaryEmbedding
@@ -171,6 +172,12 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
         self.conv_norm_out = nn.GroupNorm(num_channels=block_out_channels[0], num_groups=norm_num_groups, eps=norm_eps)
         self.conv_act = nn.SiLU()
         self.conv_out = InflatedConv3d(block_out_channels[0], out_channels, kernel_size=3, padding=1)
+        # Precision of the residual stream (conv outputs, residual sums, skip tensors, GroupNorm / LayerNorm INPUTS).
+        # torch.float32: fp32 rows, only the MFMA operands (norm outputs, attention q/k/v/p, GEGLU output) are fp16 — one
+        # fp16 rounding per contraction instead of one per stored tensor; torch.float16: every stored tensor is fp16, the
+        # arithmetic of the reference's `.half()` UNet (inference_upscale_a_video.py:113-118).  None: UAV_UNET_STREAM
+        # (f32 | f16), see DESIGN.md §4 for the measured parity / cost of both.
+        self.stream_dtype = None
 
     # ------------------------------------------------------------------------------------------
     def _embedding(self, timestep, class_labels, bsz, dev):
@@ -199,6 +206,12 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
             emb = emb + ce                                                       # broadcast (1|B, D)
         return emb.contiguous()
 
+    def stream_f32(self):
+        sd = self.stream_dtype
+        if sd is None:
+            return os.environ.get("UAV_UNET_STREAM", DEFAULT_STREAM) == "f32"
+        return sd == torch.float32
+
     @E.guarded
     def forward(self, sample, timestep, low_res, encoder_hidden_states=None, class_labels=20, attention_mask=None,
                 return_dict: bool = True, cfg_shared_input: bool = False):
@@ -207,6 +220,7 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
         if sample.shape[1] + low_res.shape[1] != self.config.in_channels:
             raise ValueError(f"expected {self.config.in_channels} input channels, got {sample.shape[1]}+{low_res.shape[1]}")
         dev = sample.device
+        s32 = self.stream_f32()
         if self.config.center_input_sample:
             # the reference centres the CONCATENATED [sample, low_res] tensor (unet_video.py:440-454)
             sample = 2 * sample - 1.0
@@ -232,7 +246,7 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
             rows1 = g.rows // 2
             g1 = E.Geom(1, g.t, g.h, g.w)
             emb1 = emb[:1].contiguous()
-            x1 = self.conv_in.run(x[:rows1], g1)
+            x1 = self.conv_in.run(x[:rows1], g1, out_f32=s32)
             skips1 = [(x1, g1)]
             x1, g1, outs = self.down_blocks[0].run(x1, g1, emb1, ehs_rows, n_text)
             skips1.extend(outs)
@@ -242,7 +256,7 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
             x, g = ops.duplicate_rows(x1), E.Geom(2, g1.t, g1.h, g1.w)
             first = 1
         else:
-            x = self.conv_in.run(x, g)
+            x = self.conv_in.run(x, g, out_f32=s32)
             skips = [(x, g)]
         for blk, tblk in list(zip(self.down_blocks, self.down_temp_blocks))[first:]:
             x, g, outs = blk.run(x, g, emb, ehs_rows, n_text)

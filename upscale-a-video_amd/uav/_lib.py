@@ -54,6 +54,7 @@ SIGNATURES = {
     "uav_groupnorm_scale_shift": (C.c_int, [c_p, c_p, i32, i32, i32, i64, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
     "uav_groupnorm_apply": (C.c_int, [c_p, c_p, i32, i32, i32, i64, i32, i64, c_p, c_p, i32, c_p, c_p]),
     "uav_layernorm_f16": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, f32, c_p]),
+    "uav_layernorm_f32in": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, f32, c_p]),
     "uav_attention_f16": (C.c_int, [c_p, i64, c_p, i64, c_p, i64, c_p, i64, i32, i32, i32, i32, i32, i32, f32, i32, c_p, c_p]),
     "uav_temporal_attention_f16": (C.c_int, [c_p, c_p, i32, i32, i64, i32, i32, f32, c_p, c_p, i32, c_p, c_p]),
     "uav_linear_small": (C.c_int, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, c_p]),
@@ -61,7 +62,9 @@ SIGNATURES = {
     "uav_pack_nhwc": (C.c_int, [c_p, i32, c_p, i32, i32, c_p, i32, i32, i32, i64, f32, c_p]),
     "uav_unpack_ncthw": (C.c_int, [c_p, i32, i32, c_p, i32, i32, i32, i32, i64, f32, f32, c_p]),
     "uav_cfg_ddim_v0": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, f32, f32, f32, i32, f32, c_p]),
+    "uav_cfg_ddim_v0_f32": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i64, f32, f32, f32, i32, f32, c_p]),
     "uav_ddim_vt": (C.c_int, [c_p, c_p, c_p, c_p, i64, f32, f32, f32, f32, f32, i32, f32, c_p]),
+    "uav_ddim_vt_f32": (C.c_int, [c_p, c_p, c_p, c_p, i64, f32, f32, f32, f32, f32, i32, f32, c_p]),
     "uav_axpby_f16": (C.c_int, [c_p, c_p, c_p, i64, f32, f32, c_p]),
     "uav_cast_f32_f16": (C.c_int, [c_p, c_p, i64, c_p]),
     "uav_sft_fuse": (C.c_int, [c_p, c_p, c_p, c_p, i64, f32, i32, i32, c_p]),

@@ -169,6 +169,12 @@ def f16_param(mod: EngineModule, name, tensor):
     return mod._cache().get(("f16", name), build, (tensor,))
 
 
+# fp32-stream blocks (VAE decoder always; UNet with stream_dtype = float32): is the ResNet BRANCH tensor between conv1 and
+# norm2 kept in fp32 as well (1), or rounded to fp16 like an MFMA operand (0)?  UAV_BRANCH_F32, default 1.
+import os as _os
+BRANCH_F32 = _os.environ.get("UAV_BRANCH_F32", "1") != "0"
+
+
 # Group count a conv assumes for the GroupNorm that (probably) consumes its output when the caller cannot name that
 # consumer (up / down samplers, TemporalModule3D.shift_conv, the decoder's conv_in): every GroupNorm of the released
 # configs has 32 groups (norm_num_groups / resnet_groups).  A miss only leaves the partials unused (ops.conv_gemm).

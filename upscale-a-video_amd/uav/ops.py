@@ -289,10 +289,16 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
         _gn_attach(out, gn)
     elif getattr(out, "_uav_gn", None) is not None:      # caller-supplied buffer rewritten without statistics
         out._uav_gn = None
-    # algorithmic work: 2*M*N*K over the LOGICAL taps x input channels (no padding counted)
+    # algorithmic work: 2*M*N*K over the LOGICAL taps x input channels (no channel / tile padding counted); temporal taps
+    # that fall outside the clip (zero padding of a (k,1,1) / 3x3x3 conv at the clip ends, which the kernel skips) are
+    # not counted either
+    tfrac = 1.0
+    if ev is not None and wt.kt > 1:
+        valid = sum(1 for t_ in range(t_len) for dt in range(wt.kt) if 0 <= t_ + dt - pt < t_len)
+        tfrac = valid / float(wt.kt * t_len)
     PROFILER.end(ev, "conv_gemm" if not PROFILER.detail else
                  f"conv_gemm cin={wt.cin} n={wt.n} k={wt.kt}x{wt.kh}x{wt.kw} M={m}{' geglu' if wt.geglu else ''}{' up' if upsample else ''}{' s2' if stride == 2 else ''}",
-                 2.0 * m * wt.n * wt.kt * wt.kh * wt.kw * wt.cin,
+                 2.0 * m * wt.n * wt.kt * wt.kh * wt.kw * wt.cin * tfrac,
                  2.0 * (n_img * hi * wi * wt.cin + m * n_out) + 2.0 * wt.n * wt.kt * wt.kh * wt.kw * wt.cin)
     return out
 
@@ -429,13 +435,16 @@ def groupnorm(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps, silu, x2=N
 
 
 def layernorm(x, gamma, beta, eps=1e-5):
+    """fp16 LayerNorm output (an MFMA operand) of fp16 rows, or of fp32 rows (fp32 residual stream)."""
     lib = _lib.load()
-    _req(x, HALF, "x")
-    y = torch.empty_like(x)
+    f32 = x.dtype == torch.float32
+    _req(x, torch.float32 if f32 else HALF, "x")
+    y = torch.empty(x.shape, dtype=HALF, device=x.device)
     rows, c = x.numel() // x.shape[-1], x.shape[-1]
     ev = PROFILER.begin("layernorm")
-    _lib.check(lib.uav_layernorm_f16(_p(x), _p(y), _p(gamma), _p(beta), rows, c, eps, _stream()), "uav_layernorm_f16")
-    PROFILER.end(ev, "layernorm", 0.0, 4.0 * rows * c)
+    fn = lib.uav_layernorm_f32in if f32 else lib.uav_layernorm_f16
+    _lib.check(fn(_p(x), _p(y), _p(gamma), _p(beta), rows, c, eps, _stream()), "uav_layernorm")
+    PROFILER.end(ev, "layernorm", 0.0, (6.0 if f32 else 4.0) * rows * c)
     return y
 
 
@@ -524,26 +533,42 @@ def unpack_ncthw(src, *, c, n_batch, t_len, h, w, out_dtype=HALF, clamp=None):
 
 
 def cfg_ddim_v0(eps_uncond, eps_text, sample, *, guidance, coef_sample, coef_eps, clip=False, clip_range=1.0):
+    """CFG combine + DDIM step_v0; all tensors fp16 (the reference's half arithmetic) or all fp32."""
     lib = _lib.load()
-    _req(eps_uncond, HALF, "eps"); _req(sample, HALF, "sample")
+    dt = _sched_dtype(sample, eps_uncond, eps_text)
     g = torch.empty_like(sample); x0 = torch.empty_like(sample)
-    rc = lib.uav_cfg_ddim_v0(_p(eps_uncond), _p(eps_text), _p(sample), _p(g), _p(x0), sample.numel(), guidance,
-                             coef_sample, coef_eps, int(clip), clip_range, _stream())
+    fn = lib.uav_cfg_ddim_v0_f32 if dt == torch.float32 else lib.uav_cfg_ddim_v0
+    rc = fn(_p(eps_uncond), _p(eps_text), _p(sample), _p(g), _p(x0), sample.numel(), guidance,
+            coef_sample, coef_eps, int(clip), clip_range, _stream())
     _lib.check(rc, "uav_cfg_ddim_v0")
     return g, x0
+
+
+def _sched_dtype(*ts):
+    dt = ts[0].dtype
+    if dt not in (HALF, torch.float32):
+        raise _lib.UavError(f"scheduler tensors must be fp16 or fp32, got {dt}")
+    for t in ts:
+        if t is not None:
+            _req(t, dt, "scheduler tensor")
+    return dt
 
 
 def ddim_vt(x0, guided, sample, *, coef_x0, coef_dir, eps_from_model, eps_from_sample, eps_from_x0=0.0, clip=False,
             clip_range=1.0):
     lib = _lib.load()
+    dt = _sched_dtype(sample, x0, guided)
     prev = torch.empty_like(sample)
-    rc = lib.uav_ddim_vt(_p(_req(x0, HALF)), _p(_req(guided, HALF)), _p(_req(sample, HALF)), _p(prev), sample.numel(),
-                         coef_x0, coef_dir, eps_from_model, eps_from_sample, eps_from_x0, int(clip), clip_range, _stream())
+    fn = lib.uav_ddim_vt_f32 if dt == torch.float32 else lib.uav_ddim_vt
+    rc = fn(_p(x0), _p(guided), _p(sample), _p(prev), sample.numel(),
+            coef_x0, coef_dir, eps_from_model, eps_from_sample, eps_from_x0, int(clip), clip_range, _stream())
     _lib.check(rc, "uav_ddim_vt")
     return prev
 
 
 def axpby(x, z, a, b):
+    if x.dtype == torch.float32:
+        return axpby_f32(x, z, a, b)
     lib = _lib.load()
     y = torch.empty_like(x)
     _lib.check(lib.uav_axpby_f16(_p(_req(x, HALF)), _p(_req(z, HALF)), _p(y), x.numel(), a, b, _stream()), "uav_axpby_f16")
