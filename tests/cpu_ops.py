@@ -94,10 +94,13 @@ def linear(x, wt, *, residual=None, out_scale=1.0, rowbias=None, rows_per_batch=
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def groupnorm(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps, silu, x2=None, c_real=None):
+def groupnorm(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps, silu, x2=None, c_real=None, want_raw=False):
     if x2 is not None and x2.shape[0] * 2 == x1.shape[0]:                             # skip tensor read batch-broadcast
         x2 = torch.cat([x2, x2])
     x = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], dim=-1)
+    if want_raw:
+        return groupnorm(x1, gamma, beta, n_inst=n_inst, rows_per_inst=rows_per_inst, groups=groups, eps=eps, silu=silu,
+                         x2=x2, c_real=c_real), _h(x)
     c = x.shape[-1]
     c_real = c if c_real is None else c_real
     xr = x[:, :c_real].reshape(n_inst, rows_per_inst, groups, c_real // groups).double()

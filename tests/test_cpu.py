@@ -868,9 +868,35 @@ def _dist_worker(rank, world, port, q):
     img_shard, lat_shard = rp("p", generator=torch.Generator().manual_seed(10), **kw14)
     pipe_same = torch.equal(img_serial, img_shard) and torch.equal(lat_serial, lat_shard)
     n_shard = len(ucalls) - n_serial
+    # --- (window x guidance branch) units: 2 windows x 2 branches x 2 steps = 8 batch-1 UNet calls, 4 per rank; bit-identical
+    # to the SAME decomposition evaluated serially, and equal to the batch-2 schedule up to fp32 summation order ---
+    rp.shard_cfg = True
+    n0 = len(ucalls)
+    img_cfg, lat_cfg = rp("p", generator=torch.Generator().manual_seed(10), **kw14)
+    n_cfg = len(ucalls) - n0
+    cfg_shapes = sorted({c[0][0] for c in ucalls[n0:]})
+    import models_video.pipeline_upscale_a_video as PM
+    real_map = PM.D.sharded_map
+    PM.D.sharded_map = lambda items, fn, **kw: [fn(it) for it in items]
+    try:
+        img_cfg_serial, lat_cfg_serial = rp("p", generator=torch.Generator().manual_seed(10), **kw14)
+    finally:
+        PM.D.sharded_map = real_map
+    cfg_same = torch.equal(img_cfg, img_cfg_serial) and torch.equal(lat_cfg, lat_cfg_serial)
+    cfg_close = float((lat_cfg.float() - lat_serial.float()).norm() / lat_serial.float().norm())
+    # one 8-frame clip (single window): the two guidance branches are the two units
+    clip8 = synth.synth_clip(1, 8, 16, 16, seed=8)
+    kw8 = dict(kw14, image=clip8)
+    n0 = len(ucalls)
+    img8, lat8 = rp("p", generator=torch.Generator().manual_seed(10), **kw8)
+    n8 = len(ucalls) - n0
+    rp.shard_windows = rp.shard_cfg = False
+    img8_ref, lat8_ref = rp("p", generator=torch.Generator().manual_seed(10), **kw8)
+    close8 = float((lat8.float() - lat8_ref.float()).norm() / lat8_ref.float().norm())
     _restore_ops(ns)
     q.put((r, mine, elapsed, total, gathered, torch.equal(sharded, serial), n_local, len(uniq),
-           [float(c.flatten()[0]) for c in chunks], float(single[0][0]), tiles_same, pipe_same, n_serial, n_shard))
+           [float(c.flatten()[0]) for c in chunks], float(single[0][0]), tiles_same, pipe_same, n_serial, n_shard,
+           cfg_same, n_cfg, cfg_shapes, cfg_close, n8, close8))
     D.finalize()
 
 
@@ -892,7 +918,11 @@ def test_dist_gloo_world2():
     assert g0 == [[0, 2, 4, 6], [1, 3, 5]] and g1 is None
     # window-sharded long clip: bit-identical to the serial schedule on BOTH ranks, each rank ran only its share
     for x in (x0, x1):
-        same, n_local, n_uniq, chunk_ids, single, tiles_same, pipe_same, n_serial, n_shard = x
+        same, n_local, n_uniq, chunk_ids, single, tiles_same, pipe_same, n_serial, n_shard, cfg_same, n_cfg, cfg_shapes, cfg_close, n8, close8 = x
+        assert cfg_same                            # (window x guidance branch) units: sharded == serial, bit for bit
+        assert n_cfg == 4 and cfg_shapes == [1]    # 8 batch-1 UNet calls per clip, 4 on each rank
+        assert cfg_close < 1e-3 and close8 < 1e-3  # == the batch-2 schedule up to summation order (fp16 latents between steps)
+        assert n8 == 2                             # ONE 8-frame clip on 2 ranks: one guidance branch per rank and step
         assert tiles_same                          # tile-sharded clip == serial CLI loop, on both ranks
         assert pipe_same                           # VideoUpscalePipeline(shard_windows=True) == serial call, bit for bit
         assert n_serial == 4 and n_shard == 2      # 2 unique windows x 2 steps; each rank evaluates one window per step

@@ -60,6 +60,29 @@ def test_unet_forward_host_side(cpu_engine, unet_and_sd, name, shape):
     assert rel_l2(out, gold) <= noise, (rel_l2(out, gold), noise)
 
 
+def test_unet_forward_host_side_fp32_stream(cpu_engine, unet_and_sd):
+    """UNetVideoModel.stream_dtype = float32 (fp32 residual stream, fp16 MFMA operands): the host orchestration — which
+    tensors are fp32 (conv outputs, skip stack, token stream, GroupNorm / LayerNorm inputs), which are fp16 operands (norm
+    outputs, the raw copy for the shortcut conv, block tails feeding proj_out / shift_conv) — against the reference
+    fixture; clearly below the fp16-row mode and below the reference's own fp16 noise."""
+    unet, usd = unet_and_sd
+    name, shape = "unet_t3_20x28", (2, 3, 20, 28)
+    sample, low, ehs, ts, cl = GC.unet_inputs(*shape, GC.UNET_TINY["cross_attention_dim"])
+    gold = torch.load(os.path.join(GOLD, name + ".pt"))
+    noise = json.load(open(os.path.join(GOLD, "PINNING.json")))["cases"][name]["reference_fp16_vs_fp32_rel_l2"]
+    errs = {}
+    try:
+        for mode, dt in (("f16", torch.float16), ("f32", torch.float32)):
+            unet.stream_dtype = dt
+            with torch.no_grad():
+                out = unet(sample, ts, low, encoder_hidden_states=ehs.half(), class_labels=cl).sample      # fp32 in -> fp32 out
+            assert out.dtype == torch.float32
+            errs[mode] = rel_l2(out, gold)
+    finally:
+        unet.stream_dtype = None
+    assert errs["f32"] < 0.75 * errs["f16"] and errs["f32"] < 0.7 * noise, (errs, noise)
+
+
 def test_unet_cfg_shared_head_host_side(cpu_engine, unet_and_sd):
     unet, _ = unet_and_sd
     sample, low, ehs, ts, cl = GC.unet_inputs(1, 3, 16, 16, GC.UNET_TINY["cross_attention_dim"])
@@ -210,3 +233,54 @@ def test_propagation_module_host_side(cpu_engine, interp):
                                           alpha1=0.001, alpha2=0.05)
     gold = torch.load(os.path.join(GOLD, f"propagation_{interp}.pt"))
     assert rel_l2(out, gold) < 5e-3
+
+
+def test_packed_cache_invalidation_rules(cpu_engine):
+    """what the packed-weight stamp sees and what it does not.  `p.copy_` (in-place on the Parameter) bumps
+    `p._version` -> repacked automatically; `p.data.copy_` writes through a detached alias with its own version counter ->
+    invisible, the documented remedy is `engine.invalidate_packed(model)` (also what `init_weights.random_init_` calls)."""
+    from models_video.resnet import InflatedConv3d
+    from uav import engine as E
+    conv = InflatedConv3d(64, 64, 1).eval()
+    x = torch.randn(1, 64, 1, 4, 4)
+    with torch.no_grad():
+        y0 = conv(x)
+        w_new = torch.randn_like(conv.weight)
+        conv.weight.copy_(w_new)                                   # visible: version counter of the Parameter moves
+        y1 = conv(x)
+        assert rel_l2(y1, torch.nn.functional.conv2d(x[:, :, 0], w_new, conv.bias)[:, :, None]) < 2e-3
+        assert rel_l2(y1, y0) > 0.5
+        w_new2 = torch.randn_like(conv.weight)
+        v = conv.weight._version
+        conv.weight.data.copy_(w_new2)                             # invisible to the stamp ...
+        assert conv.weight._version == v
+        y_stale = conv(x)
+        assert torch.equal(y_stale, y1)                            # ... so the packed copy of the old weights is served
+        E.invalidate_packed(conv)                                  # the documented remedy
+        y2 = conv(x)
+        assert rel_l2(y2, torch.nn.functional.conv2d(x[:, :, 0], w_new2, conv.bias)[:, :, None]) < 2e-3
+
+
+def test_oracle_under_gpu_shim_equals_oracle():
+    """oracle/gpu_shim.py (the GEMM-per-tap convolutions that let the oracle run on the GPU without MIOpen) on the CPU:
+    the tiny UNet and both tiny VAE decoders give the same result as the plain oracle (fp32 summation order only)."""
+    import gpu_shim
+    from models_video.unet_video import UNetVideoModel
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    usd = synth.synth_state_dict(UNetVideoModel.from_config(dict(GC.UNET_TINY)).state_dict(), seed=1234)
+    sample, low, ehs, ts, cl = GC.unet_inputs(2, 3, 20, 28, GC.UNET_TINY["cross_attention_dim"])
+    with torch.no_grad():
+        a = O.unet_forward(usd, GC.UNET_TINY, sample, ts, low, ehs, cl)
+    with gpu_shim.oracle_on("cpu") as OS:
+        b = OS.unet_forward(usd, GC.UNET_TINY, sample, ts, low, ehs, cl)
+    assert rel_l2(b, a) < 1e-5
+    assert rel_l2(a, torch.load(os.path.join(GOLD, "unet_t3_20x28.pt"))) < 1e-3        # fixture stored in fp16
+    for cfg in (GC.VAE3D_TINY, GC.VAEVIDEO_TINY):
+        vsd = synth.synth_state_dict(AutoencoderKLVideo.from_config(dict(cfg)).state_dict(), seed=4321)
+        z, img = GC.vae_inputs(1, 3, 16, 16)
+        with torch.no_grad():
+            a = O.vae_decode(vsd, cfg, z, img, 1.0)
+        with gpu_shim.oracle_on("cpu") as OS:
+            b = OS.vae_decode(vsd, cfg, z, img, 1.0)
+        assert rel_l2(b, a) < 1e-5
+    assert O.F is torch.nn.functional                               # the shim is gone again

@@ -169,8 +169,14 @@ def test_full_width_30_step_curve_vs_reference(full, dev, mode):
     unet = full["unet"]
     unet.stream_dtype = STREAMS[mode]
     res = {}
+    import models_video.pipeline_upscale_a_video as PM
+    real_randn = PM.randn_tensor
+
+    def common_noise(shape, generator=None, device=None, dtype=None, **kw):      # as in make_golden.make_full30_golden
+        return real_randn(shape, generator=generator, device=device, dtype=torch.float32, **kw).to(dtype)
+    PM.randn_tensor = common_noise
     try:
-        for draws in ("fp32", "half"):          # dtype of the text embeddings = dtype of the two randn draws (pipeline:547,573)
+        for draws in ("fp32", "half"):          # dtype of the text embeddings = dtype of the two noise tensors (pipeline:547,573)
             pipe = VideoUpscalePipeline(text_encoder=StandInTextEncoder(tok, dim, dtype=torch.float32 if draws == "fp32" else torch.float16),
                                         tokenizer=tok, low_res_scheduler=DDPMScheduler(), scheduler=DDIMScheduler(**GC.SCHED),
                                         vae=full["vae"], unet=unet, propagator=None).to(dev)
@@ -181,11 +187,12 @@ def test_full_width_30_step_curve_vs_reference(full, dev, mode):
             res[draws] = dict(trace=[x.float().cpu() for x in pipe.latents_trace], img=out.float().cpu())
     finally:
         unet.stream_dtype = None
+        PM.randn_tensor = real_randn
     steps = gold["steps"]
     curve32 = [rel_l2(res["fp32"]["trace"][k - 1], gold["latents_fp32"][i]) for i, k in enumerate(steps)]
     curve16 = [rel_l2(res["half"]["trace"][k - 1], gold["latents_half"][i]) for i, k in enumerate(steps)]
     curve16v32 = [rel_l2(res["half"]["trace"][k - 1], gold["latents_fp32"][i]) for i, k in enumerate(steps)]
-    ref_noise = [pin["reference_half_vs_fp32_latents_rel_l2_per_step"][k - 1] for k in steps]
+    ref_noise = list(pin["reference_half_vs_fp32_latents_rel_l2_at_kept_steps"])
     g32 = gold["images_fp32_sub2"].float()
     unsat = g32.abs() < 0.999
     e_img = rel_l2(res["fp32"]["img"][..., ::2, ::2][unsat], g32[unsat])

@@ -84,7 +84,8 @@ def main():
     try:
         for mode in modes:
             unet.stream_dtype = torch.float32 if mode.startswith("f32") else torch.float16
-            E.BRANCH_F32 = mode != "f32-branch16"
+            E.BRANCH_F32 = "branch16" not in mode
+            E.TOKEN_F32 = "tok16" not in mode
             keep = set(mode.split("+")[1:])
             for k, f in base.items():
                 setattr(ops, k, f)

@@ -78,6 +78,12 @@ class VideoUpscalePipeline(ConfigMixin):
         # one LONG clip over several GPUs (BASELINE config 4): deal the temporal windows of each DDIM step and the decode
         # chunks over the ranks of the default process group; results are bit-identical to the single-GPU call
         self.shard_windows = False
+        # ... at (window x guidance branch) granularity: every UNet evaluation of a DDIM step is split into its
+        # unconditional and its text-conditioned half (two batch-1 calls, the CFG-shared head is given up: +2.7 % FLOP), so
+        # T = 32 gives 10 units per step instead of 5 (speed-up bound 3.3x instead of 2.5x on 4 ranks, 5x instead of 2.5x on
+        # 8) and even one 8-frame clip splits over 2 GPUs.  Only read when `shard_windows` is set; the result is
+        # bit-identical for every world size (the unit decomposition does not depend on it).
+        self.shard_cfg = False
         self.latents_trace = None          # test hook: set to a list to collect the latents after every DDIM step
         self.cache_prompt_embeds = True
         self._prompt_cache = {}
@@ -301,27 +307,35 @@ class VideoUpscalePipeline(ConfigMixin):
                              f" `num_channels_image`: {image.shape[1]}")
 
         wins = window_schedule(t_total)
+        # per-branch text rows as stable objects: the UNet's text K/V caches are keyed on tensor identity
+        pe_branch = [prompt_embeds[b:b + 1].contiguous() for b in range(prompt_embeds.shape[0])] if do_cfg else None
         if flows_bi is not None and len(propagation_steps) > 0:
             flows_f = flows_bi[0].to(device=device, dtype=torch.float16)
             flows_b = flows_bi[1].to(device=device, dtype=torch.float16)
 
         for i, t in enumerate(timesteps):
             lin = torch.cat([latents] * 2) if do_cfg else latents
+            split = self.shard_windows and self.shard_cfg and do_cfg
+
+            def eval_unit(u):
+                """One UNet evaluation: window (s, e) with both guidance branches (b is None) or one of them."""
+                (s_, e_), b = u
+                bs = slice(None) if b is None else slice(b, b + 1)
+                return self.unet(lin[bs, :, s_:e_].contiguous(), t, image[bs, :, s_:e_].contiguous(),
+                                 encoder_hidden_states=prompt_embeds if b is None else pe_branch[b],
+                                 class_labels=level if len(wins) > 1 else level_single,
+                                 cfg_shared_input=do_cfg and self.cfg_shared_input and b is None).sample.contiguous()
+            # the windows of one step are independent UNet evaluations: with `shard_windows` and an initialised process
+            # group the units are dealt over the ranks and all-gathered (uav/dist.py:sharded_map); the blend below is
+            # replayed identically on every rank.  A duplicate tail window is evaluated once.
+            uniq = [w for k, w in enumerate(wins) if w not in wins[:k]]
+            units = [(w, b) for w in uniq for b in ((0, 1) if split else (None,))]
+            like = ((1 if split else lin.shape[0], latents.shape[1], uniq[0][1] - uniq[0][0]) + tuple(lin.shape[3:]), lat_dtype, device)
+            res = D.sharded_map(units, eval_unit, like=like) if self.shard_windows else [eval_unit(u) for u in units]
+            outs = {w: (torch.cat([res[2 * k], res[2 * k + 1]]) if split else res[k]) for k, w in enumerate(uniq)}
             if len(wins) > 1:
                 eps = None
                 written = [False] * t_total
-                # the windows of one step are independent UNet evaluations: with `shard_windows` and an initialised
-                # process group they are dealt over the ranks and all-gathered (uav/dist.py:sharded_map); the blend
-                # below is replayed identically on every rank.  A duplicate tail window is evaluated once.
-                uniq = [w for k, w in enumerate(wins) if w not in wins[:k]]
-
-                def eval_window(se):
-                    return self.unet(lin[:, :, se[0]:se[1]].contiguous(), t, image[:, :, se[0]:se[1]].contiguous(),
-                                     encoder_hidden_states=prompt_embeds, class_labels=level,
-                                     cfg_shared_input=do_cfg and self.cfg_shared_input).sample.contiguous()
-                like = ((lin.shape[0], latents.shape[1], uniq[0][1] - uniq[0][0]) + tuple(lin.shape[3:]), lat_dtype, device)
-                outs = dict(zip(uniq, D.sharded_map(uniq, eval_window, like=like) if self.shard_windows
-                                else map(eval_window, uniq)))
                 for (s, e) in wins:
                     o = outs[(s, e)]
                     if eps is None:
@@ -333,8 +347,7 @@ class VideoUpscalePipeline(ConfigMixin):
                         else:                                                     # running 0.5/0.5 blend (:634)
                             eps[:, :, idx] = ops.axpby(eps[:, :, idx].contiguous(), o[:, :, k].contiguous(), 0.5, 0.5)
             else:
-                eps = self.unet(lin, t, image, encoder_hidden_states=prompt_embeds, class_labels=level_single,
-                                cfg_shared_input=do_cfg and self.cfg_shared_input).sample
+                eps = outs[wins[0]]
             eps = eps.contiguous()
             if do_cfg:
                 guided, x0 = self.scheduler.cfg_step_v0(eps[0:1], eps[1:2], guidance_scale, t, latents)

@@ -197,15 +197,23 @@ class _ResnetBase(E.EngineModule):
         (unet_video.py)."""
         s32 = (x.dtype == torch.float32) if stream_f32 is None else bool(stream_f32)
         o32 = s32 if out_f32 is None else bool(out_f32)
+        # the shortcut conv reads the (concatenated) input as an MFMA operand: with an fp32 stream its fp16 rounding is
+        # written by the norm1 pass, which has the values in registers anyway
+        raw16 = None
+        want_raw = self.conv_shortcut is not None and x.dtype == torch.float32
         h = E.group_norm(self, "norm1", self.norm1, x, n_inst=g.b, rows_per_inst=g.rows_per_batch, silu=True, x2=x2,
-                         c_real=c_real)
+                         c_real=c_real, want_raw=want_raw)
+        if want_raw:
+            h, raw16 = h
         rb = _temb_rows(self, temb) if (temb is not None and self.time_emb_proj is not None) else None
         h = self.conv1.run(h, g, rowbias=rb, out_f32=s32 and E.BRANCH_F32, gn_groups=self.norm2.num_groups)
         h = E.group_norm(self, "norm2", self.norm2, h, n_inst=g.b, rows_per_inst=g.rows_per_batch, silu=True)
         if self.conv_shortcut is not None:
-            xs = ops.cast_f16(x)                  # the shortcut conv reads the stream as an MFMA operand
-            res = self.conv_shortcut.run(xs, g, x2=ops.cast_f16(x2), out_f32=s32) if x2 is not None else \
-                self.conv_shortcut.run(xs, g, out_f32=s32)
+            if raw16 is not None:                 # [x | x2] already concatenated and rounded
+                res = self.conv_shortcut.run(raw16, g, out_f32=s32)
+            else:
+                res = self.conv_shortcut.run(x, g, x2=x2, out_f32=s32) if x2 is not None else \
+                    self.conv_shortcut.run(x, g, out_f32=s32)
         else:
             if x2 is not None:
                 raise ops._lib.UavError("concatenated input needs a shortcut conv")

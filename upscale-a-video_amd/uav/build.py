@@ -96,22 +96,28 @@ def audit_accumulator_file():
     lines = r.stdout.splitlines()
     inside = in_asm = False
     bad = []
+    asm_blocks = 0
     for ln in lines:
         if "attn512w_kernel" in ln and not ln[:1].isspace() and ln.split(";")[0].rstrip().endswith(":"):
             inside = True
             continue
         if not inside:
             continue
-        if "s_endpgm" in ln:
+        # the function ends at its .Lfunc_end label / .size directive, not at the first s_endpgm (early-exit branches
+        # emit several)
+        if ln.startswith(".Lfunc_end") or (ln.lstrip().startswith(".size") and "attn512w_kernel" in ln):
             break
         if "#ASMSTART" in ln:
             in_asm = True
+            asm_blocks += 1
         elif "#ASMEND" in ln:
             in_asm = False
         elif not in_asm and not ln.lstrip().startswith(";") and ("v_accvgpr" in ln or " a[" in ln or ",a[" in ln):
             bad.append(ln.strip())
     if not inside:
         raise RuntimeError("audit: attn512w_kernel not found in the assembly of attention.hip")
+    if asm_blocks == 0:
+        raise RuntimeError("audit: no inline-asm block seen inside attn512w_kernel — the scan did not cover the kernel body")
     if bad:
         raise RuntimeError("audit: hipcc uses the accumulator file inside attn512w_kernel, which names a[0:255] from inline asm:\n  "
                            + "\n  ".join(bad[:8]))

@@ -41,16 +41,30 @@ class Geom:
 
 
 def _stamp(tensors):
-    """Identity of a parameter's CURRENT value: storage pointer + in-place version counter (bumped by copy_, mul_,
-    `random_init_`, optimiser steps ...); replaced / cast / moved parameters get a new pointer."""
+    """Identity of a parameter's CURRENT value as far as autograd's bookkeeping shows it: storage pointer + the tensor's
+    in-place version counter (bumped by `p.copy_`, `p.mul_`, `random_init_`, optimiser steps, load_state_dict on a plain
+    nn.Linear child ...); replaced / cast / moved parameters get a new pointer.  NOT covered: writes through `p.data`
+    (`p.data.copy_(w)` — `.data` is a detached alias with its OWN version counter, `p._version` stays put) and raw-pointer
+    writes; after those call `invalidate_packed(model)`."""
     return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
 
 
+def invalidate_packed(model: nn.Module):
+    """Drop every packed-weight / table cache under `model` (all EngineModule children).  Needed after weight edits the
+    stamp cannot see: `p.data.copy_(...)`, `p.data.normal_()`, writes from another framework through the data pointer."""
+    for m in model.modules():
+        c = m.__dict__.get("_uav_cache")
+        if c is not None:
+            c.clear()
+        m.__dict__.pop("_ehs_src", None)
+    return model
+
+
 class PackedCache:
-    """Per-model cache of packed weights.  Dropped wholesale on _apply / load_state_dict, and every entry carries the
-    stamp of the parameters it was built from, so in-place edits after the first forward (`p.data.copy_`,
-    `init_weights.random_init_`, load_state_dict on a plain nn.Linear child) rebuild it instead of silently serving
-    stale packed fp16 weights."""
+    """Per-model cache of packed weights.  Dropped wholesale on _apply / load_state_dict / `invalidate_packed`, and every
+    entry carries the stamp of the parameters it was built from, so in-place edits of the PARAMETER after the first
+    forward (`p.copy_`, `init_weights.random_init_`, load_state_dict on a plain nn.Linear child) rebuild it instead of
+    serving stale packed fp16 weights.  Edits through `p.data` are invisible to the stamp (see `_stamp`)."""
 
     def __init__(self):
         self.store = {}
@@ -173,6 +187,9 @@ def f16_param(mod: EngineModule, name, tensor):
 # norm2 kept in fp32 as well (1), or rounded to fp16 like an MFMA operand (0)?  UAV_BRANCH_F32, default 1.
 import os as _os
 BRANCH_F32 = _os.environ.get("UAV_BRANCH_F32", "1") != "0"
+# ... and is the TOKEN stream inside a Transformer3DModel (proj_in output, the four residual adds of the block) fp32 (1) or
+# fp16 (0: only the block stream around the transformer is fp32)?  UAV_TOKEN_F32, default 1.
+TOKEN_F32 = _os.environ.get("UAV_TOKEN_F32", "1") != "0"
 
 
 # Group count a conv assumes for the GroupNorm that (probably) consumes its output when the caller cannot name that
@@ -181,11 +198,12 @@ BRANCH_F32 = _os.environ.get("UAV_BRANCH_F32", "1") != "0"
 GN_GROUPS_HINT = 32
 
 
-def group_norm(mod: EngineModule, name, gn: nn.GroupNorm, x, *, n_inst, rows_per_inst, silu, x2=None, c_real=None):
+def group_norm(mod: EngineModule, name, gn: nn.GroupNorm, x, *, n_inst, rows_per_inst, silu, x2=None, c_real=None,
+               want_raw=False):
     g = f32_param(mod, name + ".g", gn.weight)
     b = f32_param(mod, name + ".b", gn.bias)
     return ops.groupnorm(x, g, b, n_inst=n_inst, rows_per_inst=rows_per_inst, groups=gn.num_groups, eps=gn.eps,
-                         silu=silu, x2=x2, c_real=c_real)
+                         silu=silu, x2=x2, c_real=c_real, want_raw=want_raw)
 
 
 def layer_norm(mod: EngineModule, name, ln: nn.LayerNorm, x):

@@ -30,4 +30,6 @@ def random_init_(model: torch.nn.Module, seed: int = 1234, device=None):
                 fan_in *= s
             t = torch.randn(shape, generator=g, device=dev) * (fan_in ** -0.5)
         p.copy_(t.to(p.dtype))
+    from . import engine
+    engine.invalidate_packed(model)          # explicit: packed fp16 copies of the old values must not survive
     return model

@@ -19,7 +19,9 @@ from . import _lib
 HALF = torch.float16
 
 
-_LAST_DEV = -1     # device index of the tensor most recently handed to _p() (benign race between threads: same device)
+import threading
+
+_TLS = threading.local()     # .dev: device index of the tensor this THREAD most recently handed to _p()
 
 
 def _stream():
@@ -28,17 +30,17 @@ def _stream():
     pointers fault or run on the wrong GPU — so a mismatch raises instead (the model entry points switch the current
     device to their tensors' device, engine.device_guard; library state such as the dynamic-LDS attribute is per device)."""
     cur = torch.cuda.current_device()
-    if _LAST_DEV != cur:
-        raise _lib.UavError(f"tensors live on cuda:{_LAST_DEV} but the current device is cuda:{cur}: wrap the call in "
-                            f"`with torch.cuda.device({_LAST_DEV})` (the model / pipeline entry points do)")
+    last = getattr(_TLS, "dev", -1)
+    if last != cur:
+        raise _lib.UavError(f"tensors live on cuda:{last} but the current device is cuda:{cur}: wrap the call in "
+                            f"`with torch.cuda.device({last})` (the model / pipeline entry points do)")
     return torch.cuda.current_stream().cuda_stream
 
 
 def _p(t):
-    global _LAST_DEV
     if t is None:
         return None
-    _LAST_DEV = t.device.index
+    _TLS.dev = t.device.index
     return t.data_ptr()
 
 
@@ -348,6 +350,8 @@ def _gn_partials_of(x, groups, c, rows_per_inst):
         return None
     if rows_per_inst % gn.rows:
         return None
+    if gn.ws.shape[-1] * gn.rows != x.shape[0]:      # partials of another row count (the tensor was re-interpreted): stats pass
+        return None
     return gn
 
 
@@ -392,10 +396,10 @@ def groupnorm_scale_shift(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps
     scale = torch.empty((n_inst, c), dtype=torch.float32, device=x1.device)
     shift = torch.empty_like(scale)
     gn = _gn_partials_of(x1, groups, c, rows_per_inst) if (x2 is None and c_real == c) else None
+    if gn is not None and gn.ws.shape[-1] * gn.rows != n_inst * rows_per_inst:
+        gn = None                                    # instance split does not cover the producer's rows: statistics pass
     if gn is not None:
         chunks_total = gn.ws.shape[-1]
-        if chunks_total * gn.rows != n_inst * rows_per_inst:
-            raise _lib.UavError("groupnorm: statistics partials do not cover the tensor")
         ev = PROFILER.begin("groupnorm_stats")
         rc = lib.uav_groupnorm_finalize_partials(_p(gn.ws), chunks_total, gn.rows, c, n_inst, rows_per_inst, groups, eps,
                                                  _p(gamma), _p(beta), _p(scale), _p(shift), _stream())
@@ -413,25 +417,28 @@ def groupnorm_scale_shift(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps
     return scale, shift
 
 
-def groupnorm_apply(x1, scale, shift, *, n_inst, rows_per_inst, silu, x2=None):
+def groupnorm_apply(x1, scale, shift, *, n_inst, rows_per_inst, silu, x2=None, want_raw=False):
+    """want_raw: also return the un-normalised [x1|x2] rows rounded to fp16 (one extra 2 B/elem write in the same pass)."""
     lib = _lib.load()
     xf32 = _gn_dtype(x1, x2)
     c1 = x1.shape[-1]
     c2 = 0 if x2 is None else x2.shape[-1]
     y = torch.empty((n_inst * rows_per_inst, c1 + c2), dtype=HALF, device=x1.device)
+    raw = torch.empty_like(y) if want_raw else None
     ev = PROFILER.begin("groupnorm_apply")
     rc = lib.uav_groupnorm_apply(_p(x1), _p(x2), xf32, c1, c2, _gn_x2_rows(x1, x2, n_inst * rows_per_inst), n_inst,
-                                 rows_per_inst, _p(scale), _p(shift), 1 if silu else 0, _p(y), _stream())
+                                 rows_per_inst, _p(scale), _p(shift), 1 if silu else 0, _p(y), _p(raw), _stream())
     _lib.check(rc, "uav_groupnorm_apply")
-    PROFILER.end(ev, "groupnorm_apply", 0.0, (6.0 if xf32 else 4.0) * n_inst * rows_per_inst * (c1 + c2))
-    return y
+    PROFILER.end(ev, "groupnorm_apply", 0.0, ((6.0 if xf32 else 4.0) + (2.0 if want_raw else 0.0)) * n_inst * rows_per_inst * (c1 + c2))
+    return (y, raw) if want_raw else y
 
 
-def groupnorm(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps, silu, x2=None, c_real=None):
-    """GroupNorm(+SiLU) over `n_inst` instances of `rows_per_inst` channels-last rows."""
+def groupnorm(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps, silu, x2=None, c_real=None, want_raw=False):
+    """GroupNorm(+SiLU) over `n_inst` instances of `rows_per_inst` channels-last rows.  want_raw: returns (y, raw16), see
+    groupnorm_apply."""
     sc, sh = groupnorm_scale_shift(x1, gamma, beta, n_inst=n_inst, rows_per_inst=rows_per_inst, groups=groups,
                                    eps=eps, x2=x2, c_real=c_real)
-    return groupnorm_apply(x1, sc, sh, n_inst=n_inst, rows_per_inst=rows_per_inst, silu=silu, x2=x2)
+    return groupnorm_apply(x1, sc, sh, n_inst=n_inst, rows_per_inst=rows_per_inst, silu=silu, x2=x2, want_raw=want_raw)
 
 
 def layernorm(x, gamma, beta, eps=1e-5):
@@ -581,7 +588,9 @@ def cast_f16(x):
         return x
     lib = _lib.load()
     y = torch.empty(x.shape, dtype=HALF, device=x.device)
+    ev = PROFILER.begin("cast_f16")
     _lib.check(lib.uav_cast_f32_f16(_p(_req(x, torch.float32, "x")), _p(y), x.numel(), _stream()), "uav_cast_f32_f16")
+    PROFILER.end(ev, "cast_f16", 0.0, 6.0 * x.numel())
     return y
 
 
