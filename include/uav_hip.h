@@ -139,8 +139,10 @@ int uav_groupnorm_finalize_partials(const float* partials, int64_t chunks_total,
 int uav_groupnorm_apply(const void* x1, const void* x2, int32_t x_f32, int32_t c1, int32_t c2, int64_t x2_rows,
                         int32_t n_inst, int64_t rows_per_inst,
                         const float* scale, const float* shift, int32_t silu,
-                        void* y, void* raw_f16_out /* optional: the un-normalised [x1|x2] rows rounded to fp16 (operand of
-                        a 1x1 shortcut conv reading an fp32 stream); NULL = not written */, void* stream);
+                        void* y, void* raw_f16_out /* optional: the un-normalised [x1|x2] rows as fp16 (operand of a 1x1
+                        shortcut conv reading an fp32 stream); NULL = not written */,
+                        int32_t raw_hilo /* 0: rows of c values fp16(x); 1: rows of 2c values [fp16(x) | fp16(x - fp16(x))] */,
+                        void* stream);
 
 /* ---- LayerNorm over the channel axis (nn.LayerNorm(dim), eps 1e-5: attention.py:457-494) */
 int uav_layernorm_f16(const void* x, void* y, const float* gamma, const float* beta,

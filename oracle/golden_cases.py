@@ -134,6 +134,7 @@ def colorfix_inputs(seed=500):
 FULL_CASES = {
     "unet_full_t8_64": (2, 8, 64, 64),
     "vae3d_full_t3_48": (1, 3, 48, 48),
+    "vaevideo_full_t3_48": (1, 3, 48, 48),
     # BASELINE.json configs[0]: single 8-frame 128x128 -> 512x512 clip, 5 DDIM steps, no propagation
     "pipe_c1_full": dict(t=8, h=128, w=128, steps=5, guidance=6.0, noise_level=120, clip_seed=41,
                          prompt="best quality, extremely detailed", negative="blur, worst quality"),

@@ -177,6 +177,7 @@ def main():
     make_colorfix_golden(ns, pin)
     make_fullwidth_goldens(ns, pin)
     make_full30_golden(ns, pin)
+    make_vaevideo_full_golden(ns, pin)
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
     print("wrote", GOLD)
 
@@ -512,6 +513,29 @@ def make_fullwidth_goldens(ns, pin):
     print("pipe_c1_full", pin["cases"]["pipe_c1_full"], flush=True)
 
 
+def make_vaevideo_full_golden(ns, pin):
+    """the FULL-WIDTH `vae_video` decoder (configs/vae_video_config.json: UpDecoderBlock3D_plus with 3x3x3
+    convs, LR-frame conditioning through condition_in + the SFT fuse block) — one 3-frame chunk 48x48 -> 192x192 with the LR
+    frames, fp32 like the pipeline's decode (pipeline:668-681), reference module vs the oracle; next to vae3d_full_t3_48."""
+    import json as _json
+    vcfg = _json.load(open(os.path.join(ref_stubs.REFERENCE_ROOT, "configs", "vae_video_config.json")))
+    vae = ns.vae.AutoencoderKLVideo.from_config(dict(vcfg)).eval()
+    vsd = synth.synth_state_dict(vae.state_dict(), seed=4321)
+    vae.load_state_dict(vsd, strict=True)
+    _, tv, hv, wv = FULL_CASES["vaevideo_full_t3_48"]
+    z, img = vae_inputs(1, tv, hv, wv)
+    with torch.no_grad():
+        t0 = time.time(); ref = vae.decode(z, img, 1.0).sample; t_ref = time.time() - t0
+        mine = O.vae_decode(vsd, vcfg, z, img, 1.0)
+        ref_noimg_w = vae.decode(z, img, 0.0).sample
+    pin["cases"]["vaevideo_full_t3_48"] = {"maxabs_oracle_vs_reference": maxabs(mine, ref), "rel_l2": rel_l2(mine, ref),
+                                           "ref_absmean": ref.abs().mean().item(), "ref_seconds": t_ref,
+                                           "saturated_fraction": (ref.abs() >= 1).float().mean().item(),
+                                           "rel_l2_w_lr_0_vs_1": rel_l2(ref_noimg_w, ref)}
+    torch.save(ref, os.path.join(GOLD, "vaevideo_full_t3_48.pt"))
+    print("vaevideo_full_t3_48", pin["cases"]["vaevideo_full_t3_48"], flush=True)
+
+
 FULL30_KEEP = (1, 2, 3, 5, 10, 15, 20, 25, 30)      # DDIM steps (1-based) whose latents are stored
 
 
@@ -642,9 +666,9 @@ def only(section):
     pin = json.load(open(os.path.join(GOLD, "PINNING.json")))
     {"raft": make_raft_goldens, "unet": make_unet_goldens, "tiles": make_tile_goldens, "pipe14": make_dup_tail_golden,
      "vaewlr": make_vae_wlr_golden, "prophalf": make_prop_half_goldens, "pipehalf": make_pipe_half_golden, "colorfix": make_colorfix_golden, "full": make_fullwidth_goldens,
-     "full30": make_full30_golden}[section](ns, pin)
+     "full30": make_full30_golden, "fullvideo": make_vaevideo_full_golden}[section](ns, pin)
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
-    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else only("tiles") if "--tiles" in sys.argv else only("pipe14") if "--pipe14" in sys.argv else only("vaewlr") if "--vaewlr" in sys.argv else only("colorfix") if "--colorfix" in sys.argv else only("pipehalf") if "--pipehalf" in sys.argv else only("prophalf") if "--prophalf" in sys.argv else only("full30") if "--full30" in sys.argv else only("full") if "--full" in sys.argv else main()
+    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else only("tiles") if "--tiles" in sys.argv else only("pipe14") if "--pipe14" in sys.argv else only("vaewlr") if "--vaewlr" in sys.argv else only("colorfix") if "--colorfix" in sys.argv else only("pipehalf") if "--pipehalf" in sys.argv else only("prophalf") if "--prophalf" in sys.argv else only("fullvideo") if "--fullvideo" in sys.argv else only("full30") if "--full30" in sys.argv else only("full") if "--full" in sys.argv else main()

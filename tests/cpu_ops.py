@@ -99,8 +99,10 @@ def groupnorm(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps, silu, x2=N
         x2 = torch.cat([x2, x2])
     x = x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], dim=-1)
     if want_raw:
+        hi = _h(x)
+        raw = torch.cat([hi, _h(x - hi.float())], dim=-1) if want_raw == "hilo" else hi
         return groupnorm(x1, gamma, beta, n_inst=n_inst, rows_per_inst=rows_per_inst, groups=groups, eps=eps, silu=silu,
-                         x2=x2, c_real=c_real), _h(x)
+                         x2=x2, c_real=c_real), raw
     c = x.shape[-1]
     c_real = c if c_real is None else c_real
     xr = x[:, :c_real].reshape(n_inst, rows_per_inst, groups, c_real // groups).double()

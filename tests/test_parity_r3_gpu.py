@@ -199,6 +199,34 @@ def test_full_width_30_step_curve_vs_reference(full, dev, mode):
     report("r3_pipe_full30_64_" + mode, steps=list(steps), engine_fp32_draws_vs_reference_fp32=curve32,
            engine_half_draws_vs_reference_half_run=curve16, engine_half_draws_vs_reference_fp32=curve16v32,
            reference_half_vs_its_fp32=ref_noise, image_rel_l2_unsaturated_vs_reference_fp32=e_img)
-    # the engine stays no further from the reference's fp32 trajectory than the reference's own half pipeline does
-    assert curve32[-1] <= 1.25 * ref_noise[-1], (curve32, ref_noise)
-    assert all(torch.isfinite(torch.tensor(curve32)))
+    # measured (MI355X, round 3) + 25 %: fp32 stream 2.4e-4 after 5 steps, 1.03e-3 after 30 (image 1.6e-3);
+    # fp16 rows 6.6e-4 / 2.21e-3 (3.0e-3); the reference's own half pipeline vs its fp32 run: 1.12e-3 / 3.0e-3 (4.0e-3)
+    i5, i30 = list(steps).index(5), list(steps).index(30)
+    bars = {"fp32_stream": (3.0e-4, 1.3e-3, 2.0e-3), "fp16_stream": (8.3e-4, 2.8e-3, 3.8e-3)}[mode]
+    assert curve32[i5] < bars[0] and curve32[i30] < bars[1] and e_img < bars[2], (curve32, e_img)
+    assert curve32[i30] < ref_noise[i30]                # closer to the fp32 trajectory than the reference's half pipeline
+    # in the CLI's mix (fp16 noise tensors) the engine and the reference half run are two fp16-grade evaluations of the
+    # same trajectory: their distance stays within 1.25x of the reference's own half-vs-fp32 distance
+    assert curve16[i30] < 1.25 * ref_noise[i30], (curve16, ref_noise)
+
+
+def test_vaevideo_full_width_decode_vs_reference(full, dev):
+    """55 M-parameter `vae_video` decoder (BASELINE configs[4]: 3x3x3 convs in every decoder ResNet, LR frames through
+    condition_in + the SFT fuse block) at the released width: one 3-frame chunk 48x48 -> 192x192 WITH the LR conditioning,
+    against the reference module's fp32 decode (tests/golden/vaevideo_full_t3_48.pt)."""
+    GC = full["GC"]
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    vae = AutoencoderKLVideo.from_config(dict(full["configs"].VAE_VIDEO))
+    vae.load_state_dict(full["synth"].synth_state_dict(vae.state_dict(), seed=4321), strict=True)
+    vae = vae.to(dev).eval()
+    _, t, h, w = GC.FULL_CASES["vaevideo_full_t3_48"]
+    z, img = GC.vae_inputs(1, t, h, w)
+    with torch.no_grad():
+        out = vae.decode(z.to(dev), img.to(dev), 1.0).sample
+        out0 = vae.decode(z.to(dev), img.to(dev), 0.0).sample
+    gold = torch.load(os.path.join(GOLD, "vaevideo_full_t3_48.pt"))
+    e = rel_l2(out, gold)
+    report("r3_vaevideo_full_t3_48", rel_l2_vs_reference_fp32=e, ref_absmean=pinning("vaevideo_full_t3_48")["ref_absmean"])
+    assert out.shape == gold.shape and out.dtype == torch.float32
+    assert e < 1e-3, e
+    assert rel_l2(out0, gold) > 0.5                     # the LR conditioning weight does change the result

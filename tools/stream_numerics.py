@@ -53,7 +53,7 @@ def main():
     modes = sys.argv[1:] or ["f16", "f32", "f32-branch16"]
     cpu_ops.install()
     from uav import ops
-    base = {k: getattr(ops, k) for k in ("groupnorm", "layernorm", "conv_gemm", "attention", "temporal_attention")}
+    base = {k: getattr(ops, k) for k in ("groupnorm", "layernorm", "conv_gemm", "attention", "temporal_attention", "cast_f16")}
     real_h = cpu_ops._h
     real_assert = None
 
@@ -83,10 +83,22 @@ def main():
         return wrap
     try:
         for mode in modes:
-            unet.stream_dtype = torch.float32 if mode.startswith("f32") else torch.float16
+            unet.stream_dtype = torch.float32 if mode.startswith("f32") else torch.float16      # "f32-bf16": fp32 stream, bf16 operands
             E.BRANCH_F32 = "branch16" not in mode
             E.TOKEN_F32 = "tok16" not in mode
             keep = set(mode.split("+")[1:])
+            cpu_ops._h = real_h
+            if "bf16" in mode:                   # bf16 MFMA operands (8-bit mantissa): every stored operand AND the weights
+                import copy
+                cpu_ops._h = lambda x: x.to(torch.bfloat16).to(torch.float16)
+                wcache = {}
+
+                def conv_bf16(a1, wt, **kw):
+                    w2 = wcache.get(id(wt))
+                    if w2 is None:
+                        w2 = copy.copy(wt); w2.w = wt.w.to(torch.bfloat16).to(torch.float16); wcache[id(wt)] = w2
+                    return base["conv_gemm"](a1, w2, **kw)
+                ops.conv_gemm = cpu_ops.conv_gemm = conv_bf16
             for k, f in base.items():
                 setattr(ops, k, f)
             cpu_ops.conv_gemm = base["conv_gemm"]
@@ -96,12 +108,27 @@ def main():
                 if "attn" in keep:
                     ops.attention = exact(base["attention"]); ops.temporal_attention = exact(base["temporal_attention"])
                 ops.conv_gemm = cpu_ops.conv_gemm = conv_exact(keep)
+                if "cast" in keep or "samp" in keep:   # stream -> operand roundings of the down / up sampler inputs
+                    ops.cast_f16 = lambda x: x if x.dtype == torch.float16 else _FakeHalf(x)
+                if "cast" in keep or "rawx" in keep:   # ... and of the shortcut-conv inputs (the raw copy of the norm1 pass)
+                    gn_fn = ops.groupnorm
+
+                    def gn_raw_exact(x1, gamma, beta, **kw):
+                        if not kw.get("want_raw"):
+                            return gn_fn(x1, gamma, beta, **kw)
+                        y, _ = gn_fn(x1, gamma, beta, **kw)
+                        x2 = kw.get("x2")
+                        if x2 is not None and x2.shape[0] * 2 == x1.shape[0]:
+                            x2 = torch.cat([x2, x2])
+                        return y, _FakeHalf(x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], dim=-1))
+                    ops.groupnorm = gn_raw_exact
             t0 = time.time()
             with torch.no_grad():
                 out = unet(sample.half(), ts, low.half(), encoder_hidden_states=ehs.half(), class_labels=cl).sample
             print(f"{mode:14s} vs reference fp32 {rel_l2(out, gold['fp32']):.3e}   vs reference fp16 {rel_l2(out, gold['fp16']):.3e}"
                   f"   (reference fp16 vs fp32 {rel_l2(gold['fp16'], gold['fp32']):.3e})   {time.time() - t0:.0f} s", flush=True)
     finally:
+        cpu_ops._h = real_h
         cpu_ops.conv_gemm = base["conv_gemm"]
         cpu_ops.restore()
 

@@ -189,17 +189,32 @@ UAV_DEVINL void conv_gn_store(const ConvArgs& p, float (&st)[NI][GnAcc<GNM>::NG]
 }
 
 // Fast paths: the whole wave tile lies inside M and N, fp16 output, 16-B aligned rows, one time-embedding row for the
-// tile.  No predicates and no flag tests inside -> ONE basic block, so the scheduler issues every bias / residual load
-// up front instead of load -> wait -> store per 16-B piece (the generic path below has ~130 s_waitcnt and ~270 branches;
-// on the K = 512 linears the epilogue was 35-40 % of the kernel time, `tools/ab_conv.sh` DBG=6).  Same arithmetic
+// tile.  No predicates and no flag tests inside -> ONE basic block (the generic path below has ~130 s_waitcnt and ~270
+// branches; on the K = 512 linears the epilogue was 35-40 % of the kernel time, `tools/ab_conv.sh` DBG=6).  Same arithmetic
 // order as the generic path: ((acc + bias) + rowbias) + residual, then * out_scale.
+//
+// Round 3 — vector-memory ORDER.  On gfx9 loads and stores share one in-order counter (vmcnt): a load issued after a store
+// cannot be waited for before that store has been acknowledged by the L2.  The round-2 epilogue ran, per 32-column tile,
+// {4 bias loads + 4 residual loads -> wait -> 4 stores}: FOUR serialized round trips per wave tile (ISA: `L x8 [vmcnt 7..0]
+// S x4` four times), the residual ones to HBM.  Now
+//   * ST (staged): bias and the time-embedding row of the tile come from LDS (the 256x256i kernel stages them behind its
+//     two DMA stages while the first k-step's data is in flight): ds_read, i.e. lgkmcnt — no vector load at all;
+//   * the residual loads are issued AHEAD of the stores: all of them at the top (fp16 residual, D = NI), or software-
+//     pipelined D column tiles ahead (statistics instances / fp32 residual, whose registers do not hold everything).
+// A conv without residual now ends in 16 back-to-back stores; one with a residual pays ONE round trip instead of four.
+typedef __attribute__((address_space(3))) const float4_t* lds_f4ptr_t;
+UAV_DEVINL float4_t lds_f4(unsigned byte_addr) { return *(lds_f4ptr_t)(size_t)byte_addr; }
+
 // RF32: the residual is an fp32 row (fp32 residual stream, fp16 result: a block output that is only read as an MFMA operand);
 // it is loaded in the accumulators' own layout (one float4 per register quad), no half-wave exchange.
-template <int NI, int MI, bool RES, bool BIAS, bool RB, int GNM, bool RF32 = false>
+// lb / lr: LDS byte addresses of the staged bias / time-embedding row at this wave's first column (ST only).
+template <int NI, int MI, bool RES, bool BIAS, bool RB, int GNM, bool RF32 = false, bool ST = false>
 UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32,
-                                   const float* rbrow) {
+                                   const float* rbrow, unsigned lb = 0, unsigned lr = 0) {
     constexpr bool GN = GNM != 0;
     constexpr int NG = GnAcc<GNM>::NG;
+    constexpr bool R16 = RES && !RF32, R32 = RES && RF32;
+    constexpr int D = R16 ? (GN ? 2 : NI) : 1;            // residual prefetch distance in column tiles
     float gst[GN ? NI : 1][NG], gsq[GN ? NI : 1][NG];    // GroupNorm partial sums of the values stored (fp32, before rounding)
     if (GN) {
 #pragma unroll
@@ -219,38 +234,45 @@ UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], 
     const float* bptr = BIAS ? p.bias + nw0 + 4 * hi32 : nullptr;
     const float* rptr = RB ? rbrow + nw0 + 4 * hi32 : nullptr;
     const float osc = p.out_scale;
+    uint4_t R[R16 ? NI : 1][MI][2];
+    float4_t RF[R32 ? NI : 1][MI][4];
+    auto issue_res = [&](int ni) {
+        if (R16) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) R[R16 ? ni : 0][mi][gp] = *(const uint4_t*)(rrow[mi] + (ni * 32 + 16 * gp) * 2);
+        }
+        if (R32) {
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) RF[R32 ? ni : 0][mi][g] = *(const float4_t*)(rrow[mi] + (ni * 32 + 8 * g) * 4);
+        }
+    };
+    if (RES) {
+#pragma unroll
+        for (int ni = 0; ni < D && ni < NI; ++ni) issue_res(ni);
+    }
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-        // statistics instances: keep the loads of the second half of the tile behind the first half's stores — hoisting
-        // all of them on top of the statistics accumulators does not fit the 256-register budget (scratch traffic)
-        if (GN && ni == NI / 2) { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); }
+        // the next residual tile goes out BEFORE this tile's stores (in-order vmcnt), D tiles ahead of its use
+        if (RES && ni + D < NI) issue_res(ni + D);
         float4_t bq[4], rq[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            if (BIAS) bq[g] = *(const float4_t*)(bptr + ni * 32 + 8 * g);
-            if (RB) rq[g] = *(const float4_t*)(rptr + ni * 32 + 8 * g);
-        }
-        uint4_t R[(RES && !RF32) ? MI : 1][2];
-        float4_t RF[(RES && RF32) ? MI : 1][4];
-        if (RES && !RF32) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int gp = 0; gp < 2; ++gp) R[mi][gp] = *(const uint4_t*)(rrow[mi] + (ni * 32 + 16 * gp) * 2);
-        }
-        if (RES && RF32) {
-#pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) RF[mi][g] = *(const float4_t*)(rrow[mi] + (ni * 32 + 8 * g) * 4);
+            const int co = ni * 32 + 8 * g;
+            if (BIAS) bq[g] = ST ? lds_f4(lb + (co + 4 * hi32) * 4) : *(const float4_t*)(bptr + co);
+            if (RB) rq[g] = ST ? lds_f4(lr + (co + 4 * hi32) * 4) : *(const float4_t*)(rptr + co);
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int gp = 0; gp < 2; ++gp) {
                 uint32_t Rr[4] = {0, 0, 0, 0};
-                if (RES && !RF32) {
-                    Rr[0] = R[mi][gp][0]; Rr[1] = R[mi][gp][1]; Rr[2] = R[mi][gp][2]; Rr[3] = R[mi][gp][3];
+                if (R16) {
+                    const uint4_t r = R[R16 ? ni : 0][mi][gp];
+                    Rr[0] = r[0]; Rr[1] = r[1]; Rr[2] = r[2]; Rr[3] = r[3];
                     swap_pair(Rr[0], Rr[2]); swap_pair(Rr[1], Rr[3]);     // -> Rr[0..1]: quad 2gp, Rr[2..3]: quad 2gp+1
                 }
                 uint32_t A[2], B[2];
@@ -268,13 +290,13 @@ UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], 
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] += rq[g][j];
                     }
-                    if (RES && !RF32) {
+                    if (R16) {
                         float2_t r0 = unpack_h2(Rr[2 * q]), r1 = unpack_h2(Rr[2 * q + 1]);
                         v[0] += r0[0]; v[1] += r0[1]; v[2] += r1[0]; v[3] += r1[1];
                     }
-                    if (RES && RF32) {
+                    if (R32) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += RF[mi][g][j];
+                        for (int j = 0; j < 4; ++j) v[j] += RF[R32 ? ni : 0][mi][g][j];
                     }
                     uint32_t* d = q == 0 ? A : B;
 #pragma unroll
@@ -295,14 +317,15 @@ UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], 
     if constexpr (GN) conv_gn_store<NI, MI, GNM>(p, gst, gsq, mw0, nw0, l32, hi32);
 }
 
-// fp32-output fast path (VAE decoder in fp32-stream mode: conv outputs, residual stream and GroupNorm inputs stay fp32,
-// only the MFMA operands are fp16).  A lane owns pixel m and, per register quad g, 4 consecutive channels: one float4
+// fp32-output fast path (fp32-stream mode of the VAE decoder / UNet: conv outputs, residual stream and GroupNorm inputs stay
+// fp32, only the MFMA operands are fp16).  A lane owns pixel m and, per register quad g, 4 consecutive channels: one float4
 // (16-B) store per quad straight from the accumulators, one float4 load for an fp32 residual; no half-wave exchange.
-// Same arithmetic order as the fp16 paths: ((acc + bias) + residual) * out_scale.
+// Same arithmetic order as the fp16 paths: ((acc + bias) + rowbias) + residual, then * out_scale.
 // RB: one time-embedding row for the whole wave tile (conv1 of a ResNet block whose branch tensor stays fp32).
-template <int NI, int MI, bool RES, int GNM, bool RB = false>
+// The residual of column tile ni + 1 is requested before tile ni's stores (see the note on vmcnt order above).
+template <int NI, int MI, bool RES, int GNM, bool RB = false, bool ST = false>
 UAV_DEVINL void conv_epilogue_f32_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32,
-                                       const float* rbrow = nullptr) {
+                                       const float* rbrow = nullptr, unsigned lb = 0, unsigned lr = 0) {
     const float osc = p.out_scale;
     constexpr bool GN = GNM != 0;
     constexpr int NG = GnAcc<GNM>::NG;
@@ -313,29 +336,34 @@ UAV_DEVINL void conv_epilogue_f32_fast(const ConvArgs& p, float16_t (&acc)[NI][M
 #pragma unroll
             for (int k = 0; k < NG; ++k) { gst[ni][k] = 0.f; gsq[ni][k] = 0.f; }
     }
+    float* orow[MI];
+    const float* rrow[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const long long m = mw0 + mi * 32 + l32;
+        orow[mi] = (float*)p.out + out_row(p, m) * p.out_stride + nw0 + 4 * hi32;
+        rrow[mi] = RES ? (const float*)p.residual + m * p.res_stride + nw0 + 4 * hi32 : nullptr;
+    }
+    float4_t R[RES ? 2 : 1][MI][4];
+    auto issue_res = [&](int ni) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) R[ni & 1][mi][g] = *(const float4_t*)(rrow[mi] + ni * 32 + 8 * g);
+    };
+    if (RES) issue_res(0);
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
-        // statistics instances: keep the loads of the second half of the tile behind the first half's stores — hoisting
-        // all of them on top of the statistics accumulators does not fit the 256-register budget (scratch traffic)
-        if (GN && ni == NI / 2) { __builtin_amdgcn_sched_barrier(0); asm volatile("" ::: "memory"); }
-        float4_t bq[4];
+        if (RES && ni + 1 < NI) issue_res(ni + 1);
+        float4_t bq[4], rq[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) bq[g] = *(const float4_t*)(p.bias + nw0 + ni * 32 + 8 * g + 4 * hi32);
-        float4_t rq[4];                                 // same order as the fp16 paths: ((acc + bias) + rowbias) + residual
-        if (RB) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) rq[g] = *(const float4_t*)(rbrow + nw0 + ni * 32 + 8 * g + 4 * hi32);
+        for (int g = 0; g < 4; ++g) {
+            const int co = ni * 32 + 8 * g + 4 * hi32;
+            bq[g] = ST ? lds_f4(lb + co * 4) : *(const float4_t*)(p.bias + nw0 + co);
+            if (RB) rq[g] = ST ? lds_f4(lr + co * 4) : *(const float4_t*)(rbrow + nw0 + co);
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
-            const long long m = mw0 + mi * 32 + l32;
-            float* orow = (float*)p.out + out_row(p, m) * p.out_stride + nw0 + ni * 32 + 4 * hi32;
-            const float* rrow = RES ? (const float*)p.residual + m * p.res_stride + nw0 + ni * 32 + 4 * hi32 : nullptr;
-            float4_t R[4];
-            if (RES) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) R[g] = *(const float4_t*)(rrow + 8 * g);
-            }
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 float4_t o;
@@ -343,10 +371,10 @@ UAV_DEVINL void conv_epilogue_f32_fast(const ConvArgs& p, float16_t (&acc)[NI][M
                 for (int j = 0; j < 4; ++j) {
                     float v = acc[ni][mi][4 * g + j] + bq[g][j];
                     if (RB) v += rq[g][j];
-                    if (RES) v += R[g][j];
+                    if (RES) v += R[RES ? (ni & 1) : 0][mi][g][j];
                     o[j] = v * osc;
                 }
-                *(float4_t*)(orow + 8 * g) = o;
+                *(float4_t*)(orow[mi] + ni * 32 + 8 * g) = o;
                 if (GN) {
                     constexpr int sh = GNM == 1 ? 0 : GNM == 2 ? 1 : 2;
                     gst[GN ? ni : 0][g >> sh] += (o[0] + o[1]) + (o[2] + o[3]);
@@ -359,8 +387,9 @@ UAV_DEVINL void conv_epilogue_f32_fast(const ConvArgs& p, float16_t (&acc)[NI][M
 }
 
 // GEGLU fast path (same preconditions; no residual / rowbias by contract): value/gate tile pairs (2b, 2b+1).
-template <int NI, int MI, bool BIAS>
-UAV_DEVINL void conv_epilogue_geglu_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32) {
+template <int NI, int MI, bool BIAS, bool ST = false>
+UAV_DEVINL void conv_epilogue_geglu_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32,
+                                         unsigned lb = 0) {
     const float osc = p.out_scale;
 #pragma unroll
     for (int blk = 0; blk < NI / 2; ++blk) {
@@ -369,8 +398,8 @@ UAV_DEVINL void conv_epilogue_geglu_fast(const ConvArgs& p, float16_t (&acc)[NI]
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (BIAS) {
-                bv[g] = *(const float4_t*)(p.bias + nb + 8 * g + 4 * hi32);
-                bg[g] = *(const float4_t*)(p.bias + nb + 32 + 8 * g + 4 * hi32);
+                bv[g] = ST ? lds_f4(lb + (blk * 64 + 8 * g + 4 * hi32) * 4) : *(const float4_t*)(p.bias + nb + 8 * g + 4 * hi32);
+                bg[g] = ST ? lds_f4(lb + (blk * 64 + 32 + 8 * g + 4 * hi32) * 4) : *(const float4_t*)(p.bias + nb + 32 + 8 * g + 4 * hi32);
             }
         }
 #pragma unroll
@@ -405,22 +434,24 @@ UAV_DEVINL void conv_epilogue_geglu_fast(const ConvArgs& p, float16_t (&acc)[NI]
 // host only launches it when every wave tile inside M x N qualifies for a fast path (conv_gn_cpg_log2), so nothing else
 // is instantiated there: the statistics variants stay out of the plain kernels, whose register allocation (no scratch) is
 // the one measured in DESIGN.md.
-template <int NI, int MI, int GNK = 0>
-UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32) {
+// ST: bias / time-embedding row of the tile are staged in LDS at lb / lr (byte addresses at this wave's first column).
+template <int NI, int MI, int GNK = 0, bool ST = false>
+UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32,
+                              unsigned lb = 0, unsigned lr = 0) {
     if constexpr (GNK != 0) {
         if (mw0 >= p.M || nw0 >= p.n) return;                   // wave tile outside the output: nothing to store or count
         const float* rbrow = p.rowbias ? p.rowbias + (long long)((int)(mw0 / p.rows_per_batch)) * p.rowbias_stride : nullptr;
         if (p.flags & UAV_CONV_OUT_F32) {
-            if (rbrow) conv_epilogue_f32_fast<NI, MI, false, GNK, true>(p, acc, mw0, nw0, l32, hi32, rbrow);   // conv1: no residual
-            else if (p.residual) conv_epilogue_f32_fast<NI, MI, true, GNK>(p, acc, mw0, nw0, l32, hi32);
-            else conv_epilogue_f32_fast<NI, MI, false, GNK>(p, acc, mw0, nw0, l32, hi32);
+            if (rbrow) conv_epilogue_f32_fast<NI, MI, false, GNK, true, ST>(p, acc, mw0, nw0, l32, hi32, rbrow, lb, lr);   // conv1: no residual
+            else if (p.residual) conv_epilogue_f32_fast<NI, MI, true, GNK, false, ST>(p, acc, mw0, nw0, l32, hi32, nullptr, lb, lr);
+            else conv_epilogue_f32_fast<NI, MI, false, GNK, false, ST>(p, acc, mw0, nw0, l32, hi32, nullptr, lb, lr);
             return;
         }
         if (p.flags & UAV_CONV_RES_F32) {               // fp32 stream in, fp16 operand out (host: bias, no rowbias)
-            conv_epilogue_fast<NI, MI, true, true, false, GNK, true>(p, acc, mw0, nw0, l32, hi32, nullptr);
+            conv_epilogue_fast<NI, MI, true, true, false, GNK, true, ST>(p, acc, mw0, nw0, l32, hi32, nullptr, lb, lr);
             return;
         }
-#define UAV_EPI(RES, BIAS, RB) conv_epilogue_fast<NI, MI, RES, BIAS, RB, GNK>(p, acc, mw0, nw0, l32, hi32, rbrow)
+#define UAV_EPI(RES, BIAS, RB) conv_epilogue_fast<NI, MI, RES, BIAS, RB, GNK, false, ST>(p, acc, mw0, nw0, l32, hi32, rbrow, lb, lr)
         switch ((p.residual ? 4 : 0) | (p.bias ? 2 : 0) | (rbrow ? 1 : 0)) {
             case 0: UAV_EPI(false, false, false); break;
             case 1: UAV_EPI(false, false, true); break;
@@ -441,27 +472,27 @@ UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long 
     if (of32 && !actf && !geglu && p.bias && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n && !(p.out_stride & 3) &&
         (!p.residual || (rf32 && !(p.res_stride & 3)))) {
         if (!p.rowbias) {
-            if (p.residual) conv_epilogue_f32_fast<NI, MI, true, 0>(p, acc, mw0, nw0, l32, hi32);
-            else conv_epilogue_f32_fast<NI, MI, false, 0>(p, acc, mw0, nw0, l32, hi32);
+            if (p.residual) conv_epilogue_f32_fast<NI, MI, true, 0, false, ST>(p, acc, mw0, nw0, l32, hi32, nullptr, lb, lr);
+            else conv_epilogue_f32_fast<NI, MI, false, 0, false, ST>(p, acc, mw0, nw0, l32, hi32, nullptr, lb, lr);
             return;
         }
         const int b0 = (int)(mw0 / p.rows_per_batch), b1 = (int)((mw0 + MI * 32 - 1) / p.rows_per_batch);
         if (b0 == b1 && !p.residual) {
-            conv_epilogue_f32_fast<NI, MI, false, 0, true>(p, acc, mw0, nw0, l32, hi32, p.rowbias + (long long)b0 * p.rowbias_stride);
+            conv_epilogue_f32_fast<NI, MI, false, 0, true, ST>(p, acc, mw0, nw0, l32, hi32, p.rowbias + (long long)b0 * p.rowbias_stride, lb, lr);
             return;
         }
     }
     if (!of32 && rf32 && !actf && !geglu && p.bias && !p.rowbias && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n &&
         !(p.out_stride & 7) && !(p.res_stride & 3)) {
-        conv_epilogue_fast<NI, MI, true, true, false, 0, true>(p, acc, mw0, nw0, l32, hi32, nullptr);
+        conv_epilogue_fast<NI, MI, true, true, false, 0, true, ST>(p, acc, mw0, nw0, l32, hi32, nullptr, lb, lr);
         return;
     }
     // wave-uniform fast-path test
     if (!of32 && !rf32 && !actf && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n && !(p.out_stride & 7) &&
         (!p.residual || !(p.res_stride & 7))) {
         if (geglu) {
-            if (p.bias) conv_epilogue_geglu_fast<NI, MI, true>(p, acc, mw0, nw0, l32, hi32);
-            else conv_epilogue_geglu_fast<NI, MI, false>(p, acc, mw0, nw0, l32, hi32);
+            if (p.bias) conv_epilogue_geglu_fast<NI, MI, true, ST>(p, acc, mw0, nw0, l32, hi32, lb);
+            else conv_epilogue_geglu_fast<NI, MI, false, false>(p, acc, mw0, nw0, l32, hi32);
             return;
         }
         const float* rbrow = nullptr;
@@ -472,7 +503,7 @@ UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long 
             rbrow = p.rowbias + (long long)b0 * p.rowbias_stride;
         }
         if (uniform) {
-#define UAV_EPI(RES, BIAS, RB) conv_epilogue_fast<NI, MI, RES, BIAS, RB, 0>(p, acc, mw0, nw0, l32, hi32, rbrow)
+#define UAV_EPI(RES, BIAS, RB) conv_epilogue_fast<NI, MI, RES, BIAS, RB, 0, false, ST>(p, acc, mw0, nw0, l32, hi32, rbrow, lb, lr)
             const int sel = (p.residual ? 4 : 0) | (p.bias ? 2 : 0) | (rbrow ? 1 : 0);
             switch (sel) {
                 case 0: UAV_EPI(false, false, false); break;
@@ -784,6 +815,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvArgs p) {
 constexpr int LM = 256, LN = 256;
 constexpr int LA_BYTES = LM * BK * 2;            // 32 KiB
 constexpr int LSTAGE = 2 * LA_BYTES;             // 64 KiB (X tile + W tile)
+constexpr int LEPI_BYTES = 5 * 1024;             // conv_gemm256i_kernel: staged bias (1 KiB) + 4 time-embedding row blocks
 
 // PERSIST: the workgroup walks tiles wg, wg + gridDim.x, ... and issues the first DMA stage of its NEXT tile before
 // the epilogue of the current one (both LDS stages are idle then), so the first-stage round trip hides behind it.
@@ -1173,6 +1205,23 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
     for (int kk = 0; kk < 4; ++kk) so[kk] = ((kk * 2 + hi32) ^ sw) << 4;
     const unsigned ldsw = ldsb + wave * 1024;           // this wave's 1-KiB slice inside every 8-KiB piece
 
+    // Epilogue constants -> LDS behind the two DMA stages (LEPI_BYTES): bias[n0 .. n0+256) and, per 64-row block of the
+    // tile, the time-embedding row of that block's batch entry.  Requested here, written to LDS after the prologue DMA
+    // has been issued (their latencies overlap) and published by the k-loop's first barrier; the fast epilogues then
+    // need no vector load for them (conv_epilogue_fast: loads issued after a store wait for that store on gfx9).
+    const unsigned ldsepi = ldsb + 2 * LSTAGE;
+    float4_t stg = {0.f, 0.f, 0.f, 0.f};
+    unsigned stg_dst = 0;                                // 0 = this thread stages nothing
+    if (tid < 64) {
+        if (p.bias) { stg = *(const float4_t*)(p.bias + n0 + 4 * tid); stg_dst = ldsepi + tid * 16; }
+    } else if (tid < 320 && p.rowbias) {
+        const int blk = (tid - 64) >> 6, piece = (tid - 64) & 63;
+        long long mrow = m0 + blk * 64; if (mrow >= p.M) mrow = 0;
+        const int col = n0 + 4 * piece;
+        if (col + 4 <= p.n) stg = *(const float4_t*)(p.rowbias + (long long)((int)(mrow / p.rows_per_batch)) * p.rowbias_stride + col);
+        stg_dst = ldsepi + 1024 + blk * 1024 + piece * 16;
+    }
+
     // LDS-DMA pieces of one stage: X rows ps*64.. -> +ps*8 KiB, W rows likewise behind the 32-KiB X tile.  M0 carries
     // the wave-uniform LDS destination; it is compiler-reserved, so the block saves and restores it.
 #define DX(I, OFF) "s_cbranch_vccz .Lnd%=_" #I "\n" "s_add_u32 m0, %[ldsn], " #OFF "\n" "s_nop 0\n" "global_load_lds_dwordx4 %[gx" #I "], off\n" ".Lnd%=_" #I ":\n"
@@ -1201,6 +1250,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
                      : [m0s] "=&s"(m0s) : DMA_OPERANDS : "memory", "scc", "vcc");
     }
     if (nk > 1) COMPUTE_ADDR()
+    if (stg_dst) *(__attribute__((address_space(3))) float4_t*)(size_t)stg_dst = stg;
 
 #define RD(D, A, OFF) "ds_read_b128 %[" #D "], %[" #A "] offset:" #OFF "\n"
 #define RDSET(S, A, AX) RD(w##S##0, A, 32768) RD(x##S##0, AX, 0) RD(x##S##1, AX, 4096) RD(w##S##1, A, 36864) RD(w##S##2, A, 40960) RD(w##S##3, A, 45056)
@@ -1279,7 +1329,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
 #undef COMPUTE_ADDR
     // the MFMAs issued last may still be in flight and the compiler cannot see them (see conv_gemm256_kernel)
     asm volatile("s_nop 15\ns_nop 15" ::: "memory");
-    conv_epilogue<4, 2, GNK>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32);
+    conv_epilogue<4, 2, GNK, true>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32, ldsepi + wn * 512,
+                                   ldsepi + 1024 + wm * 1024 + wn * 512);
 }
 
 }  // namespace
@@ -1412,7 +1463,7 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
                                  (const void*)conv_gemm256i_kernel<1>, (const void*)conv_gemm256i_kernel<2>,
                                  (const void*)conv_gemm256i_kernel<3>, (const void*)conv_gemm256i_kernel<1, 1>,
                                  (const void*)conv_gemm256i_kernel<1, 2>, (const void*)conv_gemm256i_kernel<1, 3>};
-            for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE);
+            for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE + LEPI_BYTES);
             hipDeviceProp_t prop;
             dev_ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
         });
@@ -1421,18 +1472,18 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         a.ntiles = (unsigned)grid256;
         if (a.gn_ws) {                     // statistics-reducing instances of the production kernel (env A/B switches do not apply)
             const int gnm = gn_mode_of(a.gn_cpg_log2);
-            if (gnm == 1) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 1>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
-            else if (gnm == 2) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 2>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
-            else hipLaunchKernelGGL((conv_gemm256i_kernel<1, 3>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+            if (gnm == 1) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 1>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
+            else if (gnm == 2) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 2>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
+            else hipLaunchKernelGGL((conv_gemm256i_kernel<1, 3>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
         } else if (dbg == 1) hipLaunchKernelGGL(conv_gemm256_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 2) hipLaunchKernelGGL(conv_gemm256_kernel<2>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 4) hipLaunchKernelGGL(conv_gemm256_kernel<4>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 3) hipLaunchKernelGGL(conv_gemm256_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 5) hipLaunchKernelGGL(conv_gemm256_kernel<5>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 6) hipLaunchKernelGGL(conv_gemm256_kernel<6>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
-        else if (env.dmav == 1) hipLaunchKernelGGL(conv_gemm256i_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
-        else if (env.dmav == 2) hipLaunchKernelGGL(conv_gemm256i_kernel<2>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
-        else if (env.dmav == 3) hipLaunchKernelGGL(conv_gemm256i_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+        else if (env.dmav == 1) hipLaunchKernelGGL(conv_gemm256i_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
+        else if (env.dmav == 2) hipLaunchKernelGGL(conv_gemm256i_kernel<2>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
+        else if (env.dmav == 3) hipLaunchKernelGGL(conv_gemm256i_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
         else if ((persist || (q->flags & UAV_CONV_PERSISTENT)) && grid256 > ncu) {
             // persistent form: one workgroup per CU walks tiles wg, wg + ncu, ... (UAV_CONV_PERSIST=0 disables)
             hipLaunchKernelGGL((conv_gemm256_kernel<0, 1>), dim3((unsigned)ncu), dim3(512), 2 * LSTAGE, s, a);

@@ -183,7 +183,7 @@ __global__ __launch_bounds__(1024) void gn_finalize_partials_kernel(const float*
 template <bool F32>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc s, long long rows_per_inst, int chunks,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
-                                                       int silu, char* __restrict__ y, char* __restrict__ raw) {
+                                                       int silu, char* __restrict__ y, char* __restrict__ raw, int raw_hilo) {
     const int c = s.c1 + s.c2, cvec = c >> 3;
     const int rpp = 256 / cvec;
     const int tid = threadIdx.x;
@@ -209,10 +209,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc s, long long rows_p
         }
         *(half8_t*)(y + (row * c + (long long)v * 8) * 2) = o;
         if (raw) {
-            half8_t r;
+            // raw_hilo: rows of 2c values [hi | lo], hi = fp16(x), lo = fp16(x - hi): x to ~22 bits as TWO fp16 operands (the
+            // shortcut conv then runs over K = 2c with its weights repeated), so the stream is not rounded to fp16 on that path
+            half8_t r, lo;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) r[j] = (half_t)x[j];
-            *(half8_t*)(raw + (row * c + (long long)v * 8) * 2) = r;
+            for (int j = 0; j < 8; ++j) { r[j] = (half_t)x[j]; lo[j] = (half_t)(x[j] - (float)r[j]); }
+            const long long rs = raw_hilo ? 2ll * c : (long long)c;
+            *(half8_t*)(raw + (row * rs + (long long)v * 8) * 2) = r;
+            if (raw_hilo) *(half8_t*)(raw + (row * rs + c + (long long)v * 8) * 2) = lo;
         }
     }
 }
@@ -344,7 +348,7 @@ extern "C" int uav_groupnorm_finalize_partials(const float* partials, int64_t ch
 
 extern "C" int uav_groupnorm_apply(const void* x1, const void* x2, int32_t x_f32, int32_t c1, int32_t c2, int64_t x2_rows,
                                    int32_t n_inst, int64_t rows_per_inst, const float* scale, const float* shift, int32_t silu,
-                                   void* y, void* raw_f16_out, void* stream) {
+                                   void* y, void* raw_f16_out, int32_t raw_hilo, void* stream) {
     if (!x1 || !scale || !shift || !y) return UAV_EINVAL;
     const int c = c1 + c2;
     if (c1 <= 0 || c2 < 0 || (c1 % 8) || (c2 % 8) || c > 2048 || (c2 > 0 && !x2)) return UAV_ESHAPE;
@@ -358,10 +362,10 @@ extern "C" int uav_groupnorm_apply(const void* x1, const void* x2, int32_t x_f32
     GnSrc s{(const char*)x1, (const char*)x2, c1, c2, (long long)x2_rows};
     if (x_f32)
         hipLaunchKernelGGL(gn_apply_kernel<true>, dim3((unsigned)chunks, n_inst), dim3(256), 0, (hipStream_t)stream, s,
-                           (long long)rows_per_inst, (int)chunks, scale, shift, silu, (char*)y, (char*)raw_f16_out);
+                           (long long)rows_per_inst, (int)chunks, scale, shift, silu, (char*)y, (char*)raw_f16_out, raw_hilo);
     else
         hipLaunchKernelGGL(gn_apply_kernel<false>, dim3((unsigned)chunks, n_inst), dim3(256), 0, (hipStream_t)stream, s,
-                           (long long)rows_per_inst, (int)chunks, scale, shift, silu, (char*)y, (char*)raw_f16_out);
+                           (long long)rows_per_inst, (int)chunks, scale, shift, silu, (char*)y, (char*)raw_f16_out, raw_hilo);
     return uav_launch_status();
 }
 

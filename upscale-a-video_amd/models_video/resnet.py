@@ -201,6 +201,8 @@ class _ResnetBase(E.EngineModule):
         # written by the norm1 pass, which has the values in registers anyway
         raw16 = None
         want_raw = self.conv_shortcut is not None and x.dtype == torch.float32
+        if want_raw and E.SHORTCUT_HILO and tuple(self.conv_shortcut.kernel_size) in ((1, 1), (1, 1, 1)) and c_real is None:
+            want_raw = "hilo"
         h = E.group_norm(self, "norm1", self.norm1, x, n_inst=g.b, rows_per_inst=g.rows_per_batch, silu=True, x2=x2,
                          c_real=c_real, want_raw=want_raw)
         if want_raw:
@@ -209,7 +211,10 @@ class _ResnetBase(E.EngineModule):
         h = self.conv1.run(h, g, rowbias=rb, out_f32=s32 and E.BRANCH_F32, gn_groups=self.norm2.num_groups)
         h = E.group_norm(self, "norm2", self.norm2, h, n_inst=g.b, rows_per_inst=g.rows_per_batch, silu=True)
         if self.conv_shortcut is not None:
-            if raw16 is not None:                 # [x | x2] already concatenated and rounded
+            if raw16 is not None and want_raw == "hilo":      # [x | x2] as hi and lo fp16 halves: K = 2 * C_in, weights repeated
+                res = ops.conv_gemm(raw16, E.packed_conv_hilo(self, "shortcut_hilo", self.conv_shortcut), n_img=g.n_img, t_len=g.t,
+                                    hi=g.h, wi=g.w, out_f32=s32, rows_per_batch=g.rows_per_batch)
+            elif raw16 is not None:               # [x | x2] already concatenated and rounded
                 res = self.conv_shortcut.run(raw16, g, out_f32=s32)
             else:
                 res = self.conv_shortcut.run(x, g, x2=x2, out_f32=s32) if x2 is not None else \

@@ -148,6 +148,21 @@ def packed_conv(mod: EngineModule, name, conv: nn.Module, geglu=False):
     return mod._cache().get(("conv", name), build, (conv.weight, conv.bias))
 
 
+def packed_conv_hilo(mod: EngineModule, name, conv: nn.Module):
+    """1x1 conv whose operand arrives as [hi | lo] fp16 halves of an fp32 row (ops.groupnorm_apply want_raw="hilo"): the weights
+    repeated along K, W.[hi | lo] = W.hi + W.lo.  `cin` keeps the logical channel count (FLOP accounting: the second half is
+    implementation overhead, not algorithmic work)."""
+    def build():
+        dev = _dev(conv.weight)
+        w = conv.weight.detach()
+        if any(k != 1 for k in w.shape[2:]):
+            raise ops._lib.UavError("hi/lo operands are for 1x1 convs")
+        cw = ops.pack_conv(torch.cat([w, w], dim=1), conv.bias, device=dev)
+        cw.cin = w.shape[1]
+        return cw
+    return mod._cache().get(("conv_hilo", name), build, (conv.weight, conv.bias))
+
+
 def packed_upsample_phases(mod: EngineModule, name, conv: nn.Module):
     """The four 2x2 sub-pixel phase convs of an upsampler's 3x3 conv, packed ([py][px], see ops.upsample_phase_weights)."""
     def build():
@@ -190,6 +205,10 @@ BRANCH_F32 = _os.environ.get("UAV_BRANCH_F32", "1") != "0"
 # ... and is the TOKEN stream inside a Transformer3DModel (proj_in output, the four residual adds of the block) fp32 (1) or
 # fp16 (0: only the block stream around the transformer is fp32)?  UAV_TOKEN_F32, default 1.
 TOKEN_F32 = _os.environ.get("UAV_TOKEN_F32", "1") != "0"
+# ... and does the 1x1 shortcut conv of a block with C_in != C_out read the fp32 stream as TWO fp16 operands (hi + lo, K
+# doubled: the stream is not rounded to fp16 on its way through the block, 1.01e-3 -> 0.81e-3 per forward for ~2 % of the
+# clip time) or as one (0)?  UAV_SHORTCUT_HILO, default 1.
+SHORTCUT_HILO = _os.environ.get("UAV_SHORTCUT_HILO", "1") != "0"
 
 
 # Group count a conv assumes for the GroupNorm that (probably) consumes its output when the caller cannot name that

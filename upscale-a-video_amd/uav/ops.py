@@ -418,18 +418,20 @@ def groupnorm_scale_shift(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps
 
 
 def groupnorm_apply(x1, scale, shift, *, n_inst, rows_per_inst, silu, x2=None, want_raw=False):
-    """want_raw: also return the un-normalised [x1|x2] rows rounded to fp16 (one extra 2 B/elem write in the same pass)."""
+    """want_raw: also return the un-normalised [x1|x2] rows as fp16 (extra write in the same pass): True -> rows of c values
+    fp16(x); "hilo" -> rows of 2c values [hi | lo], hi = fp16(x), lo = fp16(x - hi) (x to ~22 bits as two MFMA operands)."""
     lib = _lib.load()
     xf32 = _gn_dtype(x1, x2)
     c1 = x1.shape[-1]
     c2 = 0 if x2 is None else x2.shape[-1]
     y = torch.empty((n_inst * rows_per_inst, c1 + c2), dtype=HALF, device=x1.device)
-    raw = torch.empty_like(y) if want_raw else None
+    hilo = want_raw == "hilo"
+    raw = torch.empty((y.shape[0], (2 if hilo else 1) * (c1 + c2)), dtype=HALF, device=x1.device) if want_raw else None
     ev = PROFILER.begin("groupnorm_apply")
     rc = lib.uav_groupnorm_apply(_p(x1), _p(x2), xf32, c1, c2, _gn_x2_rows(x1, x2, n_inst * rows_per_inst), n_inst,
-                                 rows_per_inst, _p(scale), _p(shift), 1 if silu else 0, _p(y), _p(raw), _stream())
+                                 rows_per_inst, _p(scale), _p(shift), 1 if silu else 0, _p(y), _p(raw), int(hilo), _stream())
     _lib.check(rc, "uav_groupnorm_apply")
-    PROFILER.end(ev, "groupnorm_apply", 0.0, ((6.0 if xf32 else 4.0) + (2.0 if want_raw else 0.0)) * n_inst * rows_per_inst * (c1 + c2))
+    PROFILER.end(ev, "groupnorm_apply", 0.0, ((6.0 if xf32 else 4.0) + (4.0 if hilo else 2.0 if want_raw else 0.0)) * n_inst * rows_per_inst * (c1 + c2))
     return (y, raw) if want_raw else y
 
 
