@@ -163,6 +163,13 @@ def main():
     ap.add_argument("--shard-windows", action="store_true",
                     help="BASELINE configs[3]: ONE long clip (use --frames 32) whose temporal windows and decode chunks are "
                          "dealt over the ranks (strong scaling); every rank feeds the same clip and seed")
+    ap.add_argument("--shard-cfg", action="store_true",
+                    help="with --shard-windows: split every UNet evaluation into its two guidance branches, i.e. deal (window x "
+                         "branch) units over the ranks (10 per DDIM step for 32 frames, 2 for one 8-frame clip); bit-identical for "
+                         "every world size")
+    ap.add_argument("--digest", action="store_true",
+                    help="add config.output_sha256 (rank 0's last output tensor) to the JSON line: the sharded modes promise the "
+                         "same bits for every world size (tests/test_multigpu_gpu.py)")
     ap.add_argument("--clips-per-step", type=int, default=1,
                     help="clips upscaled CONCURRENTLY per GPU in one step, one HIP stream (and host thread) each: the "
                          "HBM-bound kernels of one clip run beside the MFMA-bound kernels of the other (serving mode); "
@@ -222,6 +229,9 @@ def main():
     unet_f32 = pipe.unet.stream_f32()
     pipe.cfg_shared_input = not args.no_cfg_share
     pipe.shard_windows = args.shard_windows
+    pipe.shard_cfg = args.shard_cfg
+    if args.shard_cfg and not args.shard_windows:
+        raise SystemExit("--shard-cfg refines --shard-windows")
     clip = synthetic_clip(args.frames, args.height, args.width, seed=0 if args.shard_windows else rank, dev=dev)
     flows, psteps = None, []
     if args.propagation:
@@ -338,11 +348,15 @@ def main():
                                    + ("all-fp16 decoder rows" if args.vae_fp16 else "fp32 residual stream, fp16 MFMA operands") + "), "
                                    + (f"RAFT flows (20 iters, {raft_s * 1e3:.0f} ms, outside the timed region like the reference) + "
                                       f"latent propagation at steps {psteps}; " if args.propagation else "no propagation; ")
-                                   + ("ONE clip, temporal windows + decode chunks dealt over the ranks, all-gather per DDIM step (RCCL)"
+                                   + (("ONE clip, (temporal window x guidance branch) units" if args.shard_cfg else "ONE clip, temporal windows")
+                                      + " + decode chunks dealt over the ranks, all-gather per DDIM step (RCCL)"
                                       if args.shard_windows else f"{ncl} clip(s) per GPU per step"
                                       + (" on concurrent HIP streams" if ncl > 1 else "") + " (clip-parallel, no collective)"),
                        "clips_per_step": world * ncl, "frames_per_clip": args.frames},
         }
+        if args.digest:
+            import hashlib
+            res["config"]["output_sha256"] = hashlib.sha256(out.detach().float().cpu().numpy().tobytes()).hexdigest()
         if use_events:
             summ = timed_summary
             if ops.PROFILER.detail:                       # per-shape table to stderr, then fold back

@@ -105,8 +105,10 @@ def test_pipeline_default_precision_mix_vs_reference_half(dev):
     unsat = gold["images"].float().abs() < 0.999
     e_img = rel_l2(out.float().cpu()[unsat], gold["images"].float()[unsat])
     report("pipe_t10_vaevideo_prop_refhalf", latents_rel_l2=e_lat, image_rel_l2_unsaturated=e_img)
-    assert e_lat < 1e-2, e_lat                         # two fp16 evaluations of the same 3 steps (same draws, same warps)
-    assert e_img < 3e-2, e_img
+    # measured (round 3, fp32-stream UNet with fp16 noise tensors like the CLI): 5.6e-3 / 1.13e-2 — the distance between the
+    # engine and the reference's OWN half run (fp16 rows, fp16 latents: 2.4e-3 per forward from its fp32 run); bars = +25 %
+    assert e_lat < 7e-3, e_lat
+    assert e_img < 1.4e-2, e_img
 
 
 # ------------------------------------------------------------------------------------------------
@@ -140,7 +142,8 @@ def test_unet_full_width_forward_vs_reference(full, dev):
     e32, e16 = rel_l2(out, gold["fp32"]), rel_l2(out, gold["fp16"])
     report("unet_full_t8_64", rel_l2_vs_reference_fp32=e32, rel_l2_vs_reference_fp16_run=e16, reference_fp16_vs_fp32=ref_noise)
     assert out.shape == gold["fp32"].shape
-    assert e32 <= ref_noise, (e32, ref_noise)          # no further from the fp32 reference than the reference's fp16 path
+    assert e32 < 1e-3, e32                             # BASELINE.json's stated tolerance (measured 8.07e-4, default fp32 stream)
+    assert e32 <= 0.5 * ref_noise, (e32, ref_noise)    # and less than half the reference's own fp16-vs-fp32 distance
     assert e16 <= 1.5 * ref_noise, (e16, ref_noise)
 
 
@@ -194,8 +197,10 @@ def test_baseline_config0_end_to_end_vs_reference(full, dev):
     report("pipe_c1_full", latents_rel_l2=e_lat, image_sub4_rel_l2_unsaturated=e_img, image_frame3_rel_l2_unsaturated=e_f3,
            saturated_fraction=1.0 - unsat.float().mean().item())
     assert out.shape == (1, 3, pc["t"], 4 * pc["h"], 4 * pc["w"])
-    assert e_lat < 1e-2, e_lat
-    assert e_img < 3e-2 and e_f3 < 3e-2, (e_img, e_f3)
+    # measured (round 3, default fp32 stream): latents 1.75e-3, image 2.5e-3 / 2.4e-3 (round 2, fp16 rows: 4.1e-3 / 5.5e-3);
+    # the 5-step schedule takes 200-timestep strides, each UNet error weighs ~6x what it does in the 30-step schedule
+    assert e_lat < 2.2e-3, e_lat
+    assert e_img < 3.1e-3 and e_f3 < 3.1e-3, (e_img, e_f3)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -242,8 +247,8 @@ def test_error_vs_ddim_step_curve_30_steps(dev):
     unsat = oimg.abs() < 0.999
     e_img = rel_l2(out.float().cpu()[unsat], oimg[unsat])
     report("curve_30_steps", latents_rel_l2_step1=curve[0], step5=curve[4], step15=curve[14], step30=curve[-1], image_rel_l2_unsaturated=e_img)
-    assert curve[-1] < 5e-2, curve                     # no blow-up: the error stays the size of a few fp16 forwards
-    assert max(curve) < 5e-2
+    assert curve[-1] < 1.4e-3, curve                   # measured 1.11e-3 after 30 steps (round 2, fp16 rows: 2.66e-3)
+    assert max(curve) < 1.4e-3
 
 
 # ------------------------------------------------------------------------------------------------

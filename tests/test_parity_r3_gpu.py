@@ -82,7 +82,7 @@ def test_unet_full_width_stream_modes_vs_reference(full, dev, mode):
     report("r3_unet_full_t8_64_" + mode, rel_l2_vs_reference_fp32=e32, rel_l2_vs_reference_fp16_run=e16,
            rel_l2_vs_reference_fp32_with_fp32_output=e32o, reference_fp16_vs_fp32=pinning("unet_full_t8_64")["reference_fp16_vs_fp32_rel_l2"])
     assert out.dtype == torch.float16 and out32.dtype == torch.float32
-    assert e32 < (1.3e-3 if mode == "fp32_stream" else 2.15e-3), e32
+    assert e32 < (1e-3 if mode == "fp32_stream" else 2.15e-3), e32      # measured 8.07e-4 / 1.707e-3
     assert e32o <= e32 + 1e-5
 
 
@@ -118,8 +118,8 @@ def test_headline_shape_unet_forward_vs_gpu_oracle(full, dev):
            engine_seconds_first_call_fp16=outs["fp16_stream_s"], engine_seconds_first_call_fp32=outs["fp32_stream_s"],
            ref_absmean=ref.abs().mean().item())
     assert ref.shape == (2, 4, 8, 320, 320) and bool(torch.isfinite(ref).all())
-    assert e32 < 1.5e-3, (e16, e32)
-    assert e16 < 2.6e-3, (e16, e32)
+    assert e32 < 9.6e-4, (e16, e32)                     # measured 7.68e-4: inside BASELINE.json's 1e-3 at the shape the bench times
+    assert e16 < 2.1e-3, (e16, e32)                     # measured 1.68e-3
     assert e32 < e16
 
 
@@ -144,7 +144,7 @@ def test_headline_shape_vae_chunk_vs_gpu_oracle(full, dev):
     report("r3_headline_vae3d_chunk_3x320x320_vs_gpu_oracle", rel_l2=e, rel_l2_unsaturated=e_un, oracle_seconds=t_ora,
            saturated_fraction=1.0 - unsat.float().mean().item(), ref_absmean=ref.abs().mean().item())
     assert out.shape == ref.shape == (1, 3, 3, 1280, 1280)
-    assert e < 1e-3, e
+    assert e < 7.3e-4, e                                # measured 5.8e-4
 
 
 # ------------------------------------------------------------------------------------------------
@@ -199,10 +199,11 @@ def test_full_width_30_step_curve_vs_reference(full, dev, mode):
     report("r3_pipe_full30_64_" + mode, steps=list(steps), engine_fp32_draws_vs_reference_fp32=curve32,
            engine_half_draws_vs_reference_half_run=curve16, engine_half_draws_vs_reference_fp32=curve16v32,
            reference_half_vs_its_fp32=ref_noise, image_rel_l2_unsaturated_vs_reference_fp32=e_img)
-    # measured (MI355X, round 3) + 25 %: fp32 stream 2.4e-4 after 5 steps, 1.03e-3 after 30 (image 1.6e-3);
-    # fp16 rows 6.6e-4 / 2.21e-3 (3.0e-3); the reference's own half pipeline vs its fp32 run: 1.12e-3 / 3.0e-3 (4.0e-3)
+    # measured (MI355X, round 3): fp32 stream 1.84e-4 after 5 steps, 8.6e-4 after 30 (image 1.37e-3) — the bar
+    # at step 30 is BASELINE.json's stated 1e-3, the others measured + 25 %; fp16 rows 6.6e-4 / 2.21e-3 (3.0e-3); the
+    # reference's own half pipeline vs its fp32 run: 1.12e-3 / 3.0e-3 (4.0e-3)
     i5, i30 = list(steps).index(5), list(steps).index(30)
-    bars = {"fp32_stream": (3.0e-4, 1.3e-3, 2.0e-3), "fp16_stream": (8.3e-4, 2.8e-3, 3.8e-3)}[mode]
+    bars = {"fp32_stream": (2.3e-4, 1.0e-3, 1.7e-3), "fp16_stream": (8.3e-4, 2.8e-3, 3.8e-3)}[mode]
     assert curve32[i5] < bars[0] and curve32[i30] < bars[1] and e_img < bars[2], (curve32, e_img)
     assert curve32[i30] < ref_noise[i30]                # closer to the fp32 trajectory than the reference's half pipeline
     # in the CLI's mix (fp16 noise tensors) the engine and the reference half run are two fp16-grade evaluations of the

@@ -13,6 +13,7 @@
 // HBM-bound by construction (~4 FLOP/B): algorithmic bytes = 8*C per token (read q,k,v,
 // write out, fp16).
 #include "uav_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -147,6 +148,132 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(TAttnArgs p) {
     }
 }
 
+
+// Round 3 form of the same computation (bit-identical results).  The kernel above reads K / V frame by frame behind a
+// divergent `if (rot)` block and fetches the RoPE tables and the 8 bias scalars of a row with one waited-for load each:
+// ~90 SERIALIZED memory round trips per wave (ISA: `L [vmcnt 0]` 70 times) — latency-bound at 3.0 TB/s although its
+// VALU work would allow ~11 TB/s.  Here
+//   * the small tables (bias [heads][T][T], cos / sin [T][rot/2]) are staged in LDS once per workgroup;
+//   * all 24 row loads of a pixel (q, k, v of 8 frames: 24 KiB per wave) are issued back to back, branch-free;
+//   * lanes outside the rotary dims rotate by (cos, sin) = (1, 0), which is exact, instead of branching.
+constexpr int TA_BIAS_MAX = 512, TA_ROPE_MAX = 256;
+template <int LPH>
+__global__ __launch_bounds__(256) void temporal_attn2_kernel(TAttnArgs p) {
+    __shared__ float s_bias[TA_BIAS_MAX];
+    __shared__ __attribute__((aligned(16))) float s_cs[TA_ROPE_MAX];
+    __shared__ __attribute__((aligned(16))) float s_sn[TA_ROPE_MAX];
+    const int T = p.t_len;
+    const int hr = p.rot_dim >> 1;
+    const int lane = threadIdx.x & 63;
+    const long long nwork = (long long)p.n_batch * p.hw * p.groups;
+    long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const bool active = wid < nwork;                 // tail waves load a valid pixel, take part in the barrier, store nothing
+    if (!active) wid = nwork - 1;
+    const int grp = (int)(wid % p.groups);
+    const long long bp = wid / p.groups;
+    const long long pix = bp % p.hw;
+    const int b = (int)(bp / p.hw);
+    const int c0 = grp * 512 + lane * 8;
+    const bool live = c0 < p.c;
+    const int cc = live ? c0 : 0;
+    const int head = cc / p.d;
+    const int sub = (cc % p.d) >> 3;
+    const bool rot = sub * 8 < p.rot_dim;
+    const long long row_stride = 3ll * p.c * 2;
+    const char* base = p.qkv + ((long long)b * T * p.hw + pix) * row_stride + (long long)cc * 2;
+    const long long fstride = p.hw * row_stride;
+    const int rsub = rot ? sub * 4 : 0;
+
+    // the 24 streaming loads go out first; the table staging (L2 hits) and the barrier ride in their shadow
+    half8_t qx[TMAX], kh[TMAX], vx[TMAX];
+#pragma unroll
+    for (int j = 0; j < TMAX; ++j) {
+        const int jc = j < T ? j : T - 1;
+        qx[j] = *(const half8_t*)(base + jc * fstride);
+        kh[j] = *(const half8_t*)(base + jc * fstride + (long long)p.c * 2);
+        vx[j] = *(const half8_t*)(base + jc * fstride + (long long)p.c * 4);
+    }
+    {   // straight-line staging: 4 independent (clamped) loads per thread, one wait, then the LDS writes
+        const int nb = p.heads * T * T, nr = T * hr, t0 = threadIdx.x;
+        const float b0 = p.bias[t0 < nb ? t0 : 0], b1 = p.bias[t0 + 256 < nb ? t0 + 256 : 0];
+        const float c_ = nr ? p.rope_cos[t0 < nr ? t0 : 0] : 0.f, s_ = nr ? p.rope_sin[t0 < nr ? t0 : 0] : 0.f;
+        if (t0 < nb) s_bias[t0] = b0;
+        if (t0 + 256 < nb) s_bias[t0 + 256] = b1;
+        if (t0 < nr) { s_cs[t0] = c_; s_sn[t0] = s_; }
+    }
+    __syncthreads();
+    if (!active) return;
+    float vf[TMAX][8];
+#pragma unroll
+    for (int j = 0; j < TMAX; ++j) {
+        const int jc = j < T ? j : T - 1;
+        float4_t cs = {1.f, 1.f, 1.f, 1.f}, sn = {0.f, 0.f, 0.f, 0.f};
+        if (rot) { cs = *(const float4_t*)(s_cs + jc * hr + rsub); sn = *(const float4_t*)(s_sn + jc * hr + rsub); }
+        half8_t kx = kh[j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a = (float)kx[2 * q], bb = (float)kx[2 * q + 1];
+            kx[2 * q] = (half_t)(a * cs[q] - bb * sn[q]);
+            kx[2 * q + 1] = (half_t)(bb * cs[q] + a * sn[q]);
+        }
+        kh[j] = kx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vf[j][e] = (float)vx[j][e];
+    }
+    char* obase = p.out + (((long long)b * T * p.hw + pix) * p.c + cc) * 2;
+    const long long ofstride = p.hw * (long long)p.c * 2;
+#pragma unroll
+    for (int i = 0; i < TMAX; ++i) {
+        if (i >= T) break;
+        float qf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[e] = (float)qx[i][e] * p.scale;
+        float4_t cs = {1.f, 1.f, 1.f, 1.f}, sn = {0.f, 0.f, 0.f, 0.f};
+        if (rot) { cs = *(const float4_t*)(s_cs + i * hr + rsub); sn = *(const float4_t*)(s_sn + i * hr + rsub); }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a = qf[2 * q], bb = qf[2 * q + 1];
+            qf[2 * q] = a * cs[q] - bb * sn[q];
+            qf[2 * q + 1] = bb * cs[q] + a * sn[q];
+        }
+        half2_t qh[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) qh[q] = half2_t{(half_t)qf[2 * q], (half_t)qf[2 * q + 1]};
+        const float* brow = s_bias + (head * T + i) * T;
+        float sc[TMAX];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < TMAX; ++j) {
+            float a = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a = __builtin_amdgcn_fdot2(qh[q], half2_t{kh[j][2 * q], kh[j][2 * q + 1]}, a, false);
+            a = head_allreduce<LPH>(a);
+            if (j < T) { a += brow[j]; mx = fmaxf(mx, a); }
+            sc[j] = a;
+        }
+        float den = 0.f;
+#pragma unroll
+        for (int j = 0; j < TMAX; ++j) {
+            sc[j] = j < T ? __expf(sc[j] - mx) : 0.f;
+            den += sc[j];
+        }
+        const float inv = 1.0f / den;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int j = 0; j < TMAX; ++j) {
+            const float pj = sc[j] * inv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] += pj * vf[j][e];
+        }
+        half8_t oh;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) oh[e] = (half_t)o[e];
+        if (live) *(half8_t*)(obase + i * ofstride) = oh;
+    }
+}
+
 }  // namespace
 
 extern "C" int uav_temporal_attention_f16(const void* qkv, void* out, int32_t n_batch, int32_t t_len, int64_t hw,
@@ -164,6 +291,19 @@ extern "C" int uav_temporal_attention_f16(const void* qkv, void* out, int32_t n_
     const long long blocks = (nwork + 3) / 4;
     if (blocks >= (1ll << 31)) return UAV_ESHAPE;
     hipStream_t st = (hipStream_t)stream;
+    static const int variant = [] { const char* e = getenv("UAV_TATTN"); return e ? atoi(e) : 2; }();   // 1: round-1/2 kernel (A/B)
+    if (variant == 2 && heads * t_len * t_len <= TA_BIAS_MAX && t_len * (rot_dim >> 1) <= TA_ROPE_MAX && !(rot_dim & 7)) {
+        switch (d >> 3) {
+            case 1: hipLaunchKernelGGL(temporal_attn2_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL(temporal_attn2_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+            case 4: hipLaunchKernelGGL(temporal_attn2_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+            case 8: hipLaunchKernelGGL(temporal_attn2_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+            case 16: hipLaunchKernelGGL(temporal_attn2_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+            case 32: hipLaunchKernelGGL(temporal_attn2_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL(temporal_attn2_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
+        }
+        return uav_launch_status();
+    }
     switch (d >> 3) {                       // lanes per head
         case 1: hipLaunchKernelGGL(temporal_attn_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
         case 2: hipLaunchKernelGGL(temporal_attn_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, a); break;
