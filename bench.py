@@ -361,7 +361,7 @@ def main():
             summ = timed_summary
             if ops.PROFILER.detail:                       # per-shape table to stderr, then fold back
                 tot = sum(v["seconds"] for v in summ.values())
-                for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])[:45]:
+                for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["seconds"])[:90]:
                     print(f"{v['seconds'] * 1e3:9.2f} ms {100 * v['seconds'] / tot:5.1f}% n={v['launches']:5d} "
                           f"{(v['flops'] / v['seconds'] / 1e12 if v['flops'] else 0):7.1f} TF/s "
                           f"{v['bytes'] / v['seconds'] / 1e9:8.1f} GB/s  {k}", file=sys.stderr)

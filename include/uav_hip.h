@@ -136,6 +136,14 @@ int uav_groupnorm_scale_shift(const void* x1, const void* x2,
 int uav_groupnorm_finalize_partials(const float* partials, int64_t chunks_total, int32_t chunk_rows, int32_t c,
                                     int32_t n_inst, int64_t rows_per_inst, int32_t groups, float eps,
                                     const float* gamma, const float* beta, float* scale_out, float* shift_out, void* stream);
+/* same for a channel-concatenated input [x1 | x2] whose two sources each carry the partials of their own producer
+ * ([2][groupsS][chunks_totalS]): the output groups must not straddle the seam (c1 % (c/groups) == 0) and must be whole
+ * multiples of each producer's group; n_instS = instances the source holds (n_inst, or a divisor of it when the source
+ * exists once for several batch entries: instance i reads the chunks of instance i % n_instS). */
+int uav_groupnorm_finalize_partials2(const float* partials1, int64_t chunks_total1, int32_t c1, int32_t groups1, int32_t n_inst1,
+                                     const float* partials2, int64_t chunks_total2, int32_t c2, int32_t groups2, int32_t n_inst2,
+                                     int32_t chunk_rows, int32_t n_inst, int64_t rows_per_inst, int32_t groups, float eps,
+                                     const float* gamma, const float* beta, float* scale_out, float* shift_out, void* stream);
 int uav_groupnorm_apply(const void* x1, const void* x2, int32_t x_f32, int32_t c1, int32_t c2, int64_t x2_rows,
                         int32_t n_inst, int64_t rows_per_inst,
                         const float* scale, const float* shift, int32_t silu,

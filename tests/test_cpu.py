@@ -393,7 +393,7 @@ def test_cabi_rejects_bad_arguments_without_touching_the_gpu():
     assert lib.uav_groupnorm_scale_shift(P, None, 1, 64, 0, 0, 64, 1, 16, 7, 1e-5, None, None, P, P, P, 1 << 20, None) == ESHAPE
     assert lib.uav_groupnorm_scale_shift(P, None, 0, 64, 0, 0, 64, 1, 16, 32, 1e-5, None, None, P, P, P, 8, None) == EINVAL    # workspace too small
     assert lib.uav_groupnorm_scale_shift(P, P, 0, 64, 64, 7, 128, 2, 16, 32, 1e-5, None, None, P, P, P, 1 << 20, None) == ESHAPE   # x2_rows != half
-    assert lib.uav_groupnorm_apply(P, P, 0, 64, 64, 7, 2, 16, P, P, 1, P, None) == ESHAPE
+    assert lib.uav_groupnorm_apply(P, P, 0, 64, 64, 7, 2, 16, P, P, 1, P, None, 0, None) == ESHAPE
     assert conv(c2=64, a2=P, k_pad=1152, a2_images=3) == ESHAPE                     # broadcast source: n_img must be 2 * a2_images
     # attention: null / shape / alignment
     assert lib.uav_attention_f16(None, 64, P, 64, P, 64, P, 64, 1, 8, 8, 1, 1, 64, 0.125, 0, P, None) == EINVAL

@@ -481,6 +481,48 @@ def test_conv_fused_groupnorm_statistics(ops, dev, cout, f32, res, temb, k3):
     assert rel_l2(sc2 * 2.0, sc5) < 1e-3
 
 
+@pytest.mark.parametrize("c1,c2,f32,half_skip", [(512, 512, False, False), (256, 256, True, True), (1024, 1024, True, False),
+                                                  (1024, 512, False, False)])
+def test_groupnorm_two_source_statistics_from_producer_partials(ops, dev, c1, c2, f32, half_skip):
+    """GroupNorm over a channel-concatenated input [x1 | x2] (up-block ResNets; the concat is never materialised): when the 32
+    output groups do not straddle the seam, the scale/shift tables come from the partials the two PRODUCING convs wrote
+    (uav_groupnorm_finalize_partials2: each output group = whole producer groups), incl. a skip tensor that exists once for
+    both batch entries; 1024 + 512 (48-channel groups straddle) must fall back to the statistics pass."""
+    g = torch.Generator().manual_seed(c1 + c2)
+    bsz, t_len, h, w, cin, groups = 2, 2, 64, 64, 64, 32
+    if c1 < 1024:
+        h, w = (128, 128) if c1 == 256 else (128, 64)
+    rows = bsz * t_len * h * w
+
+    def produce(cout, nb):
+        m = nb * t_len * h * w
+        x = torch.randn(m, cin, generator=g).half().to(dev)
+        cw = ops.pack_conv(h16(cout, cin, 1, 1, 1, dev=dev, scale=cin ** -0.5, gen=g), torch.randn(cout, generator=g), device=dev)
+        return ops.conv_gemm(x, cw, n_img=nb * t_len, t_len=t_len, hi=h, wi=w, out_f32=f32, gn_groups=groups)
+    x1 = produce(c1, bsz)
+    x2 = produce(c2, 1 if half_skip else bsz)
+    c = c1 + c2
+    straddle = c1 % (c // groups) != 0
+    if not straddle:
+        if half_skip and getattr(x2, "_uav_gn", None) is None:
+            pytest.skip("half-batch producer too small for the 256x256 kernel")
+        assert getattr(x1, "_uav_gn", None) is not None and getattr(x2, "_uav_gn", None) is not None
+    gamma = (1 + 0.1 * torch.randn(c, generator=g)).to(dev); beta = (0.1 * torch.randn(c, generator=g)).to(dev)
+    kw = dict(n_inst=bsz, rows_per_inst=t_len * h * w, groups=groups, eps=1e-5)
+    fused = ops._gn_two_source(x1, x2, groups, bsz, t_len * h * w)
+    assert (fused is None) == straddle
+    sc1, sh1 = ops.groupnorm_scale_shift(x1, gamma, beta, x2=x2, **kw)
+    x1c, x2c = x1.clone(), x2.clone()                       # copies carry no partials: stand-alone statistics pass
+    sc0, sh0 = ops.groupnorm_scale_shift(x1c, gamma, beta, x2=x2c, **kw)
+    assert rel_l2(sc1, sc0) < 1e-3 and rel_l2(sh1, sh0) < 1e-3
+    # and against exact statistics of the concatenated tensor
+    x2f = torch.cat([x2, x2]) if half_skip else x2
+    xc = torch.cat([x1.double(), x2f.double()], dim=-1).reshape(bsz, t_len * h * w, groups, c // groups)
+    mu = xc.mean(dim=(1, 3)); var = xc.var(dim=(1, 3), unbiased=False)
+    sc_ref = (gamma.double().reshape(1, groups, -1) / (var + 1e-5).sqrt()[:, :, None]).reshape(bsz, c)
+    assert rel_l2(sc1, sc_ref.float()) < 1e-3
+
+
 def test_conv_fused_groupnorm_statistics_not_offered(ops, dev):
     """Launches that cannot produce partials (small grids -> 128x128 kernel, N tails, GEGLU, 48-channel groups) return a
     plain tensor, and GroupNorm falls back to its own statistics pass."""

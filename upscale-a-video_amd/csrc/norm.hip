@@ -180,6 +180,46 @@ __global__ __launch_bounds__(1024) void gn_finalize_partials_kernel(const float*
 // raw (optional): the UN-normalised input, concatenated and rounded to fp16 — the MFMA operand of the 1x1 shortcut conv
 // of a block whose input is an fp32 stream (+ skip tensor); written here because this pass has the fp32 values in
 // registers anyway (a separate cast pass would read them a second time).
+// Two-source form (channel-concatenated input [x1 | x2] of an up-block ResNet, never materialised): each source carries the
+// partials ITS producer wrote for its own group size; an output group of cpg channels lies inside one source (the host
+// checks c1 % cpg == 0) and is the sum of cpg / cpgS consecutive producer groups.  A source that exists once for both batch
+// entries (skip tensor of the CFG-shared head) serves instance i with the chunks of instance i % inst2.
+struct GnSrcPartials { const float* ws; long long chunks_total, chunks; int c, groups, n_inst; };
+__global__ __launch_bounds__(1024) void gn_finalize_partials2_kernel(GnSrcPartials s1, GnSrcPartials s2, int groups,
+                                                                     long long rows_per_inst, float eps,
+                                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                     float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ double rs[1024], rq[1024];
+    const int g = blockIdx.x, inst = blockIdx.y, tid = threadIdx.x;
+    const int c = s1.c + s2.c, cpg = c / groups, ch0 = g * cpg;
+    const bool first = ch0 < s1.c;
+    const GnSrcPartials& s = first ? s1 : s2;
+    const int cpgs = s.c / s.groups, k = cpg / cpgs, pg0 = (first ? ch0 : ch0 - s1.c) / cpgs;
+    const int si = inst % s.n_inst;
+    double a = 0.0, b = 0.0;
+    for (int j = 0; j < k; ++j) {
+        const float* ps = s.ws + (long long)(pg0 + j) * s.chunks_total + (long long)si * s.chunks;
+        const float* pq = ps + (long long)s.groups * s.chunks_total;
+        for (long long q = tid; q < s.chunks; q += 1024) { a += ps[q]; b += pq[q]; }
+    }
+    rs[tid] = a; rq[tid] = b;
+    __syncthreads();
+    for (int o = 512; o > 0; o >>= 1) {
+        if (tid < o) { rs[tid] += rs[tid + o]; rq[tid] += rq[tid + o]; }
+        __syncthreads();
+    }
+    const double n = (double)rows_per_inst * cpg;
+    const double mean = rs[0] / n;
+    double var = rq[0] / n - mean * mean; if (var < 0.0) var = 0.0;
+    const float fm = (float)mean, fr = (float)(1.0 / sqrt(var + (double)eps));
+    for (int j = tid; j < cpg; j += 1024) {
+        const int ch = ch0 + j;
+        const float ga = gamma ? gamma[ch] : 1.f, be = beta ? beta[ch] : 0.f;
+        scale[(long long)inst * c + ch] = ga * fr;
+        shift[(long long)inst * c + ch] = be - fm * fr * ga;
+    }
+}
+
 template <bool F32>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc s, long long rows_per_inst, int chunks,
                                                        const float* __restrict__ scale, const float* __restrict__ shift,
@@ -231,6 +271,33 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const char* __restrict__
     const int cvec = c >> 3;
     const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long nwaves = (long long)gridDim.x * 4;
+    // gamma / beta of this lane's channels: once per wave, not once per row behind the statistics (round 2 re-loaded them
+    // for every row AFTER the reduction: a second, L2-latency-long round trip on each row's critical path)
+    float gam[NV][8], bet[NV][8];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = lane + i * 64;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { gam[i][j] = v < cvec ? gamma[v * 8 + j] : 0.f; bet[i][j] = v < cvec ? beta[v * 8 + j] : 0.f; }
+    }
+    // raw row of the NEXT iteration is requested before this row's reduction: one row always in flight per wave
+    float4_t rawf[F32 ? NV : 1][2];
+    half8_t rawh[F32 ? 1 : NV];
+    auto fetch = [&](long long row) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int v = lane + i * 64;
+            if (v < cvec) {
+                if (F32) {
+                    rawf[F32 ? i : 0][0] = *(const float4_t*)(x + (row * c + (long long)v * 8) * 4);
+                    rawf[F32 ? i : 0][1] = *(const float4_t*)(x + (row * c + (long long)v * 8) * 4 + 16);
+                } else {
+                    rawh[F32 ? 0 : i] = *(const half8_t*)(x + (row * c + (long long)v * 8) * 2);
+                }
+            }
+        }
+    };
+    if (wave_id < rows) fetch(wave_id);
     for (long long row = wave_id; row < rows; row += nwaves) {
         float xv[NV][8];
         float s = 0.f;
@@ -239,19 +306,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const char* __restrict__
             const int v = lane + i * 64;
             if (v < cvec) {
                 if (F32) {
-                    const float4_t a = *(const float4_t*)(x + (row * c + (long long)v * 8) * 4);
-                    const float4_t b = *(const float4_t*)(x + (row * c + (long long)v * 8) * 4 + 16);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { xv[i][j] = a[j]; xv[i][4 + j] = b[j]; }
+                    for (int j = 0; j < 4; ++j) { xv[i][j] = rawf[F32 ? i : 0][0][j]; xv[i][4 + j] = rawf[F32 ? i : 0][1][j]; }
                 } else {
-                    const half8_t h = *(const half8_t*)(x + (row * c + (long long)v * 8) * 2);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) xv[i][j] = (float)h[j];
+                    for (int j = 0; j < 8; ++j) xv[i][j] = (float)rawh[F32 ? 0 : i][j];
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s += xv[i][j];
             }
         }
+        if (row + nwaves < rows) fetch(row + nwaves);
         const float mean = wave_sum(s) / (float)c;
         float q = 0.f;
 #pragma unroll
@@ -269,10 +334,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const char* __restrict__
             if (v < cvec) {
                 half8_t o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int ch = v * 8 + j;
-                    o[j] = (half_t)((xv[i][j] - mean) * rstd * gamma[ch] + beta[ch]);
-                }
+                for (int j = 0; j < 8; ++j) o[j] = (half_t)((xv[i][j] - mean) * rstd * gam[i][j] + bet[i][j]);
                 *(half8_t*)(y + (row * c + (long long)v * 8) * 2) = o;
             }
         }
@@ -343,6 +405,29 @@ extern "C" int uav_groupnorm_finalize_partials(const float* partials, int64_t ch
     hipLaunchKernelGGL(gn_finalize_partials_kernel, dim3(groups, n_inst), dim3(1024), 0, (hipStream_t)stream, partials,
                        (long long)chunks_total, (long long)(rows_per_inst / chunk_rows), c, groups, (long long)rows_per_inst,
                        eps, gamma, beta, scale_out, shift_out);
+    return uav_launch_status();
+}
+
+extern "C" int uav_groupnorm_finalize_partials2(const float* partials1, int64_t chunks_total1, int32_t c1, int32_t groups1, int32_t n_inst1,
+                                                const float* partials2, int64_t chunks_total2, int32_t c2, int32_t groups2, int32_t n_inst2,
+                                                int32_t chunk_rows, int32_t n_inst, int64_t rows_per_inst, int32_t groups, float eps,
+                                                const float* gamma, const float* beta, float* scale_out, float* shift_out,
+                                                void* stream) {
+    if (!partials1 || !partials2 || !scale_out || !shift_out) return UAV_EINVAL;
+    const int c = c1 + c2;
+    if (c1 <= 0 || c2 <= 0 || groups <= 0 || groups > 2048 || (c % groups) || groups1 <= 0 || groups2 <= 0 || (c1 % groups1) ||
+        (c2 % groups2) || n_inst <= 0 || n_inst > 65535 || rows_per_inst <= 0 || chunk_rows <= 0 || (rows_per_inst % chunk_rows))
+        return UAV_ESHAPE;
+    const int cpg = c / groups;
+    if ((c1 % cpg) || (cpg % (c1 / groups1)) || (cpg % (c2 / groups2))) return UAV_ESHAPE;      // groups must not straddle
+    const long long chunks = rows_per_inst / chunk_rows;
+    if (n_inst1 <= 0 || n_inst2 <= 0 || (n_inst % n_inst1) || (n_inst % n_inst2) || chunks_total1 != (int64_t)n_inst1 * chunks ||
+        chunks_total2 != (int64_t)n_inst2 * chunks)
+        return UAV_ESHAPE;
+    GnSrcPartials s1{partials1, (long long)chunks_total1, chunks, c1, groups1, n_inst1};
+    GnSrcPartials s2{partials2, (long long)chunks_total2, chunks, c2, groups2, n_inst2};
+    hipLaunchKernelGGL(gn_finalize_partials2_kernel, dim3(groups, n_inst), dim3(1024), 0, (hipStream_t)stream, s1, s2, groups,
+                       (long long)rows_per_inst, eps, gamma, beta, scale_out, shift_out);
     return uav_launch_status();
 }
 

@@ -330,6 +330,7 @@ def linear(x, wt: ConvW, *, residual=None, out_scale=1.0, rowbias=None, rows_per
 # the tensor OBJECT the conv returned: a view, a copy or an in-place update of it (`_version` moves) does not carry them,
 # and the GroupNorm then runs its own statistics pass.
 FUSE_GN_STATS = os.environ.get("UAV_FUSE_GN_STATS", "1") != "0"
+GN_TWO_SOURCE = os.environ.get("UAV_GN_TWO_SOURCE", "1") != "0"      # concatenated inputs: statistics from the two producers' partials
 
 
 class GnPartials:
@@ -353,6 +354,34 @@ def _gn_partials_of(x, groups, c, rows_per_inst):
     if gn.ws.shape[-1] * gn.rows != x.shape[0]:      # partials of another row count (the tensor was re-interpreted): stats pass
         return None
     return gn
+
+
+def _gn_partials_any(x):
+    """Valid statistics partials riding on `x`, whatever group count their producer assumed."""
+    gn = getattr(x, "_uav_gn", None)
+    if gn is None or gn.version != x._version or x.shape[-1] != gn.c or gn.ws.shape[-1] * gn.rows != x.shape[0]:
+        return None
+    return gn
+
+
+def _gn_two_source(x1, x2, groups, n_inst, rows_per_inst):
+    """(gn1, gn2, n_inst2) when the statistics of the concatenated input [x1 | x2] can be had from the two producers'
+    partials (uav_groupnorm_finalize_partials2), else None."""
+    g1, g2 = _gn_partials_any(x1), _gn_partials_any(x2)
+    if g1 is None or g2 is None or g1.rows != g2.rows or rows_per_inst % g1.rows:
+        return None
+    c1, c2 = x1.shape[-1], x2.shape[-1]
+    c = c1 + c2
+    if c % groups:
+        return None
+    cpg = c // groups
+    if c1 % cpg or cpg % (c1 // g1.groups) or cpg % (c2 // g2.groups):
+        return None
+    rows = n_inst * rows_per_inst
+    if x1.shape[0] != rows or x2.shape[0] not in (rows, rows // 2) or (x2.shape[0] != rows and (n_inst % 2 or rows % 2)):
+        return None
+    n2 = n_inst if x2.shape[0] == rows else n_inst // 2
+    return g1, g2, n2
 
 
 def duplicate_rows(t):
@@ -398,6 +427,16 @@ def groupnorm_scale_shift(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps
     gn = _gn_partials_of(x1, groups, c, rows_per_inst) if (x2 is None and c_real == c) else None
     if gn is not None and gn.ws.shape[-1] * gn.rows != n_inst * rows_per_inst:
         gn = None                                    # instance split does not cover the producer's rows: statistics pass
+    two = _gn_two_source(x1, x2, groups, n_inst, rows_per_inst) if (x2 is not None and c_real == c and FUSE_GN_STATS and GN_TWO_SOURCE) else None
+    if two is not None:
+        g1, g2, n2 = two
+        ev = PROFILER.begin("groupnorm_stats")
+        rc = lib.uav_groupnorm_finalize_partials2(_p(g1.ws), g1.ws.shape[-1], c1, g1.groups, n_inst, _p(g2.ws), g2.ws.shape[-1], c2,
+                                                  g2.groups, n2, g1.rows, n_inst, rows_per_inst, groups, eps, _p(gamma), _p(beta),
+                                                  _p(scale), _p(shift), _stream())
+        _lib.check(rc, "uav_groupnorm_finalize_partials2")
+        PROFILER.end(ev, "groupnorm_finalize_fused", 0.0, 4.0 * (g1.ws.numel() + g2.ws.numel()))
+        return scale, shift
     if gn is not None:
         chunks_total = gn.ws.shape[-1]
         ev = PROFILER.begin("groupnorm_stats")
