@@ -381,14 +381,20 @@ def main():
             # HBM traffic per launch of the dominant kernel cannot be read from inside this process: it comes from the
             # committed PMC pass over this same command (tools/pmc_traffic.sh -> profiles/pmc_conv_traffic.json;
             # TCC_EA0_RDREQ / WRREQ with the gfx950 corrections of MI355X_MICROARCH.md) and stays null without it.
-            traffic = None
+            traffic, traffic_note = None, None
             tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_conv_traffic.json")
-            if name == "conv_gemm" and os.path.exists(tfile) and not (args.propagation or args.shard_windows or args.video_vae or args.frames != 8 or args.height != 320 or args.width != 320):
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
+            if name == "conv_gemm" and os.path.exists(tfile) and not (args.propagation or args.shard_windows or args.video_vae or args.frames != 8 or args.height != 320 or args.width != 320 or args.unet_stream == "f16"):
+                from uav import build as _build
+                tj = json.load(open(tfile))
+                if tj.get("kernel_sources_digest") == _build._digest():
+                    traffic = tj.get("hbm_bytes_per_launch")
+                else:           # the PMC pass describes another build of the kernels: do not replay it
+                    traffic_note = "profiles/pmc_conv_traffic.json was taken with other kernel sources (digest mismatch): not replayed"
             res["roofline"] = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_TFLOPS_F16, "unit": "TFLOP/s",
                                "frac": ach / PEAK_TFLOPS_F16, "traffic": traffic,
-                               "traffic_source": None if traffic is None else "replayed from profiles/pmc_conv_traffic.json (separate rocprofv3 "
-                                                 "--pmc pass over this command, tools/pmc_traffic.sh); not measured by this run",
+                               "traffic_source": traffic_note if traffic is None else "replayed from profiles/pmc_conv_traffic.json (separate rocprofv3 "
+                                                 "--pmc pass over this command with the SAME kernel sources — digest checked —, tools/pmc_traffic.sh); "
+                                                 "not measured by this run",
                                "launches": d["launches"],
                                "avg_launch_us": d["seconds"] / d["launches"] * 1e6,
                                "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,

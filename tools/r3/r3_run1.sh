@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call 1: new parity tests (stream modes, headline shape vs the GPU oracle), whole GPU suite, bench in both UNet stream modes
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && rm -f gpurun_out/parity.jsonl
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && rm -f gpurun_out/parity.jsonl
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_parity_r3_gpu.py -q -m gpu -k "not 30_step" 2>&1 | tail -25 > gpurun_out/r3_tests_parity_r3.log
 cat gpurun_out/r3_tests_parity_r3.log | tail -8

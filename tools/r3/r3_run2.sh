@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call 2: per-shape tables of both UNet stream modes (same box)
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 for m in f16 f32; do
   UAV_BENCH_DETAIL=1 timeout 600 python bench.py --steps 1 --no-cpu-baseline --unet-stream $m > gpurun_out/r3_detail_$m.json 2> gpurun_out/r3_detail_$m.txt

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call 3: 30-step curve (both stream modes) vs the reference fixture, unit tests after the raw-copy change, bench f32
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && rm -f gpurun_out/parity.jsonl
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && rm -f gpurun_out/parity.jsonl
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_parity_r3_gpu.py -q -m gpu 2>&1 | tail -25 > gpurun_out/r3_tests_parity_r3.log
 tail -6 gpurun_out/r3_tests_parity_r3.log

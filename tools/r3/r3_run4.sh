@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, GPU call 4: epilogue vector-memory order (staged bias, residual loads ahead of the stores): kernel tests, same-box A/B
 # of the two library builds on the conv micro-benchmarks (with the epilogue variants that matter) and end to end
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$PWD
 timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_models_gpu.py tests/test_fullsize_gpu.py -q -m gpu -x 2>&1 | tail -4

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3, GPU call 5: new defaults (fp32 stream + hi/lo shortcut operands + epilogue order): whole GPU suite, smoke, parity
 # report, default bench, fp16-stream bench, per-shape table
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out && rm -f gpurun_out/parity.jsonl
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out && rm -f gpurun_out/parity.jsonl
 export TMPDIR=/tmp
 timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -15 > gpurun_out/r3_tests_all.log
 tail -6 gpurun_out/r3_tests_all.log

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call 7: temporal attention v2 (loads issued together) A/B inside one box, kernel tests
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_models_gpu.py -q -m gpu -x 2>&1 | tail -3
 UAV_TATTN=1 timeout 200 python tools/bench_kernels.py tattn 2>/dev/null | sed 's/^/v1 /'

@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 3, GPU call 8: GroupNorm statistics of concatenated inputs from the two producers' partials: test + same-box A/B
-cd "$(dirname "$0")/.." && mkdir -p gpurun_out
+cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
 export TMPDIR=/tmp
 timeout 600 python -m pytest tests/test_kernels_gpu.py tests/test_models_gpu.py tests/test_fullsize_gpu.py -q -m gpu -x 2>&1 | tail -3
 for i in 1 2; do

@@ -261,7 +261,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnSrc s, long long rows_p
     }
 }
 
-// LayerNorm: one wave per row, row held in registers (c <= 2048), two-pass mean/variance.  F32: the rows are the fp32
+// LayerNorm: one wave per row, row held in registers (c <= 2048), two-pass mean/variance.  (Round 3 tried hoisting gamma / beta
+// out of the row loop and prefetching the next row: 196 -> 228 ms per clip, dropped — the extra registers cost occupancy, and the
+// in-order vmcnt puts the prefetch's wait in front of the store anyway.)  F32: the rows are the fp32
 // residual stream (UNet stream_dtype = float32); the output is always the fp16 MFMA operand of the projection that follows.
 template <int NV, bool F32>
 __global__ __launch_bounds__(256) void layernorm_kernel(const char* __restrict__ x, char* __restrict__ y,
@@ -271,33 +273,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const char* __restrict__
     const int cvec = c >> 3;
     const long long wave_id = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const long long nwaves = (long long)gridDim.x * 4;
-    // gamma / beta of this lane's channels: once per wave, not once per row behind the statistics (round 2 re-loaded them
-    // for every row AFTER the reduction: a second, L2-latency-long round trip on each row's critical path)
-    float gam[NV][8], bet[NV][8];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int v = lane + i * 64;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) { gam[i][j] = v < cvec ? gamma[v * 8 + j] : 0.f; bet[i][j] = v < cvec ? beta[v * 8 + j] : 0.f; }
-    }
-    // raw row of the NEXT iteration is requested before this row's reduction: one row always in flight per wave
-    float4_t rawf[F32 ? NV : 1][2];
-    half8_t rawh[F32 ? 1 : NV];
-    auto fetch = [&](long long row) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int v = lane + i * 64;
-            if (v < cvec) {
-                if (F32) {
-                    rawf[F32 ? i : 0][0] = *(const float4_t*)(x + (row * c + (long long)v * 8) * 4);
-                    rawf[F32 ? i : 0][1] = *(const float4_t*)(x + (row * c + (long long)v * 8) * 4 + 16);
-                } else {
-                    rawh[F32 ? 0 : i] = *(const half8_t*)(x + (row * c + (long long)v * 8) * 2);
-                }
-            }
-        }
-    };
-    if (wave_id < rows) fetch(wave_id);
     for (long long row = wave_id; row < rows; row += nwaves) {
         float xv[NV][8];
         float s = 0.f;
@@ -306,17 +281,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const char* __restrict__
             const int v = lane + i * 64;
             if (v < cvec) {
                 if (F32) {
+                    const float4_t a = *(const float4_t*)(x + (row * c + (long long)v * 8) * 4);
+                    const float4_t b = *(const float4_t*)(x + (row * c + (long long)v * 8) * 4 + 16);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) { xv[i][j] = rawf[F32 ? i : 0][0][j]; xv[i][4 + j] = rawf[F32 ? i : 0][1][j]; }
+                    for (int j = 0; j < 4; ++j) { xv[i][j] = a[j]; xv[i][4 + j] = b[j]; }
                 } else {
+                    const half8_t h = *(const half8_t*)(x + (row * c + (long long)v * 8) * 2);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) xv[i][j] = (float)rawh[F32 ? 0 : i][j];
+                    for (int j = 0; j < 8; ++j) xv[i][j] = (float)h[j];
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) s += xv[i][j];
             }
         }
-        if (row + nwaves < rows) fetch(row + nwaves);
         const float mean = wave_sum(s) / (float)c;
         float q = 0.f;
 #pragma unroll
@@ -334,7 +311,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const char* __restrict__
             if (v < cvec) {
                 half8_t o;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o[j] = (half_t)((xv[i][j] - mean) * rstd * gam[i][j] + bet[i][j]);
+                for (int j = 0; j < 8; ++j) {
+                    const int ch = v * 8 + j;
+                    o[j] = (half_t)((xv[i][j] - mean) * rstd * gamma[ch] + beta[ch]);
+                }
                 *(half8_t*)(y + (row * c + (long long)v * 8) * 2) = o;
             }
         }
