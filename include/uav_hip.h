@@ -328,6 +328,17 @@ int uav_corr_lookup_f32(const float* const* levels, const int64_t* strides, cons
 int uav_convex_upsample_f32(const float* flow, int32_t flow_stride, const float* mask, float* out,
                             int32_t n, int32_t h, int32_t w, void* stream);
 
+/* ---- K13: the CLI's frame I/O conversions on the device ---------------------------------------------
+ * frames (T,C,H,W) in 0..255 (uint8 or fp32, what utils.read_frame_from_videos returns) -> clip (C,T,H,W) fp32 in [-1,1]:
+ * `(vframes/255. - 0.5) * 2` + 'b t c h w -> b c t h w' (inference_upscale_a_video.py:180,186-187); the >= 1280-px area
+ * down-sampling in between (:183-184) is uav_resize_area_f32 on the (C*T) planes */
+int uav_frames_to_clip_f32(const void* frames_tchw, int32_t src_is_u8, float* clip_cthw, int32_t t_len, int32_t c,
+                           int64_t hw, void* stream);
+/* frames (T,C,H,W) fp32 in [-1,1] -> (T,H,W,C) uint8 as the CLI hands them to imageio: `(output/2 + 0.5).clamp(0,1)*255`,
+ * 't c h w -> t h w c', `.astype(np.uint8)` (truncation) (inference_upscale_a_video.py:357-359); C <= 4 */
+int uav_clip_to_frames_u8(const float* frames_tchw, void* frames_thwc_u8, int32_t t_len, int32_t c, int64_t hw,
+                          void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,6 +157,57 @@ extern "C" int uav_resize_area_f32(const float* src, float* dst, int32_t planes,
     return uav_launch_status();
 }
 
+// ---- K13: frame I/O conversions of the CLI, HBM-bound elementwise -----------------------------------
+namespace {
+// (T,C,H,W) frames in 0..255 (uint8, or the fp32 tensor `read_frame_from_videos` returns) -> (C,T,H,W) fp32 in [-1,1]:
+// `(vframes / 255. - 0.5) * 2` then 'b t c h w -> b c t h w' (inference_upscale_a_video.py:180,186-187), same op order.
+template <typename T>
+__global__ __launch_bounds__(256) void frames_to_clip_kernel(const T* __restrict__ src, float* __restrict__ dst, int t_len, int c,
+                                                             long long hw) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= hw) return;
+    const int tc = blockIdx.y, t = tc / c, ch = tc - t * c;
+    const float v = (float)src[(long long)tc * hw + i];
+    dst[((long long)ch * t_len + t) * hw + i] = (v / 255.0f - 0.5f) * 2.0f;
+}
+// (T,C,H,W) fp32 in [-1,1] -> (T,H,W,C) uint8: `(output / 2 + 0.5).clamp(0, 1) * 255`, 't c h w -> t h w c', numpy
+// `.astype(np.uint8)` = truncation (inference_upscale_a_video.py:357-359).  One thread per pixel, C <= 4 channels.
+__global__ __launch_bounds__(256) void clip_to_u8_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, int c,
+                                                         long long hw) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= hw) return;
+    const int t = blockIdx.y;
+    for (int ch = 0; ch < c; ++ch) {
+        float v = src[((long long)t * c + ch) * hw + i] / 2.0f + 0.5f;
+        v = fminf(fmaxf(v, 0.0f), 1.0f) * 255.0f;
+        dst[((long long)t * hw + i) * c + ch] = (unsigned char)(int)v;
+    }
+}
+}  // namespace
+
+extern "C" int uav_frames_to_clip_f32(const void* frames_tchw, int32_t src_is_u8, float* clip_cthw, int32_t t_len, int32_t c,
+                                      int64_t hw, void* stream) {
+    if (!frames_tchw || !clip_cthw) return UAV_EINVAL;
+    if (t_len <= 0 || c <= 0 || hw <= 0 || (int64_t)t_len * c > 65535) return UAV_ESHAPE;
+    const dim3 grid((unsigned)((hw + 255) / 256), (unsigned)(t_len * c));
+    if (src_is_u8)
+        hipLaunchKernelGGL(frames_to_clip_kernel<unsigned char>, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned char*)frames_tchw,
+                           clip_cthw, t_len, c, (long long)hw);
+    else
+        hipLaunchKernelGGL(frames_to_clip_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)frames_tchw, clip_cthw,
+                           t_len, c, (long long)hw);
+    return uav_launch_status();
+}
+
+extern "C" int uav_clip_to_frames_u8(const float* frames_tchw, void* frames_thwc_u8, int32_t t_len, int32_t c, int64_t hw,
+                                     void* stream) {
+    if (!frames_tchw || !frames_thwc_u8) return UAV_EINVAL;
+    if (t_len <= 0 || t_len > 65535 || c <= 0 || c > 4 || hw <= 0) return UAV_ESHAPE;
+    hipLaunchKernelGGL(clip_to_u8_kernel, dim3((unsigned)((hw + 255) / 256), (unsigned)t_len), dim3(256), 0, (hipStream_t)stream,
+                       frames_tchw, (unsigned char*)frames_thwc_u8, c, (long long)hw);
+    return uav_launch_status();
+}
+
 extern "C" int64_t uav_plane_stats_workspace_bytes(int32_t planes) { return (int64_t)planes * CF_CHUNKS * 2 * 8; }
 
 extern "C" int uav_plane_stats_f32(const float* x, int32_t planes, int64_t hw, float* mean_out, float* var_out, void* workspace,

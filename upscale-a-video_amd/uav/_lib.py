@@ -52,6 +52,8 @@ SIGNATURES = {
     "uav_groupnorm_finalize_partials": (C.c_int, [c_p, i64, i32, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p]),
     "uav_groupnorm_workspace_bytes": (i64, [i32, i32]),
     "uav_groupnorm_scale_shift": (C.c_int, [c_p, c_p, i32, i32, i32, i64, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
+    "uav_frames_to_clip_f32": (C.c_int, [c_p, i32, c_p, i32, i32, i64, c_p]),
+    "uav_clip_to_frames_u8": (C.c_int, [c_p, c_p, i32, i32, i64, c_p]),
     "uav_groupnorm_finalize_partials2": (C.c_int, [c_p, i64, i32, i32, i32, c_p, i64, i32, i32, i32, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p]),
     "uav_groupnorm_apply": (C.c_int, [c_p, c_p, i32, i32, i32, i64, i32, i64, c_p, c_p, i32, c_p, c_p, i32, c_p]),
     "uav_layernorm_f16": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, f32, c_p]),

@@ -876,3 +876,28 @@ def resize_area_f32(x, ho, wo, mul=1.0):
     out = torch.empty(tuple(x.shape[:-2]) + (ho, wo), dtype=F32, device=x.device)
     _lib.check(lib.uav_resize_area_f32(_p(x), _p(out), planes, hi, wi, ho, wo, float(mul), _stream()), "uav_resize_area_f32")
     return out
+
+
+# ------------------------------------------------------------------------------------------------
+# frame I/O conversions of the CLI (K13)
+def frames_to_clip_f32(frames):
+    """(T,C,H,W) uint8 / fp32 frames in 0..255 -> (C,T,H,W) fp32 in [-1,1] (`(x/255. - 0.5)*2` + the CLI's rearrange)."""
+    lib = _lib.load()
+    if frames.dtype not in (torch.uint8, torch.float32) or frames.dim() != 4:
+        raise _lib.UavError("frames_to_clip_f32: (T,C,H,W) uint8 or fp32 expected")
+    _req(frames, frames.dtype, "frames")
+    t, c, h, w = frames.shape
+    out = torch.empty((c, t, h, w), dtype=torch.float32, device=frames.device)
+    rc = lib.uav_frames_to_clip_f32(_p(frames), int(frames.dtype == torch.uint8), _p(out), t, c, h * w, _stream())
+    _lib.check(rc, "uav_frames_to_clip_f32")
+    return out
+
+
+def clip_to_frames_u8(frames):
+    """(T,C,H,W) fp32 in [-1,1] -> (T,H,W,C) uint8 (`(x/2 + 0.5).clamp(0,1)*255`, truncated like numpy's astype)."""
+    lib = _lib.load()
+    _req(frames, torch.float32, "frames")
+    t, c, h, w = frames.shape
+    out = torch.empty((t, h, w, c), dtype=torch.uint8, device=frames.device)
+    _lib.check(lib.uav_clip_to_frames_u8(_p(frames), _p(out), t, c, h * w, _stream()), "uav_clip_to_frames_u8")
+    return out
