@@ -386,7 +386,7 @@ def main():
             if name == "conv_gemm" and os.path.exists(tfile) and not (args.propagation or args.shard_windows or args.video_vae or args.frames != 8 or args.height != 320 or args.width != 320 or args.unet_stream == "f16"):
                 from uav import build as _build
                 tj = json.load(open(tfile))
-                if tj.get("kernel_sources_digest") == _build._digest():
+                if tj.get("kernel_sources_digest") == _build.conv_kernel_digest():
                     traffic = tj.get("hbm_bytes_per_launch")
                 else:           # the PMC pass describes another build of the kernels: do not replay it
                     traffic_note = "profiles/pmc_conv_traffic.json was taken with other kernel sources (digest mismatch): not replayed"

@@ -20,7 +20,7 @@ rd = (c["TCC_EA0_RDREQ_sum"] - c.get("TCC_EA0_RDREQ_32B_sum", 0)) * 128 + c.get(
 wr = c.get("TCC_EA0_WRREQ_64B_sum", 0) * 64 + (c["TCC_EA0_WRREQ_sum"] - c.get("TCC_EA0_WRREQ_64B_sum", 0)) * 32
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "upscale-a-video_amd"))
 from uav import build as _build  # noqa: E402
-out = {"kernel_sources_digest": _build._digest(),     # bench.py replays this file only for the library built from these sources
+out = {"kernel_sources_digest": _build.conv_kernel_digest(),     # bench.py replays this file only for the library built from these sources
        "command": "rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum -- "
                   "python bench.py --no-cpu-baseline --no-kernel-events --warmup 0 --steps 1",
        "kernels": "conv_gemm_kernel<*>, conv_gemm256i_kernel<1, *> (all fp16 implicit-GEMM launches)", "launches": launches, "counters": c,

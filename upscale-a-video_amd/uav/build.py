@@ -32,6 +32,17 @@ def _digest():
     return h.hexdigest()
 
 
+def conv_kernel_digest():
+    """Digest of the sources of the dominant kernel only (csrc/conv_gemm.hip + the shared device header): what a PMC traffic
+    pass of the conv kernels stays valid for (bench.py replays profiles/pmc_conv_traffic.json only on a match)."""
+    h = hashlib.sha256()
+    for f in (os.path.join(CSRC, "conv_gemm.hip"), os.path.join(CSRC, "uav_common.h")):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode()); h.update(fh.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
 def is_fresh():
     if not (os.path.exists(LIB) and os.path.exists(STAMP)):
         return False

@@ -301,7 +301,9 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
     PROFILER.end(ev, "conv_gemm" if not PROFILER.detail else
                  f"conv_gemm cin={wt.cin} n={wt.n} k={wt.kt}x{wt.kh}x{wt.kw} M={m}{' geglu' if wt.geglu else ''}{' up' if upsample else ''}{' s2' if stride == 2 else ''}",
                  2.0 * m * wt.n * wt.kt * wt.kh * wt.kw * wt.cin * tfrac,
-                 2.0 * (n_img * hi * wi * wt.cin + m * n_out) + 2.0 * wt.n * wt.kt * wt.kh * wt.kw * wt.cin)
+                 # algorithmic bytes: every operand once — X and W fp16, the result and the residual in their stored type
+                 2.0 * n_img * hi * wi * wt.cin + 2.0 * wt.n * wt.kt * wt.kh * wt.kw * wt.cin + (4.0 if out_f32 else 2.0) * m * n_out
+                 + (0.0 if residual is None else (4.0 if residual.dtype == torch.float32 else 2.0) * m * n_out))
     return out
 
 
