@@ -102,6 +102,11 @@ typedef struct {
      * of images 0 .. a2_images-1 (the skip tensors of the CFG-shared UNet head exist once, unet_blocks.py:563 concatenates
      * them to both batch entries).  0: a2 has n_img images.  stride 1, no upsampling. */
     int32_t      a2_images;
+    /* Source 2 takes part in the CENTRE tap only (a 1x1 conv of a2 summed into a kh x kw conv of a1 in one accumulator: the
+     * shortcut conv of a ResNet block folded into its conv2, resnet.py:286-292 — `conv_shortcut(x) + conv2(h)`): the packed
+     * weights keep the layout k = tap*(c1+c2) + c with ZERO entries for (tap != centre, c >= c1), so every kernel computes
+     * the same sum; the 256x256 kernel skips those k-steps.  Needs stride 1, kt == 1, pad = k/2, no upsampling.  0: off. */
+    int32_t      a2_center_tap;
 } uav_conv_params;
 
 int uav_conv_gemm_f16(const uav_conv_params* p, void* stream);

@@ -523,6 +523,48 @@ def test_groupnorm_two_source_statistics_from_producer_partials(ops, dev, c1, c2
     assert rel_l2(sc1, sc_ref.float()) < 1e-3
 
 
+@pytest.mark.parametrize("c,cs,cout,h,w,hilo,f32", [(128, 192, 128, 24, 20, False, False), (256, 384, 256, 128, 128, True, True),
+                                                     (512, 256, 512, 64, 64, True, False)])
+def test_shortcut_conv_folded_into_conv2(ops, dev, c, cs, cout, h, w, hilo, f32):
+    """uav_conv_params.a2_center_tap: `conv_shortcut(x) + conv2(h)` (resnet.py:286-292) as ONE implicit GEMM — 3x3 over the C
+    channels of h plus the centre tap over the shortcut operand (optionally a [hi | lo] pair with repeated weights) — against
+    the two separate convs, on the 128x128 kernel (small grid: multiplies the structural zeros) and on the 256x256 kernel
+    (skips them), with the GroupNorm statistics riding along."""
+    g = torch.Generator().manual_seed(c + cs)
+    n_img, t_len = 4, 2
+    m = n_img * h * w
+    hh = torch.randn(m, c, generator=g).half().to(dev)
+    x32 = (torch.randn(m, cs, generator=g) * 2.0).to(dev)
+    w2 = h16(cout, c, 3, 3, dev=dev, scale=(9 * c) ** -0.5, gen=g); b2 = torch.randn(cout, generator=g).to(dev)
+    ws = h16(cout, cs, 1, 1, dev=dev, scale=cs ** -0.5, gen=g); bs = torch.randn(cout, generator=g).to(dev)
+    hi = x32.half()
+    raw = torch.cat([hi, (x32 - hi.float()).half()], dim=1).contiguous() if hilo else hi
+    cw = ops.pack_conv_with_shortcut(w2, b2, ws, bs, 2 if hilo else 1, device=dev)
+    kw = dict(n_img=n_img, t_len=t_len, hi=h, wi=w, out_scale=1.0 / 1.2, out_f32=f32, rows_per_batch=t_len * h * w)
+    y = ops.conv_gemm(hh, cw, a2=raw, a2_center=True, gn_groups=32, **kw)
+    ref = (F.conv2d(hh.float().reshape(n_img, h, w, c).permute(0, 3, 1, 2), w2.float(), b2, padding=1)
+           + F.conv2d((raw[:, :cs].float() + (raw[:, cs:].float() if hilo else 0)).reshape(n_img, h, w, cs).permute(0, 3, 1, 2), ws.float(), bs)) / 1.2
+    ref = ref.permute(0, 2, 3, 1).reshape(m, cout)
+    assert y.dtype == (torch.float32 if f32 else torch.float16)
+    assert rel_l2(y, ref) < (2e-4 if f32 else 6e-4), rel_l2(y, ref)
+    if hilo:                                    # the pair carries x to ~22 bits: closer to the fp32 operand than one fp16 rounding
+        exact = (F.conv2d(hh.float().reshape(n_img, h, w, c).permute(0, 3, 1, 2), w2.float(), b2, padding=1)
+                 + F.conv2d(x32.reshape(n_img, h, w, cs).permute(0, 3, 1, 2), ws.float(), bs)) / 1.2
+        assert rel_l2(y, exact.permute(0, 2, 3, 1).reshape(m, cout)) < (2e-4 if f32 else 6e-4)
+    # two separate launches (shortcut as its own conv, result as the residual) give the same numbers
+    res = ops.conv_gemm(raw, ops.pack_conv(torch.cat([ws, ws], dim=1) if hilo else ws, bs, device=dev), n_img=n_img, t_len=t_len, hi=h, wi=w,
+                        out_f32=f32, rows_per_batch=t_len * h * w)
+    y2 = ops.conv_gemm(hh, ops.pack_conv(w2, b2, device=dev), residual=res, **kw)
+    assert rel_l2(y, y2) < (1e-5 if f32 else 1.5e-3)
+    if m * cout // (256 * 256) >= 224:          # big kernel: statistics partials present and consistent
+        gn = getattr(y, "_uav_gn", None)
+        assert gn is not None
+        gamma = torch.ones(cout, device=dev); beta = torch.zeros(cout, device=dev)
+        sc1, sh1 = ops.groupnorm_scale_shift(y, gamma, beta, n_inst=n_img // t_len, rows_per_inst=t_len * h * w, groups=32, eps=1e-6)
+        sc0, sh0 = ops.groupnorm_scale_shift(y.clone(), gamma, beta, n_inst=n_img // t_len, rows_per_inst=t_len * h * w, groups=32, eps=1e-6)
+        assert rel_l2(sc1, sc0) < 1e-3 and rel_l2(sh1, sh0) < 1e-3
+
+
 def test_conv_fused_groupnorm_statistics_not_offered(ops, dev):
     """Launches that cannot produce partials (small grids -> 128x128 kernel, N tails, GEGLU, 48-channel groups) return a
     plain tensor, and GroupNorm falls back to its own statistics pass."""

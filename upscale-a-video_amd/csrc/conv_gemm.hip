@@ -48,6 +48,7 @@ struct ConvArgs {
     float* gn_ws; int gn_groups, gn_cpg_log2; long long gn_chunks;     // fused GroupNorm statistics (see conv_gn_store)
     int omw, omsy, omsx, omoff;                                        // strided output rows (uav_conv_params.out_map_*)
     int a2_pix;                                                        // pixels of source 2 when it is read batch-broadcast (0: off)
+    int a2_ctr;                                                        // source 2 multiplies the centre tap only (uav_conv_params.a2_center_tap)
 };
 
 // Source-2 pixel of GEMM pixel px: the skip tensors of the CFG-shared UNet head exist once and serve both batch entries
@@ -1151,7 +1152,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
     }
     const int tap_lo = dt_lo * p.kh * p.kw;
     const int ntaps = dt_hi * p.kh * p.kw;               // one past the last tap this tile multiplies
-    const int nk = (cin / BK) * (ntaps - tap_lo) + (p.k_pad - p.kt * p.kh * p.kw * cin) / BK;
+    // a2_ctr: the channel blocks of source 2 visit the centre tap only (their other weight entries are zero by contract)
+    const int ctr_tap = (p.pad_t * p.kh + p.pad_h) * p.kw + p.pad_w;
+    const int nk = p.a2_ctr ? (p.c1 / BK) * (ntaps - tap_lo) + p.c2 / BK
+                            : (cin / BK) * (ntaps - tap_lo) + (p.k_pad - p.kt * p.kh * p.kw * cin) / BK;
     // W operand: scalar base of piece ps at K offset kb = wtile + ps*wps + kb, per-lane constant byte offset woff
     const char* wtile = p.w + (long long)n0 * p.k_pad * 2;
     const long long wps = 64ll * p.k_pad * 2;
@@ -1178,10 +1182,15 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
         const int xcoff = (first ? kc : kc - p.c1) + slot_log * 8;                                           \
         XADDR(0, gx0) XADDR(1, gx1) XADDR(2, gx2) XADDR(3, gx3)                                              \
         wkb = ((long long)ktap * cin + kc) * 2;                                                              \
-        if (p.korder) {                          /* tap-innermost K order (see conv_gemm_kernel) */          \
+        if (p.a2_ctr && kc >= p.c1) {            /* source 2: one (centre) tap per channel block */          \
+            kc += BK;                                                                                        \
+        } else if (p.korder) {                   /* tap-innermost K order (see conv_gemm_kernel) */          \
             ++ktap;                                                                                          \
             if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } }                           \
-            if (ktap == ntaps) { ktap = tap_lo; kdt = dt_lo; kdy = 0; kdx = 0; kc += BK; }                   \
+            if (ktap == ntaps) {                                                                             \
+                ktap = tap_lo; kdt = dt_lo; kdy = 0; kdx = 0; kc += BK;                                      \
+                if (p.a2_ctr && kc >= p.c1) { ktap = ctr_tap; kdt = p.pad_t; kdy = p.pad_h; kdx = p.pad_w; } \
+            }                                                                                                \
         } else {                                                                                             \
             kc += BK;                                                                                        \
             if (kc >= cin) { kc = 0; ++ktap; if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } } } \
@@ -1423,6 +1432,15 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         if (q->a2_images < 0 || q->c2 <= 0 || q->n_img != 2 * q->a2_images || q->upsample || q->stride != 1) return UAV_ESHAPE;
         a.a2_pix = q->a2_images * q->hi * q->wi;
     }
+    a.a2_ctr = 0;
+    if (q->a2_center_tap) {
+        // the kernels that do not skip (128x128, ablation builds, channel-innermost order) still compute the same sum: the
+        // off-centre weight entries of source 2 are zero by contract
+        if (q->c2 <= 0 || q->kt != 1 || q->stride != 1 || q->upsample || q->pad_t != 0 || q->pad_h != q->kh / 2 || q->pad_w != q->kw / 2 ||
+            !(q->kh & 1) || !(q->kw & 1) || small)
+            return UAV_ESHAPE;
+        a.a2_ctr = 1;
+    }
     a.omw = 0; a.omsy = 0; a.omsx = 0; a.omoff = 0;
     if (q->out_map_w > 0) {
         if (q->residual || q->gn_partials || (q->flags & UAV_CONV_GEGLU) || q->out_map_sy < 0 || q->out_map_sx <= 0 ||
@@ -1442,6 +1460,7 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     const ConvEnv& env = conv_env();
     a.korder = env.korder;
     a.tile_order = env.tile_order;
+    if (!a.korder) a.a2_ctr = 0;                   // channel-innermost walk (A/B switch): multiply the zeros
     const long long mtiles = (a.M + BM - 1) / BM;
     const long long grid = mtiles * (q->n_pad / BN);
     if (grid >= (1ll << 31)) return UAV_ESHAPE;

@@ -210,6 +210,16 @@ class _ResnetBase(E.EngineModule):
         rb = _temb_rows(self, temb) if (temb is not None and self.time_emb_proj is not None) else None
         h = self.conv1.run(h, g, rowbias=rb, out_f32=s32 and E.BRANCH_F32, gn_groups=self.norm2.num_groups)
         h = E.group_norm(self, "norm2", self.norm2, h, n_inst=g.b, rows_per_inst=g.rows_per_batch, silu=True)
+        osc = 1.0 / self.output_scale_factor
+        if self.conv_shortcut is not None and raw16 is not None and E.FUSE_SHORTCUT and isinstance(self.conv2, InflatedConv3d) \
+                and tuple(self.conv2.stride) == (1, 1) and tuple(self.conv_shortcut.kernel_size) == (1, 1) \
+                and raw16.shape[-1] % 64 == 0:
+            # conv_shortcut([x | x2]) + conv2(h) in ONE implicit GEMM: the raw copy (fp16, or hi | lo halves) is the second
+            # source and multiplies the centre tap only; no fp32 shortcut tensor is written and read back as the residual
+            cw = E.packed_conv_with_shortcut(self, "conv2+shortcut", self.conv2, self.conv_shortcut, 2 if want_raw == "hilo" else 1)
+            return ops.conv_gemm(h, cw, a2=raw16, a2_center=True, n_img=g.n_img, t_len=g.t, hi=g.h, wi=g.w,
+                                 pad=(0, self.conv2.padding[0], self.conv2.padding[1]), out_scale=osc, out_f32=o32,
+                                 rows_per_batch=g.rows_per_batch, gn_groups=self.norm2.num_groups)
         if self.conv_shortcut is not None:
             if raw16 is not None and want_raw == "hilo":      # [x | x2] as hi and lo fp16 halves: K = 2 * C_in, weights repeated
                 res = ops.conv_gemm(raw16, E.packed_conv_hilo(self, "shortcut_hilo", self.conv_shortcut), n_img=g.n_img, t_len=g.t,
@@ -226,8 +236,7 @@ class _ResnetBase(E.EngineModule):
                 raise ops._lib.UavError("fp32 stream requested for an fp16 identity shortcut")
             res = x
         # the block's output is the stream the next block normalises (with this block's group count, as a rule)
-        return self.conv2.run(h, g, residual=res, out_scale=1.0 / self.output_scale_factor, out_f32=o32,
-                              gn_groups=self.norm2.num_groups)
+        return self.conv2.run(h, g, residual=res, out_scale=osc, out_f32=o32, gn_groups=self.norm2.num_groups)
 
     def forward(self, input_tensor, temb=None):
         cin = self.in_channels

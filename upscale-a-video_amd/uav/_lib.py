@@ -32,7 +32,7 @@ class ConvParams(C.Structure):
         ("out_scale", f32), ("flags", u32), ("zero_page", c_p),
         ("gn_partials", c_p), ("gn_groups", i32),
         ("out_map_w", i32), ("out_map_sy", i32), ("out_map_sx", i32), ("out_map_off", i32),
-        ("a2_images", i32),
+        ("a2_images", i32), ("a2_center_tap", i32),
     ]
 
 

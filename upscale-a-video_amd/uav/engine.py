@@ -163,6 +163,14 @@ def packed_conv_hilo(mod: EngineModule, name, conv: nn.Module):
     return mod._cache().get(("conv_hilo", name), build, (conv.weight, conv.bias))
 
 
+def packed_conv_with_shortcut(mod: EngineModule, name, conv: nn.Module, shortcut: nn.Module, repeat_short):
+    """conv2 of a ResNet block with its 1x1 shortcut conv folded in as extra K (ops.pack_conv_with_shortcut)."""
+    def build():
+        dev = _dev(conv.weight)
+        return ops.pack_conv_with_shortcut(conv.weight, conv.bias, shortcut.weight, shortcut.bias, repeat_short, device=dev)
+    return mod._cache().get(("conv+shortcut", name, repeat_short), build, (conv.weight, conv.bias, shortcut.weight, shortcut.bias))
+
+
 def packed_upsample_phases(mod: EngineModule, name, conv: nn.Module):
     """The four 2x2 sub-pixel phase convs of an upsampler's 3x3 conv, packed ([py][px], see ops.upsample_phase_weights)."""
     def build():
@@ -199,9 +207,12 @@ def f16_param(mod: EngineModule, name, tensor):
 
 
 # fp32-stream blocks (VAE decoder always; UNet with stream_dtype = float32): is the ResNet BRANCH tensor between conv1 and
-# norm2 kept in fp32 as well (1), or rounded to fp16 like an MFMA operand (0)?  UAV_BRANCH_F32, default 1.
+# norm2 kept in fp32 as well (1), or rounded to fp16 like an MFMA operand (0)?  UAV_BRANCH_F32.
 import os as _os
-BRANCH_F32 = _os.environ.get("UAV_BRANCH_F32", "1") != "0"
+# Round 3 measurement (GPU, full width): fp16 costs 8.07e-4 -> 8.55e-4 per forward, 7.7e-4 -> 8.1e-4 at the headline shape, 8.6e-4 ->
+# 8.8e-4 after 30 steps, 5.8e-4 -> 6.1e-4 for a decode chunk, and saves 2.2 % of the clip time (one fp32 write + one fp32
+# read of every ResNet's branch tensor): default 0.
+BRANCH_F32 = _os.environ.get("UAV_BRANCH_F32", "0") != "0"
 # ... and is the TOKEN stream inside a Transformer3DModel (proj_in output, the four residual adds of the block) fp32 (1) or
 # fp16 (0: only the block stream around the transformer is fp32)?  UAV_TOKEN_F32, default 1.
 TOKEN_F32 = _os.environ.get("UAV_TOKEN_F32", "1") != "0"
@@ -209,6 +220,9 @@ TOKEN_F32 = _os.environ.get("UAV_TOKEN_F32", "1") != "0"
 # doubled: the stream is not rounded to fp16 on its way through the block, 1.01e-3 -> 0.81e-3 per forward for ~2 % of the
 # clip time) or as one (0)?  UAV_SHORTCUT_HILO, default 1.
 SHORTCUT_HILO = _os.environ.get("UAV_SHORTCUT_HILO", "1") != "0"
+# ... and is that shortcut conv folded into the block's conv2 (one implicit GEMM over K = 9*C + C_in: no separate launch, no fp32
+# shortcut tensor written and read back as the residual) (1) or a launch of its own (0)?  UAV_FUSE_SHORTCUT, default 1.
+FUSE_SHORTCUT = _os.environ.get("UAV_FUSE_SHORTCUT", "1") != "0"
 
 
 # Group count a conv assumes for the GroupNorm that (probably) consumes its output when the caller cannot name that

@@ -120,6 +120,7 @@ class ConvW:
     kh: int
     kw: int
     geglu: bool = False
+    k_logical: int = 0          # multiply-adds per output element when the packed K axis carries structural zeros (0: kt*kh*kw*cin)
 
     @property
     def n_out(self):
@@ -182,6 +183,29 @@ def pack_conv(weight, bias=None, geglu=False, device=None, n_store_align=4):
     return ConvW(wp.to(dev), None if bp is None else bp.to(dev), n, n_pad, k_pad, i, cin_p, kt, kh, kw, geglu)
 
 
+def pack_conv_with_shortcut(w_main, b_main, w_short, b_short, repeat_short=1, device=None):
+    """`conv_shortcut(x) + conv2(h)` of a ResNet block (reference resnet.py:286-292) as ONE implicit GEMM: K = taps x (C + Cs),
+    the 1x1 shortcut weights sit at the centre tap of the Cs extra input channels and every other entry of those channels is
+    zero (uav_conv_params.a2_center_tap: the 256x256 kernel skips the zero k-steps).  repeat_short = 2: the shortcut operand
+    arrives as [hi | lo] fp16 halves, its weights are repeated.  Bias = b_main + b_short (fp32)."""
+    w2 = w_main.detach().float()
+    ws = w_short.detach().float()
+    if w2.dim() != 4 or ws.dim() not in (4, 5) or any(k != 1 for k in ws.shape[2:]) or not (w2.shape[2] & 1 and w2.shape[3] & 1):
+        raise _lib.UavError("pack_conv_with_shortcut: (O,C,kh,kw) odd-sized main conv + 1x1 shortcut expected")
+    o, c, kh, kw = w2.shape
+    ws = ws.reshape(o, -1)
+    cs = ws.shape[1] * repeat_short
+    full = torch.zeros((o, c + cs, kh, kw), dtype=torch.float32, device=w2.device)
+    full[:, :c] = w2
+    full[:, c:, kh // 2, kw // 2] = torch.cat([ws] * repeat_short, dim=1)
+    b = None
+    if b_main is not None or b_short is not None:
+        b = (0 if b_main is None else b_main.detach().float()) + (0 if b_short is None else b_short.detach().float())
+    cw = pack_conv(full, b, device=device if device is not None else w_main.device)
+    cw.k_logical = kh * kw * c + ws.shape[1]
+    return cw
+
+
 def upsample_phase_weights(weight):
     """Sub-pixel form of "nearest 2x upsampling, then 3x3 conv with padding 1" (reference resnet.py:144-158): output pixel
     (2y + py, 2x + px) only ever sees the 2x2 input pixels (y - 1 + py .., x - 1 + px ..), because two of the three taps
@@ -203,7 +227,7 @@ def upsample_phase_weights(weight):
 
 def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None,
               rowbias=None, rows_per_batch=0, residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None,
-              persistent=False, act=None, gn_groups=None, out_map=None):
+              persistent=False, act=None, gn_groups=None, out_map=None, a2_center=False):
     """out[M][n_out] = scale*(conv(a1|a2, W) + bias + rowbias[m//rows_per_batch] + residual).
 
     gn_groups: the output feeds a GroupNorm of that many groups — when the launch qualifies
@@ -271,6 +295,10 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
     p.n = wt.n; p.n_pad = wt.n_pad; p.k_pad = wt.k_pad
     p.out_scale = out_scale; p.flags = flags; p.zero_page = _p(zero_page(a1.device))
     p.a2_images = a2_images
+    if a2_center:                    # a2 takes part in the centre tap only (shortcut conv folded into conv2, pack_conv_with_shortcut)
+        if a2 is None:
+            raise _lib.UavError("a2_center needs a second source")
+        p.a2_center_tap = 1
     if out_map is not None:
         p.out_map_w, p.out_map_sy, p.out_map_sx, p.out_map_off = (int(v) for v in out_map)
         if (m // out_map[0] - 1) * out_map[1] + (out_map[0] - 1) * out_map[2] + out_map[3] >= out.shape[0]:
@@ -295,6 +323,8 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
     # that fall outside the clip (zero padding of a (k,1,1) / 3x3x3 conv at the clip ends, which the kernel skips) are
     # not counted either
     tfrac = 1.0
+    if wt.k_logical:
+        tfrac = wt.k_logical / float(wt.kt * wt.kh * wt.kw * wt.cin)
     if ev is not None and wt.kt > 1:
         valid = sum(1 for t_ in range(t_len) for dt in range(wt.kt) if 0 <= t_ + dt - pt < t_len)
         tfrac = valid / float(wt.kt * t_len)
