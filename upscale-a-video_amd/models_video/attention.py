@@ -253,7 +253,8 @@ class Transformer3DModel(ModelMixin, ConfigMixin, E.EngineModule):
         res = x
         n = E.group_norm(self, "norm", self.norm, x, n_inst=g.n_img, rows_per_inst=g.hw, silu=False)   # per frame
         s32 = res.dtype == torch.float32         # fp32 residual stream: the token stream is one too (LayerNorm inputs)
-        tok = ops.linear(n, E.packed_conv(self, "proj_in", self.proj_in), out_f32=s32 and E.TOKEN_F32)
+        tok32 = s32 and E.TOKEN_F32 and (E.TOKEN_F32_MAX_HW <= 0 or g.hw <= E.TOKEN_F32_MAX_HW)
+        tok = ops.linear(n, E.packed_conv(self, "proj_in", self.proj_in), out_f32=tok32)
         last = len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):
             tok = blk.run(tok, g, ehs_rows, n_text, out_f32=False if i == last else None)   # proj_out reads it as an operand

@@ -216,6 +216,9 @@ BRANCH_F32 = _os.environ.get("UAV_BRANCH_F32", "0") != "0"
 # ... and is the TOKEN stream inside a Transformer3DModel (proj_in output, the four residual adds of the block) fp32 (1) or
 # fp16 (0: only the block stream around the transformer is fp32)?  UAV_TOKEN_F32, default 1.
 TOKEN_F32 = _os.environ.get("UAV_TOKEN_F32", "1") != "0"
+# ... only in the transformers with at most this many tokens per frame (0 = everywhere): the token stream of the
+# highest-resolution transformers carries 3/4 of the token traffic.  UAV_TOKEN_F32_MAX_HW.
+TOKEN_F32_MAX_HW = int(_os.environ.get("UAV_TOKEN_F32_MAX_HW", "0"))
 # ... and does the 1x1 shortcut conv of a block with C_in != C_out read the fp32 stream as TWO fp16 operands (hi + lo, K
 # doubled: the stream is not rounded to fp16 on its way through the block, 1.01e-3 -> 0.81e-3 per forward for ~2 % of the
 # clip time) or as one (0)?  UAV_SHORTCUT_HILO, default 1.
