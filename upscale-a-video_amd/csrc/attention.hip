@@ -208,6 +208,148 @@ __global__ __launch_bounds__(256, (D <= 128 ? 2 : 1)) void attn_kernel(AttnArgs 
 
 
 // ---------------------------------------------------------------------------------------------
+// Short key sets (text cross-attention: Lk = 77 -> 3 tiles).  attn_kernel walks its tiles with one L2 round trip per tile
+// (issue tile t+1, compute tile t — which takes a fraction of a round trip —, wait, barrier): with 3 tiles a workgroup spends
+// ~5.5 us for 32 KiB of Q / O traffic and the kernel sits at 3.0 TB/s.  Here EVERY K tile (LDS-DMA) and V tile (registers ->
+// V^T images) is requested before anything is waited for: one round trip, one barrier, then the 3 tiles back to back.
+// Same arithmetic, same order: bit-identical to attn_kernel.
+constexpr int NTS = 3;
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_short_kernel(AttnArgs p) {
+    using C = AttnCfg<D>;
+    static_assert(C::VUNITS == 1, "short-key kernel: head dims up to 256");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ks = smem;                                // [NTS][KV][D] halves, swizzled
+    char* Vt = smem + NTS * C::KS_BYTES;            // [NTS][D][36] halves
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int bk = b / p.q_per_kv;
+    const char* kbase = p.k + ((long long)bk * p.lk * p.k_stride + (long long)h * D) * 2;
+    const char* vbase = p.v + ((long long)bk * p.lk * p.v_stride + (long long)h * D) * 2;
+    const int nt = (p.lk + KV - 1) / KV;            // <= NTS (host)
+
+    const int qrow = q0 + l32;
+    const int qr = qrow < p.lq ? qrow : p.lq - 1;
+    const char* qptr = p.q + (((long long)b * p.lq + qr) * p.q_stride + (long long)h * D) * 2;
+    half8_t qf[D / 16];
+#pragma unroll
+    for (int s = 0; s < D / 16; ++s) qf[s] = *(const half8_t*)(qptr + (16 * s + 8 * hi) * 2);
+
+    // ---- all K tiles by DMA, all V tiles into registers: nothing is waited for in between -----
+#pragma unroll
+    for (int t = 0; t < NTS; ++t) {
+        if (t < nt) {
+            char* dst = Ks + t * C::KS_BYTES;
+#pragma unroll
+            for (int ps = 0; ps < C::KPIECES; ++ps) {
+                const int pi = ps * 256 + tid;
+                const int row = pi / C::SLOTS, sp = pi % C::SLOTS;
+                const int sl = sp ^ kswz<D>(row);
+                const int key = t * KV + row;
+                const char* g = key < p.lk ? kbase + ((long long)key * p.k_stride + sl * 8) * 2 : p.zero_page;
+                __builtin_amdgcn_global_load_lds((gptr_t)g, (lptr_t)(dst + (ps * 256 + wave * 64) * 16), 16, 0, 0);
+            }
+        }
+    }
+    half8_t vst[NTS][4];
+    const bool vrole = tid < D;
+    const int kg = tid & 7, dv = tid >> 3;
+#pragma unroll
+    for (int t = 0; t < NTS; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int key = t * KV + kg * 4 + i;
+            half8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+            vst[t][i] = (vrole && t < nt && key < p.lk) ? *(const half8_t*)(vbase + ((long long)key * p.v_stride + dv * 8) * 2) : z;
+        }
+#pragma unroll
+    for (int t = 0; t < NTS; ++t) {
+        if (vrole && t < nt) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                half4_t w = {vst[t][0][e], vst[t][1][e], vst[t][2][e], vst[t][3][e]};
+                *(half4_t*)(Vt + t * C::VT_BYTES + (dv * 8 + e) * VT_STRIDE + kg * 8) = w;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    float16_t oacc[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+    for (int t = 0; t < nt; ++t) {
+        const char* kst = Ks + t * C::KS_BYTES + l32 * (2 * D);
+        const int ksw = kswz<D>(l32);
+        float16_t sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < D / 16; ++s) {
+            half8_t kf = *(const half8_t*)(kst + (((2 * s + hi) ^ ksw) << 4));
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc, 0, 0, 0);
+        }
+        const int key0 = t * KV + 4 * hi;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = key0 + (r & 3) + 8 * (r >> 2);
+            float s = sacc[r] * p.scale_log2;
+            s = key < p.lk ? s : -INFINITY;
+            sacc[r] = s; mx = fmaxf(mx, s);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float ps = 0.f;
+        half8_t pf[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(sacc[r] - m_new);
+            ps += e;
+            pf[r >> 3][r & 7] = (half_t)e;
+        }
+        l_run = l_run * alpha + ps;
+        m_run = m_new;
+        if (!__all(alpha == 1.0f)) {
+#pragma unroll
+            for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        }
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i) {
+            const char* vrow = Vt + t * C::VT_BYTES + (i * 32 + l32) * VT_STRIDE + hi * 8;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                half4_t a = *(const half4_t*)(vrow + s2 * 32);
+                half4_t c = *(const half4_t*)(vrow + s2 * 32 + 16);
+                half8_t vf = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+                oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s2], oacc[i], 0, 0, 0);
+            }
+        }
+    }
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qrow < p.lq) {
+        char* optr = p.o + (((long long)b * p.lq + qrow) * p.o_stride + (long long)h * D) * 2;
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                half4_t o = {(half_t)(oacc[i][4 * g] * inv), (half_t)(oacc[i][4 * g + 1] * inv),
+                             (half_t)(oacc[i][4 * g + 2] * inv), (half_t)(oacc[i][4 * g + 3] * inv)};
+                *(half4_t*)(optr + (i * 32 + 8 * g + 4 * hi) * 2) = o;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // head_dim = 512 (VAE mid-block attention, one head, L = H*W up to 102400; 57 % of the VAE FLOPs).
 // The generic kernel above would need 256 (O^T) + 128 (Q) accumulator/operand registers per lane
 // and spills.  Here a PAIR of waves shares 32 queries and splits d in halves of 256:
@@ -627,6 +769,17 @@ int launch_attn512(const AttnArgs& a, hipStream_t s) {
 template <int D>
 int launch_attn(const AttnArgs& a, hipStream_t s) {
     using C = AttnCfg<D>;
+    if constexpr (D <= 256) {
+        static const int short_on = [] { const char* e = getenv("UAV_ATTN_SHORT"); return e ? atoi(e) : 1; }();   // 0: A/B
+        if (short_on && a.lk <= NTS * KV && !a.causal) {
+            constexpr int smem = NTS * (C::KS_BYTES + C::VT_BYTES);
+            static UavDynLds lds_s;
+            if (smem > 65536)
+                if (int rc = uav_set_dyn_lds(lds_s, (const void*)attn_short_kernel<D>, smem)) return rc;
+            hipLaunchKernelGGL(attn_short_kernel<D>, dim3((a.lq + 127) / 128, a.heads, a.bq), dim3(256), smem, s, a);
+            return uav_launch_status();
+        }
+    }
     static UavDynLds lds;
     if (C::SMEM > 65536)
         if (int rc = uav_set_dyn_lds(lds, (const void*)attn_kernel<D>, C::SMEM)) return rc;
