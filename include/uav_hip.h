@@ -107,9 +107,26 @@ typedef struct {
      * weights keep the layout k = tap*(c1+c2) + c with ZERO entries for (tap != centre, c >= c1), so every kernel computes
      * the same sum; the 256x256 kernel skips those k-steps.  Needs stride 1, kt == 1, pad = k/2, no upsampling.  0: off. */
     int32_t      a2_center_tap;
+    /* LayerNorm folded into the consuming projection (attention.py:523-564: `attn(norm(x))`, `ff(norm3(x))` — LayerNorm, then
+     * a Linear): LN(x).W^T + b = rstd_m * (x . (W o gamma)^T - mu_m * colsum(W o gamma)) + (W.beta + b).
+     *   PRODUCER of x (a linear with an fp32 result): ln_raw_out != NULL -> also writes fp16(x) rows [M][n] (the consumer's MFMA
+     *     operand) and, per row and 128-column chunk c, (sum, sum of squares) of the fp32 values: ln_stat_out[(c*M + m)*2 + {0,1}],
+     *     n/128 chunks.
+     *   CONSUMER (1x1, fp16 result, no residual / time embedding; GEGLU allowed): ln_stat_in != NULL -> a1 = fp16(x) rows, w = the
+     *     packed fp16(W o gamma), bias = W.beta + b (fp32), ln_colsum[n_pad] = row sums of the packed weights (fp32), ln_chunks /
+     *     ln_n / ln_eps = chunk count, LayerNorm width (= c1) and epsilon.
+     * Only launches for which uav_conv_gemm_ln_ok() returns 1 (256x256 kernel, full wave tiles); else UAV_ESHAPE.  NULL: off. */
+    void*        ln_raw_out;
+    float*       ln_stat_out;
+    const float* ln_stat_in;
+    const float* ln_colsum;
+    int32_t      ln_chunks, ln_n;
+    float        ln_eps;
 } uav_conv_params;
 
 int uav_conv_gemm_f16(const uav_conv_params* p, void* stream);
+/* 1 if uav_conv_gemm_f16(p) can honour p's LayerNorm-fold fields (ln_raw_out / ln_stat_in), else 0.  Host-only. */
+int uav_conv_gemm_ln_ok(const uav_conv_params* p);
 /* Rows per statistics chunk (64) if uav_conv_gemm_f16(p) can produce GroupNorm partials for p->gn_groups, else 0 (small
  * launches, N tails, GEGLU / activation epilogues, groups of other than 4..128 channels): decide BEFORE setting
  * gn_partials — a launch that cannot honour the request returns UAV_ESHAPE.  Host-only, no device work. */

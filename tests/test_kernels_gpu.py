@@ -629,3 +629,51 @@ def test_second_source_batch_broadcast(ops, dev, h, w, k3):
     cw = ops.pack_conv(wt, torch.randn(cout, generator=g), device=dev)
     ckw = dict(n_img=bsz * t_len, t_len=t_len, hi=h, wi=w)
     assert torch.equal(ops.conv_gemm(x, cw, a2=skip1, **ckw), ops.conv_gemm(x, cw, a2=skip2, **ckw))
+
+
+# ------------------------------------------------------------------------------------------------
+# LayerNorm folded into the consuming projection (uav_conv_params.ln_*)
+@pytest.mark.parametrize("k,n,geglu,res", [(512, 512, False, True), (512, 1536, False, False), (512, 4096, True, True), (1024, 1024, False, True)])
+def test_layernorm_folded_into_projection(ops, dev, k, n, geglu, res):
+    """A linear with an fp32 result (ln_produce) writes the fp16 operand copy + per-row statistics; the consuming projection
+    (ln_consume, optionally GEGLU) applies rstd * (x16 . (W o gamma)^T - mu * colsum) + (W.beta + b) in its epilogue.  Against
+    fp32 LayerNorm -> Linear (-> GEGLU) on the same rows, and against the unfused engine path (layernorm kernel + linear)."""
+    import torch.nn as nn
+    from uav import engine as E
+    g = torch.Generator().manual_seed(k + n)
+    m = 128 * 512                                   # 256 m-tiles x >= 2 n-tiles: the 256x256 kernel
+    x0 = torch.randn(m, k, generator=g).half().to(dev)
+    wp = ops.pack_conv(h16(k, k, dev=dev, scale=k ** -0.5, gen=g), torch.randn(k, generator=g) * 0.1, device=dev)
+    rr = (torch.randn(m, k, generator=g) * 1.5 + 0.3).to(dev) if res else None
+    x = ops.linear(x0, wp, residual=rr, out_f32=True, ln_produce=True)          # the stream rows (fp32) + their LnOperand
+    op = ops.ln_operand_of(x)
+    assert op is not None and op.raw.shape == (m, k) and op.stat.shape == (k // 128, m, 2)
+    assert torch.equal(op.raw, x.half())
+    xc = x.double().reshape(m, k // 128, 128)
+    assert rel_l2(op.stat[:, :, 0].t(), xc.sum(-1).float()) < 1e-5 and rel_l2(op.stat[:, :, 1].t(), (xc * xc).sum(-1).float()) < 1e-5
+    assert torch.equal(x, ops.linear(x0, wp, residual=rr, out_f32=True))        # the fp32 rows themselves are unchanged
+
+    class M(E.EngineModule):
+        pass
+    mod = M()
+    ln = nn.LayerNorm(k).to(dev)
+    lin = nn.Linear(k, n).to(dev)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.2 * torch.randn(k, generator=g)); ln.bias.copy_(0.1 * torch.randn(k, generator=g))
+        lin.weight.copy_(h16(n, k, dev=dev, scale=k ** -0.5, gen=g).float()); lin.bias.copy_(0.1 * torch.randn(n, generator=g))
+    y = E.ln_linear(mod, "t", ln, x, [lin], geglu=geglu)
+    with torch.no_grad():
+        ref = torch.nn.functional.linear(torch.nn.functional.layer_norm(x, (k,), ln.weight, ln.bias, ln.eps), lin.weight, lin.bias)
+        if geglu:
+            a, b = ref.chunk(2, dim=-1)
+            ref = a * torch.nn.functional.gelu(b)
+    assert y.dtype == torch.float16 and y.shape == ref.shape
+    e_fold = rel_l2(y, ref)
+    old = E.LN_FOLD
+    E.LN_FOLD = False
+    try:
+        y0 = E.ln_linear(mod, "t", ln, x, [lin], geglu=geglu)
+    finally:
+        E.LN_FOLD = old
+    e_plain = rel_l2(y0, ref)
+    assert e_fold < 1.5e-3 and e_fold < 2.0 * e_plain + 1e-4, (e_fold, e_plain)

@@ -49,6 +49,11 @@ struct ConvArgs {
     int omw, omsy, omsx, omoff;                                        // strided output rows (uav_conv_params.out_map_*)
     int a2_pix;                                                        // pixels of source 2 when it is read batch-broadcast (0: off)
     int a2_ctr;                                                        // source 2 multiplies the centre tap only (uav_conv_params.a2_center_tap)
+    // LayerNorm folded into the consuming projection (uav_conv_params.ln_*): a PRODUCER also writes the fp16 rounding of its
+    // fp32 result rows and, per row and 128-column chunk, (sum, sum of squares); a CONSUMER turns acc = x16 . (W o gamma) into
+    // rstd_m * (acc - mu_m * colsum_n) + bias'_n with the row statistics of its operand.
+    char* lnp_raw; float* lnp_stat;                                    // producer outputs (nullptr: off)
+    const float* lnc_stat; const float* lnc_colsum; int lnc_chunks, lnc_n; float lnc_eps;   // consumer inputs (lnc_stat nullptr: off)
 };
 
 // Source-2 pixel of GEMM pixel px: the skip tensors of the CFG-shared UNet head exist once and serve both batch entries
@@ -209,10 +214,32 @@ UAV_DEVINL float4_t lds_f4(unsigned byte_addr) { return *(lds_f4ptr_t)(size_t)by
 // RF32: the residual is an fp32 row (fp32 residual stream, fp16 result: a block output that is only read as an MFMA operand);
 // it is loaded in the accumulators' own layout (one float4 per register quad), no half-wave exchange.
 // lb / lr: LDS byte addresses of the staged bias / time-embedding row at this wave's first column (ST only).
-template <int NI, int MI, bool RES, bool BIAS, bool RB, int GNM, bool RF32 = false, bool ST = false>
+// Row statistics of a LayerNorm-folded consumer: mean and 1/std of the operand rows this lane owns, from the producer's
+// per-chunk (sum, sum of squares) partials [chunk][row][2].
+template <int MI>
+UAV_DEVINL void ln_row_stats(const ConvArgs& p, long long mw0, int l32, float (&mu)[MI], float (&rstd)[MI]) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+        const long long m = mw0 + mi * 32 + l32;
+        float s1 = 0.f, s2 = 0.f;
+        for (int c = 0; c < p.lnc_chunks; ++c) {
+            const float2_t v = *(const float2_t*)(p.lnc_stat + ((long long)c * p.M + m) * 2);
+            s1 += v[0]; s2 += v[1];
+        }
+        const float inv_n = 1.0f / (float)p.lnc_n;
+        const float mean = s1 * inv_n;
+        float var = s2 * inv_n - mean * mean; var = var > 0.f ? var : 0.f;
+        mu[mi] = mean; rstd[mi] = rsqrtf(var + p.lnc_eps);
+    }
+}
+
+// LNC: LayerNorm folded in (staged kernels only): lr holds colsum(W') instead of a time-embedding row, bias = W.beta + b.
+template <int NI, int MI, bool RES, bool BIAS, bool RB, int GNM, bool RF32 = false, bool ST = false, bool LNC = false>
 UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32,
                                    const float* rbrow, unsigned lb = 0, unsigned lr = 0) {
     constexpr bool GN = GNM != 0;
+    float lmu[MI], lrs[MI];
+    if (LNC) ln_row_stats<MI>(p, mw0, l32, lmu, lrs);
     constexpr int NG = GnAcc<GNM>::NG;
     constexpr bool R16 = RES && !RF32, R32 = RES && RF32;
     constexpr int D = R16 ? (GN ? 2 : NI) : 1;            // residual prefetch distance in column tiles
@@ -264,7 +291,7 @@ UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], 
         for (int g = 0; g < 4; ++g) {
             const int co = ni * 32 + 8 * g;
             if (BIAS) bq[g] = ST ? lds_f4(lb + (co + 4 * hi32) * 4) : *(const float4_t*)(bptr + co);
-            if (RB) rq[g] = ST ? lds_f4(lr + (co + 4 * hi32) * 4) : *(const float4_t*)(rptr + co);
+            if (RB || LNC) rq[g] = ST ? lds_f4(lr + (co + 4 * hi32) * 4) : *(const float4_t*)(rptr + co);
         }
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
@@ -283,6 +310,10 @@ UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], 
                     float v[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] = acc[ni][mi][4 * g + j];
+                    if (LNC) {                  // rstd * (acc - mu * colsum), then + (W.beta + b) below
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = lrs[mi] * (v[j] - lmu[mi] * rq[g][j]);
+                    }
                     if (BIAS) {
 #pragma unroll
                         for (int j = 0; j < 4; ++j) v[j] += bq[g][j];
@@ -324,10 +355,15 @@ UAV_DEVINL void conv_epilogue_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], 
 // Same arithmetic order as the fp16 paths: ((acc + bias) + rowbias) + residual, then * out_scale.
 // RB: one time-embedding row for the whole wave tile (conv1 of a ResNet block whose branch tensor stays fp32).
 // The residual of column tile ni + 1 is requested before tile ni's stores (see the note on vmcnt order above).
-template <int NI, int MI, bool RES, int GNM, bool RB = false, bool ST = false>
+// LNP: LayerNorm-fold producer: the fp16 rounding of every result row (the consumer's MFMA operand) and the row's (sum, sum of
+// squares) over this wave's 128 columns go out beside the fp32 rows.
+template <int NI, int MI, bool RES, int GNM, bool RB = false, bool ST = false, bool LNP = false>
 UAV_DEVINL void conv_epilogue_f32_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32,
                                        const float* rbrow = nullptr, unsigned lb = 0, unsigned lr = 0) {
     const float osc = p.out_scale;
+    float ls1[MI], ls2[MI];
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) { ls1[mi] = 0.f; ls2[mi] = 0.f; }
     constexpr bool GN = GNM != 0;
     constexpr int NG = GnAcc<GNM>::NG;
     float gst[GN ? NI : 1][NG], gsq[GN ? NI : 1][NG];
@@ -376,6 +412,13 @@ UAV_DEVINL void conv_epilogue_f32_fast(const ConvArgs& p, float16_t (&acc)[NI][M
                     o[j] = v * osc;
                 }
                 *(float4_t*)(orow[mi] + ni * 32 + 8 * g) = o;
+                if (LNP) {
+                    ls1[mi] += (o[0] + o[1]) + (o[2] + o[3]);
+                    ls2[mi] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+                    const long long m = mw0 + mi * 32 + l32;
+                    half4_t h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
+                    *(half4_t*)(p.lnp_raw + (m * p.out_stride + nw0 + ni * 32 + 8 * g + 4 * hi32) * 2) = h;
+                }
                 if (GN) {
                     constexpr int sh = GNM == 1 ? 0 : GNM == 2 ? 1 : 2;
                     gst[GN ? ni : 0][g >> sh] += (o[0] + o[1]) + (o[2] + o[3]);
@@ -384,23 +427,40 @@ UAV_DEVINL void conv_epilogue_f32_fast(const ConvArgs& p, float16_t (&acc)[NI][M
             }
         }
     }
+    if (LNP) {                                   // the two half-waves hold the two halves of each row's channel quads
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const float a = both_halves(ls1[mi]), b = both_halves(ls2[mi]);
+            if (hi32 == 0) {
+                const long long m = mw0 + mi * 32 + l32;
+                float2_t st = {a, b};
+                *(float2_t*)(p.lnp_stat + ((long long)(nw0 >> 7) * p.M + m) * 2) = st;
+            }
+        }
+    }
     if constexpr (GN) conv_gn_store<NI, MI, GNM>(p, gst, gsq, mw0, nw0, l32, hi32);
 }
 
 // GEGLU fast path (same preconditions; no residual / rowbias by contract): value/gate tile pairs (2b, 2b+1).
-template <int NI, int MI, bool BIAS, bool ST = false>
+template <int NI, int MI, bool BIAS, bool ST = false, bool LNC = false>
 UAV_DEVINL void conv_epilogue_geglu_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32,
-                                         unsigned lb = 0) {
+                                         unsigned lb = 0, unsigned lr = 0) {
     const float osc = p.out_scale;
+    float lmu[MI], lrs[MI];
+    if (LNC) ln_row_stats<MI>(p, mw0, l32, lmu, lrs);
 #pragma unroll
     for (int blk = 0; blk < NI / 2; ++blk) {
         const int nb = nw0 + blk * 64;
-        float4_t bv[4], bg[4];
+        float4_t bv[4], bg[4], cv[4], cg[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             if (BIAS) {
                 bv[g] = ST ? lds_f4(lb + (blk * 64 + 8 * g + 4 * hi32) * 4) : *(const float4_t*)(p.bias + nb + 8 * g + 4 * hi32);
                 bg[g] = ST ? lds_f4(lb + (blk * 64 + 32 + 8 * g + 4 * hi32) * 4) : *(const float4_t*)(p.bias + nb + 32 + 8 * g + 4 * hi32);
+            }
+            if (LNC) {
+                cv[g] = lds_f4(lr + (blk * 64 + 8 * g + 4 * hi32) * 4);
+                cg[g] = lds_f4(lr + (blk * 64 + 32 + 8 * g + 4 * hi32) * 4);
             }
         }
 #pragma unroll
@@ -417,6 +477,7 @@ UAV_DEVINL void conv_epilogue_geglu_fast(const ConvArgs& p, float16_t (&acc)[NI]
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         float hv = acc[2 * blk][mi][4 * g + j], gv = acc[2 * blk + 1][mi][4 * g + j];
+                        if (LNC) { hv = lrs[mi] * (hv - lmu[mi] * cv[g][j]); gv = lrs[mi] * (gv - lmu[mi] * cg[g][j]); }
                         if (BIAS) { hv += bv[g][j]; gv += bg[g][j]; }
                         o[j] = hv * uav_gelu_erf(gv) * osc;
                     }
@@ -436,9 +497,24 @@ UAV_DEVINL void conv_epilogue_geglu_fast(const ConvArgs& p, float16_t (&acc)[NI]
 // is instantiated there: the statistics variants stay out of the plain kernels, whose register allocation (no scratch) is
 // the one measured in DESIGN.md.
 // ST: bias / time-embedding row of the tile are staged in LDS at lb / lr (byte addresses at this wave's first column).
-template <int NI, int MI, int GNK = 0, bool ST = false>
+// LNF: the LayerNorm-fold instances of the kernel (1: producer, 2: consumer) — like the statistics instances they are kernels
+// of their own so that their registers do not weigh on the plain kernel's allocation; the host launches them only when every
+// wave tile qualifies (conv_ln_ok).
+template <int NI, int MI, int GNK = 0, bool ST = false, int LNF = 0>
 UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32,
                               unsigned lb = 0, unsigned lr = 0) {
+    if constexpr (LNF == 1) {
+        if (mw0 >= p.M || nw0 >= p.n) return;
+        if (p.residual) conv_epilogue_f32_fast<NI, MI, true, 0, false, ST, true>(p, acc, mw0, nw0, l32, hi32, nullptr, lb, lr);
+        else conv_epilogue_f32_fast<NI, MI, false, 0, false, ST, true>(p, acc, mw0, nw0, l32, hi32, nullptr, lb, lr);
+        return;
+    }
+    if constexpr (LNF == 2) {
+        if (mw0 >= p.M || nw0 >= p.n) return;
+        if (p.flags & UAV_CONV_GEGLU) conv_epilogue_geglu_fast<NI, MI, true, ST, true>(p, acc, mw0, nw0, l32, hi32, lb, lr);
+        else conv_epilogue_fast<NI, MI, false, true, false, 0, false, ST, true>(p, acc, mw0, nw0, l32, hi32, nullptr, lb, lr);
+        return;
+    }
     if constexpr (GNK != 0) {
         if (mw0 >= p.M || nw0 >= p.n) return;                   // wave tile outside the output: nothing to store or count
         const float* rbrow = p.rowbias ? p.rowbias + (long long)((int)(mw0 / p.rows_per_batch)) * p.rowbias_stride : nullptr;
@@ -1098,7 +1174,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
 //     path works while the matrix pipe does, and M0 (LDS destination) is written by s_add right before each.
 // Stage hand-over is unchanged (2 stages, vmcnt(0) + barrier per k-step), so the numerics and the tile walk are
 // bit-identical to the round-1 kernel (tests/test_fullsize_gpu.py compares them).
-template <int V, int GNK = 0>
+template <int V, int GNK = 0, int LNF = 0>
 __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -1223,6 +1299,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
     unsigned stg_dst = 0;                                // 0 = this thread stages nothing
     if (tid < 64) {
         if (p.bias) { stg = *(const float4_t*)(p.bias + n0 + 4 * tid); stg_dst = ldsepi + tid * 16; }
+    } else if (LNF == 2 && tid < 128) {              // LayerNorm-fold consumer: colsum(W') of the tile's columns takes row block 0
+        const int piece = tid - 64;
+        stg = *(const float4_t*)(p.lnc_colsum + n0 + 4 * piece);
+        stg_dst = ldsepi + 1024 + piece * 16;
     } else if (tid < 320 && p.rowbias) {
         const int blk = (tid - 64) >> 6, piece = (tid - 64) & 63;
         long long mrow = m0 + blk * 64; if (mrow >= p.M) mrow = 0;
@@ -1338,8 +1418,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
 #undef COMPUTE_ADDR
     // the MFMAs issued last may still be in flight and the compiler cannot see them (see conv_gemm256_kernel)
     asm volatile("s_nop 15\ns_nop 15" ::: "memory");
-    conv_epilogue<4, 2, GNK, true>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32, ldsepi + wn * 512,
-                                   ldsepi + 1024 + wm * 1024 + wn * 512);
+    conv_epilogue<4, 2, GNK, true, LNF>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32, ldsepi + wn * 512,
+                                        ldsepi + 1024 + (LNF == 2 ? 0 : wm * 1024) + wn * 512);
 }
 
 }  // namespace
@@ -1386,7 +1466,32 @@ int conv_gn_cpg_log2(const uav_conv_params* q) {
     }
     return cl;
 }
+// LayerNorm fold (producer: ln_raw_out + ln_stat_out; consumer: ln_stat_in + ln_colsum): only launches whose EVERY wave tile takes
+// the staged fast epilogue of the production 256x256 kernel.
+bool conv_ln_ok(const uav_conv_params* q) {
+    const long long M = (long long)q->n_img * q->ho * q->wo;
+    const ConvEnv& env = conv_env();
+    if (!conv_uses_big_tile(q) || (M % 64) || (q->n % 128) || q->out_map_w || q->gn_partials || q->rowbias || !q->bias) return false;
+    if (env.dbg || env.persist || env.dmav != 1 || (q->flags & (UAV_CONV_PERSISTENT | UAV_CONV_GELU | UAV_CONV_QUICK_GELU))) return false;
+    const bool of32 = q->flags & UAV_CONV_OUT_F32, rf32 = q->flags & UAV_CONV_RES_F32;
+    if (q->ln_raw_out) {                                   // producer: fp32 result (+ fp32 residual), rows of n = out_stride values
+        if (!q->ln_stat_out || !of32 || (q->flags & UAV_CONV_GEGLU) || (q->out_stride & 3) || q->out_stride != q->n ||
+            (q->residual && (!rf32 || (q->res_stride & 3))))
+            return false;
+    }
+    if (q->ln_stat_in) {                                   // consumer: fp16 result, no residual
+        if (!q->ln_colsum || of32 || q->residual || (q->out_stride & 7) || q->ln_chunks <= 0 || q->ln_n <= 0 || q->ln_chunks * 128 != q->ln_n ||
+            q->ln_n != q->c1 || q->c2 || q->kt * q->kh * q->kw != 1 || ((q->flags & UAV_CONV_GEGLU) && (q->n % 64)))
+            return false;
+    }
+    return true;
+}
 }  // namespace
+
+extern "C" int uav_conv_gemm_ln_ok(const uav_conv_params* q) {
+    if (!q || q->n_pad <= 0 || (!q->ln_raw_out && !q->ln_stat_in)) return 0;
+    return conv_ln_ok(q) ? 1 : 0;
+}
 
 extern "C" int uav_conv_gemm_gn_chunk_rows(const uav_conv_params* q) {
     if (!q || q->n_pad <= 0 || q->gn_groups <= 0) return 0;
@@ -1441,6 +1546,14 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
             return UAV_ESHAPE;
         a.a2_ctr = 1;
     }
+    a.lnp_raw = nullptr; a.lnp_stat = nullptr; a.lnc_stat = nullptr; a.lnc_colsum = nullptr; a.lnc_chunks = 0; a.lnc_n = 0; a.lnc_eps = 0.f;
+    if (q->ln_raw_out || q->ln_stat_in) {
+        if (!conv_ln_ok(q)) return UAV_ESHAPE;             // ask uav_conv_gemm_ln_ok() first
+        if (q->ln_raw_out) { a.lnp_raw = (char*)q->ln_raw_out; a.lnp_stat = (float*)q->ln_stat_out; }
+        if (q->ln_stat_in) {
+            a.lnc_stat = q->ln_stat_in; a.lnc_colsum = q->ln_colsum; a.lnc_chunks = q->ln_chunks; a.lnc_n = q->ln_n; a.lnc_eps = q->ln_eps;
+        }
+    }
     a.omw = 0; a.omsy = 0; a.omsx = 0; a.omoff = 0;
     if (q->out_map_w > 0) {
         if (q->residual || q->gn_partials || (q->flags & UAV_CONV_GEGLU) || q->out_map_sy < 0 || q->out_map_sx <= 0 ||
@@ -1481,7 +1594,8 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
                                  (const void*)conv_gemm256_kernel<6>, (const void*)conv_gemm256_kernel<0, 1>,
                                  (const void*)conv_gemm256i_kernel<1>, (const void*)conv_gemm256i_kernel<2>,
                                  (const void*)conv_gemm256i_kernel<3>, (const void*)conv_gemm256i_kernel<1, 1>,
-                                 (const void*)conv_gemm256i_kernel<1, 2>, (const void*)conv_gemm256i_kernel<1, 3>};
+                                 (const void*)conv_gemm256i_kernel<1, 2>, (const void*)conv_gemm256i_kernel<1, 3>,
+                                 (const void*)conv_gemm256i_kernel<1, 0, 1>, (const void*)conv_gemm256i_kernel<1, 0, 2>};
             for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE + LEPI_BYTES);
             hipDeviceProp_t prop;
             dev_ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
@@ -1489,7 +1603,9 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         const long long ncu = dev_ncu[dev];
         const int dbg = env.dbg, persist = env.persist;
         a.ntiles = (unsigned)grid256;
-        if (a.gn_ws) {                     // statistics-reducing instances of the production kernel (env A/B switches do not apply)
+        if (a.lnp_raw) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 0, 1>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
+        else if (a.lnc_stat) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 0, 2>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
+        else if (a.gn_ws) {                // statistics-reducing instances of the production kernel (env A/B switches do not apply)
             const int gnm = gn_mode_of(a.gn_cpg_log2);
             if (gnm == 1) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 1>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
             else if (gnm == 2) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 2>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);

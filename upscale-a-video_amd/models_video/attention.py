@@ -90,20 +90,23 @@ class CrossAttention(E.EngineModule):
         self.to_v = nn.Linear(cad, inner, bias=bias)
         self.to_out = nn.ModuleList([nn.Linear(inner, query_dim), nn.Dropout(dropout)])
 
-    def run(self, x, residual, *, bq, lq, text=None, q_per_kv=1):
-        """x: normalised tokens [bq*lq][C]; text: TextKV cache entry (k, v, lk) for cross-attention."""
+    def run(self, x, residual, *, bq, lq, text=None, q_per_kv=1, ln=None):
+        """x: normalised tokens [bq*lq][C] — or, with `ln` (the block's LayerNorm in front of this attention), the
+        un-normalised stream itself: the LayerNorm is then folded into the q / q|k|v projection where the launch allows it
+        (engine.ln_linear); text: TextKV cache entry (k, v, lk) for cross-attention."""
         c = self.heads * self.dim_head
         if self.is_cross:
-            q = ops.linear(x, E.packed_conv(self, "q", self.to_q))
+            q = ops.linear(x, E.packed_conv(self, "q", self.to_q)) if ln is None else E.ln_linear(self, "q", ln, x, [self.to_q])
             k, v, lk = text
             o = ops.attention(q, k, v, bq=bq, lq=lq, lk=lk, heads=self.heads, head_dim=self.dim_head, q_per_kv=q_per_kv,
                               scale=self.scale, q_stride=c, k_stride=2 * c, v_stride=2 * c)
         else:
-            qkv = ops.linear(x, E.packed_cat(self, "qkv", [self.to_q, self.to_k, self.to_v]))
+            qkv = ops.linear(x, E.packed_cat(self, "qkv", [self.to_q, self.to_k, self.to_v])) if ln is None else \
+                E.ln_linear(self, "qkv", ln, x, [self.to_q, self.to_k, self.to_v])
             o = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], bq=bq, lq=lq, lk=lq, heads=self.heads,
                               head_dim=self.dim_head, scale=self.scale, q_stride=3 * c, k_stride=3 * c, v_stride=3 * c)
-        return ops.linear(o, E.packed_conv(self, "out", self.to_out[0]), residual=residual,
-                          out_f32=residual.dtype == torch.float32)
+        s32 = residual.dtype == torch.float32
+        return ops.linear(o, E.packed_conv(self, "out", self.to_out[0]), residual=residual, out_f32=s32, ln_produce=s32)
 
     def project_text(self, ehs_rows):
         """K|V of the text tokens: [B*77][2C] (fused GEMM), computed once per prompt tensor."""
@@ -138,14 +141,15 @@ class TemporalAttention(CrossAttention):
         return self._cache().get(("ttab", t_len), build, (self.time_rel_pos_bias.relative_attention_bias.weight,
                                                           None if self.rotary_emb is None else self.rotary_emb.freqs))
 
-    def run_temporal(self, x, residual, g: E.Geom):
+    def run_temporal(self, x, residual, g: E.Geom, ln=None):
         c = self.heads * self.dim_head
         bias, cos, sin, rot = self._tables(g.t)
-        qkv = ops.linear(x, E.packed_cat(self, "qkv", [self.to_q, self.to_k, self.to_v]))
+        qkv = ops.linear(x, E.packed_cat(self, "qkv", [self.to_q, self.to_k, self.to_v])) if ln is None else \
+            E.ln_linear(self, "qkv", ln, x, [self.to_q, self.to_k, self.to_v])
         o = ops.temporal_attention(qkv, n_batch=g.b, t_len=g.t, hw=g.hw, c=c, heads=self.heads, scale=self.scale,
                                    rope_cos=cos, rope_sin=sin, rot_dim=rot, bias=bias)
-        return ops.linear(o, E.packed_conv(self, "out", self.to_out[0]), residual=residual,
-                          out_f32=residual.dtype == torch.float32)
+        s32 = residual.dtype == torch.float32
+        return ops.linear(o, E.packed_conv(self, "out", self.to_out[0]), residual=residual, out_f32=s32, ln_produce=s32)
 
 
 class GEGLU(nn.Module):
@@ -164,8 +168,9 @@ class FeedForward(E.EngineModule):
         inner = int(dim * mult)
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim_out or dim)])
 
-    def run(self, x, residual, out_f32=None):
-        h = ops.linear(x, E.packed_conv(self, "up", self.net[0].proj, geglu=True))
+    def run(self, x, residual, out_f32=None, ln=None):
+        h = ops.linear(x, E.packed_conv(self, "up", self.net[0].proj, geglu=True)) if ln is None else \
+            E.ln_linear(self, "up", ln, x, [self.net[0].proj], geglu=True)
         return ops.linear(h, E.packed_conv(self, "down", self.net[2]), residual=residual,
                           out_f32=(residual.dtype == torch.float32) if out_f32 is None else out_f32)
 
@@ -210,20 +215,18 @@ class BasicTransformerBlock(E.EngineModule):
         """x: tokens [B*T*HW][C] (rows ordered b,t,p), fp16 or fp32 (residual stream); ehs_rows: [B*n_text][Cx] fp16.
         out_f32=False: the block's output is only read as an MFMA operand (proj_out) -> written in fp16."""
         bq, lq = g.n_img, g.hw
-        n = E.layer_norm(self, "norm1", self.norm1, x)
+        # every LayerNorm is handed to its consumer together with the un-normalised stream: engine.ln_linear folds it into
+        # the projection when the stream is fp32 and its producer wrote the operand copy, else runs the LayerNorm pass
         if self.only_cross_attention:
             k, v = self._text_kv(self.attn1, ehs_rows, "a1")
-            x = self.attn1.run(n, x, bq=bq, lq=lq, text=(k, v, n_text), q_per_kv=g.t)
+            x = self.attn1.run(x, x, bq=bq, lq=lq, text=(k, v, n_text), q_per_kv=g.t, ln=self.norm1)
         else:
-            x = self.attn1.run(n, x, bq=bq, lq=lq)
+            x = self.attn1.run(x, x, bq=bq, lq=lq, ln=self.norm1)
         if self.attn2 is not None:
-            n = E.layer_norm(self, "norm2", self.norm2, x)
             k, v = self._text_kv(self.attn2, ehs_rows, "a2")
-            x = self.attn2.run(n, x, bq=bq, lq=lq, text=(k, v, n_text), q_per_kv=g.t)
-        n = E.layer_norm(self, "norm_temporal", self.norm_temporal, x)
-        x = self.attn_temporal.run_temporal(n, x, g)
-        n = E.layer_norm(self, "norm3", self.norm3, x)
-        return self.ff.run(n, x, out_f32)
+            x = self.attn2.run(x, x, bq=bq, lq=lq, text=(k, v, n_text), q_per_kv=g.t, ln=self.norm2)
+        x = self.attn_temporal.run_temporal(x, x, g, ln=self.norm_temporal)
+        return self.ff.run(x, x, out_f32, ln=self.norm3)
 
 
 class Transformer3DModel(ModelMixin, ConfigMixin, E.EngineModule):
@@ -254,7 +257,7 @@ class Transformer3DModel(ModelMixin, ConfigMixin, E.EngineModule):
         n = E.group_norm(self, "norm", self.norm, x, n_inst=g.n_img, rows_per_inst=g.hw, silu=False)   # per frame
         s32 = res.dtype == torch.float32         # fp32 residual stream: the token stream is one too (LayerNorm inputs)
         tok32 = s32 and E.TOKEN_F32 and (E.TOKEN_F32_MAX_HW <= 0 or g.hw <= E.TOKEN_F32_MAX_HW)
-        tok = ops.linear(n, E.packed_conv(self, "proj_in", self.proj_in), out_f32=tok32)
+        tok = ops.linear(n, E.packed_conv(self, "proj_in", self.proj_in), out_f32=tok32, ln_produce=tok32)
         last = len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):
             tok = blk.run(tok, g, ehs_rows, n_text, out_f32=False if i == last else None)   # proj_out reads it as an operand

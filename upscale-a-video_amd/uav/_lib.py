@@ -33,6 +33,8 @@ class ConvParams(C.Structure):
         ("gn_partials", c_p), ("gn_groups", i32),
         ("out_map_w", i32), ("out_map_sy", i32), ("out_map_sx", i32), ("out_map_off", i32),
         ("a2_images", i32), ("a2_center_tap", i32),
+        ("ln_raw_out", c_p), ("ln_stat_out", c_p), ("ln_stat_in", c_p), ("ln_colsum", c_p),
+        ("ln_chunks", i32), ("ln_n", i32), ("ln_eps", f32),
     ]
 
 
@@ -52,6 +54,7 @@ SIGNATURES = {
     "uav_groupnorm_finalize_partials": (C.c_int, [c_p, i64, i32, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p]),
     "uav_groupnorm_workspace_bytes": (i64, [i32, i32]),
     "uav_groupnorm_scale_shift": (C.c_int, [c_p, c_p, i32, i32, i32, i64, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p, i64, c_p]),
+    "uav_conv_gemm_ln_ok": (C.c_int, [C.POINTER(ConvParams)]),
     "uav_frames_to_clip_f32": (C.c_int, [c_p, i32, c_p, i32, i32, i64, c_p]),
     "uav_clip_to_frames_u8": (C.c_int, [c_p, c_p, i32, i32, i64, c_p]),
     "uav_groupnorm_finalize_partials2": (C.c_int, [c_p, i64, i32, i32, i32, c_p, i64, i32, i32, i32, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p]),

@@ -127,6 +127,22 @@ class ConvW:
         return self.n // 2 if self.geglu else self.n
 
 
+class LnOperand:
+    """What a LayerNorm-folding consumer needs of its input rows x (fp32): `raw` = fp16(x) [M][n] and `stat` = per row and
+    128-column chunk (sum, sum of squares) of x, [n/128][M][2] fp32 — written by the linear that produced x (ln_produce)."""
+    __slots__ = ("raw", "stat", "n", "version")
+
+    def __init__(self, raw, stat, n):
+        self.raw, self.stat, self.n, self.version = raw, stat, n, None
+
+
+def ln_operand_of(x):
+    op = getattr(x, "_uav_ln", None)
+    if op is None or op.version != x._version or x.shape[-1] != op.n or op.raw.shape[0] != x.shape[0]:
+        return None
+    return op
+
+
 def _round_up(x, m):
     return (x + m - 1) // m * m
 
@@ -227,8 +243,12 @@ def upsample_phase_weights(weight):
 
 def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None,
               rowbias=None, rows_per_batch=0, residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None,
-              persistent=False, act=None, gn_groups=None, out_map=None, a2_center=False):
+              persistent=False, act=None, gn_groups=None, out_map=None, a2_center=False, ln_produce=False, ln_consume=None):
     """out[M][n_out] = scale*(conv(a1|a2, W) + bias + rowbias[m//rows_per_batch] + residual).
+
+    ln_produce: the fp32 output feeds a LayerNorm whose consumer folds it (`LnFold`): the launch also writes the fp16 rounding of
+    the rows and per-row statistics partials, attached to the returned tensor as `_uav_ln` when the launch qualifies.
+    ln_consume = (LnOperand, colsum, eps): a1 is `LnOperand.raw`; the epilogue applies rstd * (acc - mu * colsum) + bias.
 
     gn_groups: the output feeds a GroupNorm of that many groups — when the launch qualifies
     (`uav_conv_gemm_gn_chunk_rows`) the epilogue also reduces the statistics partials and the returned tensor carries
@@ -303,8 +323,20 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
         p.out_map_w, p.out_map_sy, p.out_map_sx, p.out_map_off = (int(v) for v in out_map)
         if (m // out_map[0] - 1) * out_map[1] + (out_map[0] - 1) * out_map[2] + out_map[3] >= out.shape[0]:
             raise _lib.UavError("out_map places rows past the end of `out`")
+    lnop = None
+    if ln_produce and out_f32 and n_out % 128 == 0 and out.shape[-1] == n_out:
+        lnop = LnOperand(torch.empty((m, n_out), dtype=HALF, device=a1.device),
+                         torch.empty((n_out // 128, m, 2), dtype=torch.float32, device=a1.device), n_out)
+        p.ln_raw_out = _p(lnop.raw); p.ln_stat_out = _p(lnop.stat)
+        if not lib.uav_conv_gemm_ln_ok(C.byref(p)):
+            lnop = None; p.ln_raw_out = None; p.ln_stat_out = None
+    if ln_consume is not None:
+        src, colsum, eps = ln_consume
+        p.ln_stat_in = _p(src.stat); p.ln_colsum = _p(colsum); p.ln_chunks = src.stat.shape[0]; p.ln_n = src.n; p.ln_eps = float(eps)
+        if not lib.uav_conv_gemm_ln_ok(C.byref(p)):
+            raise _lib.UavError("conv_gemm: this launch cannot fold the LayerNorm (ask ln_fold_ok first)")
     gn = None
-    if gn_groups and FUSE_GN_STATS and out_map is None:
+    if gn_groups and FUSE_GN_STATS and out_map is None and lnop is None:
         p.gn_groups = int(gn_groups)
         rows = lib.uav_conv_gemm_gn_chunk_rows(C.byref(p))
         if rows > 0:
@@ -319,6 +351,9 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
         _gn_attach(out, gn)
     elif getattr(out, "_uav_gn", None) is not None:      # caller-supplied buffer rewritten without statistics
         out._uav_gn = None
+    if lnop is not None:
+        lnop.version = out._version
+        out._uav_ln = lnop
     # algorithmic work: 2*M*N*K over the LOGICAL taps x input channels (no channel / tile padding counted); temporal taps
     # that fall outside the clip (zero padding of a (k,1,1) / 3x3x3 conv at the clip ends, which the kernel skips) are
     # not counted either
@@ -350,11 +385,24 @@ def _factor_rows(m):
 
 
 def linear(x, wt: ConvW, *, residual=None, out_scale=1.0, rowbias=None, rows_per_batch=0, out_f32=False, act=None,
-           gn_groups=None):
+           gn_groups=None, ln_produce=False, ln_consume=None):
     """nn.Linear over token rows x[M][K] (a 1x1 'conv': every row is one pixel)."""
     n_img, hi = _factor_rows(x.shape[0])
     return conv_gemm(x, wt, n_img=n_img, t_len=1, hi=hi, wi=1, residual=residual, out_scale=out_scale,
-                     rowbias=rowbias, rows_per_batch=rows_per_batch, out_f32=out_f32, act=act, gn_groups=gn_groups)
+                     rowbias=rowbias, rows_per_batch=rows_per_batch, out_f32=out_f32, act=act, gn_groups=gn_groups,
+                     ln_produce=ln_produce, ln_consume=ln_consume)
+
+
+def ln_fold_ok(m, k, wt: ConvW):
+    """Can a linear over m rows of k channels with packed weights `wt` fold a LayerNorm (uav_conv_gemm_ln_ok)?  Mirrors the C
+    check without building a launch: 256x256 kernel (enough tiles), full wave tiles."""
+    n_img, hi = _factor_rows(m)
+    p = _lib.ConvParams()
+    p.c1 = k; p.c2 = 0; p.n_img = n_img; p.t_len = 1; p.hi = hi; p.wi = 1; p.ho = hi; p.wo = 1; p.kt = p.kh = p.kw = 1; p.stride = 1
+    p.n = wt.n; p.n_pad = wt.n_pad; p.k_pad = wt.k_pad; p.out_stride = wt.n_out
+    p.flags = _lib.CONV_GEGLU if wt.geglu else 0
+    p.bias = 1; p.ln_stat_in = 1; p.ln_colsum = 1; p.ln_chunks = k // 128; p.ln_n = k     # non-NULL markers: host-only query
+    return bool(_lib.load().uav_conv_gemm_ln_ok(C.byref(p)))
 
 
 # ------------------------------------------------------------------------------------------------
