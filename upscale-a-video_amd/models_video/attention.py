@@ -106,7 +106,7 @@ class CrossAttention(E.EngineModule):
             o = ops.attention(qkv[:, :c], qkv[:, c:2 * c], qkv[:, 2 * c:], bq=bq, lq=lq, lk=lq, heads=self.heads,
                               head_dim=self.dim_head, scale=self.scale, q_stride=3 * c, k_stride=3 * c, v_stride=3 * c)
         s32 = residual.dtype == torch.float32
-        return ops.linear(o, E.packed_conv(self, "out", self.to_out[0]), residual=residual, out_f32=s32, ln_produce=s32)
+        return ops.linear(o, E.packed_conv(self, "out", self.to_out[0]), residual=residual, out_f32=s32, ln_produce=s32 and E.LN_FOLD)
 
     def project_text(self, ehs_rows):
         """K|V of the text tokens: [B*77][2C] (fused GEMM), computed once per prompt tensor."""
@@ -149,7 +149,7 @@ class TemporalAttention(CrossAttention):
         o = ops.temporal_attention(qkv, n_batch=g.b, t_len=g.t, hw=g.hw, c=c, heads=self.heads, scale=self.scale,
                                    rope_cos=cos, rope_sin=sin, rot_dim=rot, bias=bias)
         s32 = residual.dtype == torch.float32
-        return ops.linear(o, E.packed_conv(self, "out", self.to_out[0]), residual=residual, out_f32=s32, ln_produce=s32)
+        return ops.linear(o, E.packed_conv(self, "out", self.to_out[0]), residual=residual, out_f32=s32, ln_produce=s32 and E.LN_FOLD)
 
 
 class GEGLU(nn.Module):
@@ -257,7 +257,7 @@ class Transformer3DModel(ModelMixin, ConfigMixin, E.EngineModule):
         n = E.group_norm(self, "norm", self.norm, x, n_inst=g.n_img, rows_per_inst=g.hw, silu=False)   # per frame
         s32 = res.dtype == torch.float32         # fp32 residual stream: the token stream is one too (LayerNorm inputs)
         tok32 = s32 and E.TOKEN_F32 and (E.TOKEN_F32_MAX_HW <= 0 or g.hw <= E.TOKEN_F32_MAX_HW)
-        tok = ops.linear(n, E.packed_conv(self, "proj_in", self.proj_in), out_f32=tok32, ln_produce=tok32)
+        tok = ops.linear(n, E.packed_conv(self, "proj_in", self.proj_in), out_f32=tok32, ln_produce=tok32 and E.LN_FOLD)
         last = len(self.transformer_blocks) - 1
         for i, blk in enumerate(self.transformer_blocks):
             tok = blk.run(tok, g, ehs_rows, n_text, out_f32=False if i == last else None)   # proj_out reads it as an operand
