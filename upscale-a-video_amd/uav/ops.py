@@ -354,6 +354,8 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
     if lnop is not None:
         lnop.version = out._version
         out._uav_ln = lnop
+    elif getattr(out, "_uav_ln", None) is not None:      # caller-supplied buffer rewritten without the LayerNorm operand copy
+        out._uav_ln = None
     # algorithmic work: 2*M*N*K over the LOGICAL taps x input channels (no channel / tile padding counted); temporal taps
     # that fall outside the clip (zero padding of a (k,1,1) / 3x3x3 conv at the clip ends, which the kernel skips) are
     # not counted either
