@@ -27,8 +27,9 @@ timeout 300 python bench.py --unet-stream f16 --no-cpu-baseline > gpurun_out/r3_
 timeout 300 python bench.py --propagation --no-cpu-baseline > gpurun_out/r3_bench_config3_final.json 2> gpurun_out/r3_bench_config3_final.err
 timeout 400 python bench.py --video-vae --height 348 --width 384 --no-cpu-baseline > gpurun_out/r3_bench_config5_tile_final.json 2> gpurun_out/r3_bench_config5_tile_final.err
 timeout 300 python bench.py --clips-per-step 2 --no-cpu-baseline > gpurun_out/r3_bench_two_clips_final.json 2> gpurun_out/r3_bench_two_clips_final.err
+timeout 400 python bench.py --shard-windows --frames 32 --warmup 0 --no-cpu-baseline > gpurun_out/r3_bench_config4_t32_1gpu_final.json 2> gpurun_out/r3_bench_config4_t32_1gpu_final.err
 cat gpurun_out/r3_tests_final.log
-for f in default_final f16_final config3_final config5_tile_final two_clips_final under_rocprof; do python -c "
+for f in default_final f16_final config3_final config5_tile_final two_clips_final config4_t32_1gpu_final under_rocprof; do python -c "
 import json; d=json.load(open('gpurun_out/r3_bench_$f.json')); r=d.get('roofline',{}); print('$f', round(d['value'],4), round(d['ms_per_step'],1), round(r.get('achieved',0),1), r.get('traffic'), d.get('cpu_baseline',{}).get('value'))"; done
 head -14 gpurun_out/r3_rocprofv3_kernel_stats_bench.csv
 cat gpurun_out/r3_pmc_sq_conv.jsonl
