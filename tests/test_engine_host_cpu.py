@@ -284,3 +284,32 @@ def test_oracle_under_gpu_shim_equals_oracle():
             b = OS.vae_decode(vsd, cfg, z, img, 1.0)
         assert rel_l2(b, a) < 1e-5
     assert O.F is torch.nn.functional                               # the shim is gone again
+
+
+def test_pack_conv_with_shortcut_layout(cpu_engine):
+    """`conv_shortcut(x) + conv2(h)` packed as ONE weight matrix (ops.pack_conv_with_shortcut): K = taps x (C + Cs), the 1x1
+    weights at the centre tap of the extra channels, zeros elsewhere, bias = b2 + bs, `k_logical` = 9 C + Cs for the FLOP
+    accounting; with the [hi | lo] operand pair the shortcut weights are repeated.  Checked through the conv stand-in (which
+    multiplies the structural zeros like the 128x128 kernel does) against the two convs."""
+    from uav import ops
+    g = torch.Generator().manual_seed(8)
+    c, cs, o, h, w, n_img = 64, 128, 64, 6, 5, 2
+    w2 = (torch.randn(o, c, 3, 3, generator=g) * 0.05).half().float(); b2 = torch.randn(o, generator=g)
+    ws = (torch.randn(o, cs, 1, 1, generator=g) * 0.1).half().float(); bs = torch.randn(o, generator=g)
+    hh = torch.randn(n_img * h * w, c, generator=g).half()
+    x32 = torch.randn(n_img * h * w, cs, generator=g) * 3
+    hi = x32.half(); lo = (x32 - hi.float()).half()
+    for rep, raw in ((1, hi), (2, torch.cat([hi, lo], dim=1))):
+        cw = ops.pack_conv_with_shortcut(w2, b2, ws, bs, rep)
+        assert cw.cin_p == c + rep * cs and cw.k_logical == 9 * c + cs and cw.kh == cw.kw == 3
+        wk = cw.w[:o, : 9 * (c + rep * cs)].float().reshape(o, 9, c + rep * cs)
+        assert torch.equal(wk[:, :, :c].permute(0, 2, 1).reshape(o, c, 3, 3), w2)
+        assert torch.count_nonzero(wk[:, [0, 1, 2, 3, 5, 6, 7, 8], c:]) == 0                 # off-centre taps of the shortcut channels
+        assert torch.equal(wk[:, 4, c:c + cs], ws.reshape(o, cs)) and (rep == 1 or torch.equal(wk[:, 4, c + cs:], ws.reshape(o, cs)))
+        assert torch.allclose(cw.bias[:o], b2 + bs)
+        y = ops.conv_gemm(hh, cw, a2=raw, a2_center=True, n_img=n_img, t_len=1, hi=h, wi=w, out_f32=True)
+        xs = raw[:, :cs].float() + (raw[:, cs:].float() if rep == 2 else 0)
+        ref = torch.nn.functional.conv2d(hh.float().reshape(n_img, h, w, c).permute(0, 3, 1, 2), w2, b2, padding=1) + \
+            torch.nn.functional.conv2d(xs.reshape(n_img, h, w, cs).permute(0, 3, 1, 2), ws, bs)
+        assert rel_l2(y, ref.permute(0, 2, 3, 1).reshape(-1, o)) < 1e-5
+    assert rel_l2(hi.float() + lo.float(), x32) < 1e-6                                         # the pair carries x to ~22 bits
