@@ -136,6 +136,8 @@ def self_launch(n):
     """Re-exec this script as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n ... bench.py <same args>`."""
     import subprocess
     have = torch.cuda.device_count()
+    if os.environ.get("UAV_BENCH_SAME_GPU") == "1" and have >= 1:
+        have = n                        # test mode: all ranks on GPU 0, gloo transport (RCCL refuses two ranks per device)
     if have < n:
         print(f"bench.py: --gpus {n} requested but only {have} GPU(s) are visible", file=sys.stderr)
         return 2
@@ -203,21 +205,26 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
-    if local_rank >= torch.cuda.device_count():
-        raise SystemExit(f"bench.py: rank {rank} needs GPU {local_rank} but only {torch.cuda.device_count()} are visible")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    same_gpu = os.environ.get("UAV_BENCH_SAME_GPU") == "1"     # TEST MODE (tests/test_multigpu_gpu.py on a 1-GPU box): every rank on GPU 0
+    gpu_index = 0 if same_gpu else local_rank
+    if gpu_index >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} needs GPU {gpu_index} but only {torch.cuda.device_count()} are visible")
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)        # RCCL on ROCm; one process per GPU
+        if same_gpu:
+            dist.init_process_group("gloo")                    # transport through host memory; the kernels are the real ones
+        else:
+            dist.init_process_group("nccl", device_id=dev)    # RCCL on ROCm; one process per GPU
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"bench.py: RCCL reports {dist.get_world_size()} ranks, expected {args.gpus}")
 
     from uav import _lib, ops
     lib = _lib.load()
-    if lib.uav_device_check(local_rank, None) != 0:
+    if lib.uav_device_check(gpu_index, None) != 0:
         raise SystemExit("bench.py needs an MI355X (gfx950)")
 
     from uav import configs as _cfg
@@ -299,7 +306,10 @@ def main():
     def barrier():
         if world > 1:
             import torch.distributed as dist
-            dist.barrier(device_ids=[local_rank])
+            if same_gpu:
+                dist.barrier()
+            else:
+                dist.barrier(device_ids=[local_rank])
         torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -328,7 +338,7 @@ def main():
     assert out.shape == (1, 3, args.frames, 4 * args.height, 4 * args.width) and bool(torch.isfinite(out).all())
     if world > 1:
         import torch.distributed as dist
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device="cpu" if same_gpu else dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

@@ -40,10 +40,11 @@ def test_bench_shard_windows_two_ranks():
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["frames_per_clip"] == 14
 
 
-def _bench_line(extra, gpus):
+def _bench_line(extra, gpus, same_gpu=False):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "1", "--warmup", "0", "--height", "64", "--width", "64",
            "--ddim-steps", "2", "--no-cpu-baseline", "--no-kernel-events", "--text-encoder", "standin", "--digest"] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    env = dict(os.environ, UAV_BENCH_SAME_GPU="1") if same_gpu else None
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stderr[-2000:]
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
 
@@ -57,9 +58,13 @@ def test_sharded_clip_is_bit_identical_to_one_gpu(extra):
     if torch.cuda.device_count() < 2:
         if "--shard-cfg" not in extra or "14" not in extra:
             pytest.skip("needs >= 2 GPUs")
-        one = _bench_line(extra, 1)             # 1-GPU box: the (window x branch) schedule runs and reports a digest
-        assert len(one["config"]["output_sha256"]) == 64 and one["scaling"] == "strong"
-        pytest.skip("needs >= 2 GPUs for the 2-rank leg (1-rank schedule ran)")
+        # 1-GPU box: TWO ranks on the one GPU (UAV_BENCH_SAME_GPU: gloo transport through host memory, because RCCL refuses two
+        # ranks per device) — the sharded schedule, the all-gathers and the REAL kernels, against the 1-rank run: same bits
+        one = _bench_line(extra, 1)
+        two = _bench_line(extra, 2, same_gpu=True)
+        assert two["n_gpus"] == 2 and two["scaling"] == "strong"
+        assert two["config"]["output_sha256"] == one["config"]["output_sha256"]
+        return
     one = _bench_line(extra, 1)
     two = _bench_line(extra, 2)
     assert two["n_gpus"] == 2 and two["scaling"] == "strong"

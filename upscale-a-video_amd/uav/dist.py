@@ -62,9 +62,22 @@ def sharded_map(items, fn, group=None, like=None):
     buf = torch.zeros((per_rank,) + shape, dtype=dtype, device=device)
     for i, t in enumerate(mine):
         buf[i] = t
-    gathered = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(gathered, buf, group=group)
+    gathered = _all_gather(buf, world, group)
     return [gathered[i % world][i // world] for i in range(len(items))]
+
+
+def _all_gather(buf, world, group=None):
+    """all_gather of one tensor per rank.  RCCL ("nccl") gathers device tensors in place over xGMI; the gloo backend (CPU tests,
+    and the 2-ranks-on-ONE-GPU check of tests/test_multigpu_gpu.py, where RCCL refuses two ranks on a device) is staged
+    through host memory — bit-exact either way."""
+    if dist.get_backend(group) == "gloo" and buf.is_cuda:
+        host = buf.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(parts, host, group=group)
+        return [p_.to(buf.device) for p_ in parts]
+    parts = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf, group=group)
+    return parts
 
 
 def _default_device():

@@ -113,5 +113,10 @@ def upscale_tiled(pipeline, prompt, vframes: torch.Tensor, flows_bi: Optional[li
         out[:, :, :, dy0:dy1, dx0:dx1] = res[:, :, :, cy0:cy1, cx0:cx1]
     if world > 1:
         generator.set_state(final_state)
-        dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)               # disjoint boxes: x + 0 is exact
+        if dist.get_backend(group) == "gloo" and out.is_cuda:                   # gloo (tests): staged through host memory
+            host = out.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            out.copy_(host)
+        else:
+            dist.all_reduce(out, op=dist.ReduceOp.SUM, group=group)           # disjoint boxes: x + 0 is exact
     return out
