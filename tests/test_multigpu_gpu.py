@@ -56,8 +56,6 @@ def test_sharded_clip_is_bit_identical_to_one_gpu(extra):
     chunks) gives the SAME BITS as the 1-rank run of the same schedule (VERDICT r2 next #4a).  The 1-rank leg also runs on
     a single-GPU box for one of the schedules."""
     if torch.cuda.device_count() < 2:
-        if "--shard-cfg" not in extra or "14" not in extra:
-            pytest.skip("needs >= 2 GPUs")
         # 1-GPU box: TWO ranks on the one GPU (UAV_BENCH_SAME_GPU: gloo transport through host memory, because RCCL refuses two
         # ranks per device) — the sharded schedule, the all-gathers and the REAL kernels, against the 1-rank run: same bits
         one = _bench_line(extra, 1)
@@ -69,3 +67,12 @@ def test_sharded_clip_is_bit_identical_to_one_gpu(extra):
     two = _bench_line(extra, 2)
     assert two["n_gpus"] == 2 and two["scaling"] == "strong"
     assert two["config"]["output_sha256"] == one["config"]["output_sha256"]
+
+
+def test_clip_parallel_two_ranks_on_one_gpu():
+    """The default (clip-parallel, weak-scaling) bench path with two ranks — on a 1-GPU box both on GPU 0 over gloo
+    (UAV_BENCH_SAME_GPU): barrier + MAX-reduce bracketing, one clip per rank, one JSON line from rank 0 with n_gpus = 2."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("covered by test_bench_self_launch_two_ranks on multi-GPU boxes")
+    d = _bench_line([], 2, same_gpu=True)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["clips_per_step"] == 2 and d["value"] > 0
