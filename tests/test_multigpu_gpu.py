@@ -76,3 +76,21 @@ def test_clip_parallel_two_ranks_on_one_gpu():
         pytest.skip("covered by test_bench_self_launch_two_ranks on multi-GPU boxes")
     d = _bench_line([], 2, same_gpu=True)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["clips_per_step"] == 2 and d["value"] > 0
+
+
+def test_tiled_clip_two_ranks_same_bits_as_one():
+    """BASELINE configs[4]'s sharding (the CLI's spatial tiles dealt over the ranks, shared-generator draws replayed, output boxes
+    merged by one all-reduce) with the real pipeline: 2 ranks — on a 1-GPU box both on GPU 0 over gloo — against 1 rank."""
+    tool = os.path.join(ROOT, "tools", "tiled_ranks.py")
+
+    def run(n):
+        same = torch.cuda.device_count() < 2
+        env = dict(os.environ, UAV_BENCH_SAME_GPU="1") if (same and n > 1) else dict(os.environ)
+        cmd = [sys.executable, tool] if n == 1 else [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1",
+                                                     "--nnodes=1", f"--nproc-per-node={n}", tool]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    one, two = run(1), run(2)
+    assert one["tiles"] >= 2 and two["world"] == 2
+    assert one["output_sha256"] == two["output_sha256"]
