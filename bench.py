@@ -176,6 +176,13 @@ def main():
                     help="clips upscaled CONCURRENTLY per GPU in one step, one HIP stream (and host thread) each: the "
                          "HBM-bound kernels of one clip run beside the MFMA-bound kernels of the other (serving mode); "
                          "per-launch HIP events are switched off because launches overlap")
+    ap.add_argument("--overlap-streams", type=int, default=int(os.environ.get("UAV_OVERLAP_STREAMS", "0")),
+                    help="ONE clip, its independent units (the two guidance branches of a DDIM step / the temporal windows of a long "
+                         "clip, the 3-frame decode chunks) issued on this many HIP streams from one host thread (uav/streams.py); "
+                         "bit-identical output.  Launches overlap, so `roofline` is then measured in one extra SERIAL step")
+    ap.add_argument("--overlap-split-cfg", action="store_true",
+                    help="with --overlap-streams: also split a window into its two guidance branches (batch-1 units, CFG-shared "
+                         "head given up) when there are fewer windows than streams — measured slower on the 8-frame clip")
     ap.add_argument("--video-vae", action="store_true",
                     help="BASELINE configs[4] building block: the SFT-conditioned video VAE (vae_video config, 3x3x3 convs) instead "
                          "of vae_3d; use with --height 348 --width 384 for one CLI tile of a 540p frame")
@@ -237,6 +244,9 @@ def main():
     pipe.cfg_shared_input = not args.no_cfg_share
     pipe.shard_windows = args.shard_windows
     pipe.shard_cfg = args.shard_cfg
+    pipe.overlap_streams = 0 if args.shard_windows else args.overlap_streams
+    pipe.overlap_split_cfg = args.overlap_split_cfg
+    overlapped = pipe.overlap_streams > 1
     if args.shard_cfg and not args.shard_windows:
         raise SystemExit("--shard-cfg refines --shard-windows")
     clip = synthetic_clip(args.frames, args.height, args.width, seed=0 if args.shard_windows else rank, dev=dev)
@@ -319,7 +329,8 @@ def main():
     all_events = args.all_kernel_events or bool(os.environ.get("UAV_BENCH_DETAIL"))
     if use_events:
         ops.PROFILER.detail = bool(os.environ.get("UAV_BENCH_DETAIL"))
-        ops.PROFILER.start(only=None if all_events else {"conv_gemm"})
+        if not overlapped:              # per-launch events mean nothing while launches of two streams share the chip
+            ops.PROFILER.start(only=None if all_events else {"conv_gemm"})
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = one_step(10 + i)
@@ -328,13 +339,18 @@ def main():
     ops.PROFILER.stop()
     timed_summary = ops.PROFILER.summary() if use_events else None
     extra_summary = None
-    if use_events and not all_events and world == 1:
-        # per-kernel table: one extra step AFTER the timed region with events around every kernel family
+    if use_events and (overlapped or (not all_events and world == 1)):
+        # per-kernel table: one extra step AFTER the timed region with events around every kernel family (serial, i.e. with the
+        # stream overlap switched off for this step: the kernel measurements are those of the default mode)
+        pipe.overlap_streams = 0
         ops.PROFILER.start()
         one_step(10)
         torch.cuda.synchronize()
         ops.PROFILER.stop()
         extra_summary = ops.PROFILER.summary()
+        pipe.overlap_streams = args.overlap_streams if overlapped else 0
+        if overlapped:
+            timed_summary = extra_summary
     assert out.shape == (1, 3, args.frames, 4 * args.height, 4 * args.width) and bool(torch.isfinite(out).all())
     if world > 1:
         import torch.distributed as dist
@@ -360,7 +376,9 @@ def main():
                                       f"latent propagation at steps {psteps}; " if args.propagation else "no propagation; ")
                                    + (("ONE clip, (temporal window x guidance branch) units" if args.shard_cfg else "ONE clip, temporal windows")
                                       + " + decode chunks dealt over the ranks, all-gather per DDIM step (RCCL)"
-                                      if args.shard_windows else f"{ncl} clip(s) per GPU per step"
+                                      if args.shard_windows else
+                                      (f"the clip's {'guidance branches / ' if args.overlap_split_cfg else ''}windows and decode chunks on {pipe.overlap_streams} concurrent HIP streams, " if overlapped else "")
+                                      + f"{ncl} clip(s) per GPU per step"
                                       + (" on concurrent HIP streams" if ncl > 1 else "") + " (clip-parallel, no collective)"),
                        "clips_per_step": world * ncl, "frames_per_clip": args.frames},
         }
@@ -405,6 +423,8 @@ def main():
                                "traffic_source": traffic_note if traffic is None else "replayed from profiles/pmc_conv_traffic.json (separate rocprofv3 "
                                                  "--pmc pass over this command with the SAME kernel sources — digest checked —, tools/pmc_traffic.sh); "
                                                  "not measured by this run",
+                               "measured": ("one extra SERIAL step after the timed region (launches of the timed region overlap on "
+                                            f"{pipe.overlap_streams} streams)" if overlapped else "HIP events inside the timed region"),
                                "launches": d["launches"],
                                "avg_launch_us": d["seconds"] / d["launches"] * 1e6,
                                "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,

@@ -21,6 +21,7 @@ Multi-GPU: `UAV_RANKS` style clip/chunk sharding lives in bench.py / uav.dist â€
 always drives ONE GPU, like the reference.
 """
 import inspect
+import os
 from dataclasses import dataclass
 from typing import List, Optional, Union
 
@@ -29,6 +30,7 @@ import torch
 from uav import dist as D
 from uav import engine as E
 from uav import ops
+from uav import streams
 
 from ._compat import BaseOutput, ConfigMixin
 from .scheduling_ddim import DDIMScheduler, DDPMScheduler
@@ -84,6 +86,13 @@ class VideoUpscalePipeline(ConfigMixin):
         # 8) and even one 8-frame clip splits over 2 GPUs.  Only read when `shard_windows` is set; the result is
         # bit-identical for every world size (the unit decomposition does not depend on it).
         self.shard_cfg = False
+        # ONE clip on ONE GPU, its independent units on `overlap_streams` HIP streams (uav/streams.py): the temporal windows of a
+        # DDIM step (a clip longer than 8 frames) and the 3-frame decode chunks; 0 / 1 = off.  Same bits as the serial order.
+        # `overlap_split_cfg`: when there are fewer windows than streams, also evaluate the two guidance branches of a window
+        # as separate batch-1 units (the decomposition of `shard_cfg`, same bits as THAT serial order) â€” measured slower on
+        # the 8-frame headline clip (half-size launches, the CFG-shared head given up: -2.4 %, DESIGN Â§6), so off by default.
+        self.overlap_streams = int(os.environ.get("UAV_OVERLAP_STREAMS", "0"))
+        self.overlap_split_cfg = os.environ.get("UAV_OVERLAP_SPLIT_CFG", "0") == "1"
         self.latents_trace = None          # test hook: set to a list to collect the latents after every DDIM step
         self.cache_prompt_embeds = True
         self._prompt_cache = {}
@@ -307,15 +316,27 @@ class VideoUpscalePipeline(ConfigMixin):
                              f" `num_channels_image`: {image.shape[1]}")
 
         wins = window_schedule(t_total)
+        overlap = None
+        if self.overlap_streams > 1 and not self.shard_windows and torch.device(device).type == "cuda":
+            overlap = streams.stream_set(device, self.overlap_streams)
         # per-branch text rows as stable objects: the UNet's text K/V caches are keyed on tensor identity
-        pe_branch = [prompt_embeds[b:b + 1].contiguous() for b in range(prompt_embeds.shape[0])] if do_cfg else None
+        # (and kept across calls for the same prompt tensor, so those caches also hit on the next clip / tile)
+        pe_branch = None
+        if do_cfg:
+            hit = self.__dict__.get("_pe_branch")
+            if hit is None or hit[0] is not prompt_embeds or hit[1] != prompt_embeds._version:
+                hit = (prompt_embeds, prompt_embeds._version, [prompt_embeds[b:b + 1].contiguous() for b in range(prompt_embeds.shape[0])])
+                E.publish()
+                self.__dict__["_pe_branch"] = hit
+            pe_branch = hit[2]
         if flows_bi is not None and len(propagation_steps) > 0:
             flows_f = flows_bi[0].to(device=device, dtype=torch.float16)
             flows_b = flows_bi[1].to(device=device, dtype=torch.float16)
 
         for i, t in enumerate(timesteps):
             lin = torch.cat([latents] * 2) if do_cfg else latents
-            split = self.shard_windows and self.shard_cfg and do_cfg
+            uniq = [w for k, w in enumerate(wins) if w not in wins[:k]]
+            split = do_cfg and ((self.shard_windows and self.shard_cfg) or (overlap is not None and self.overlap_split_cfg and len(uniq) < len(overlap.streams)))
 
             def eval_unit(u):
                 """One UNet evaluation: window (s, e) with both guidance branches (b is None) or one of them."""
@@ -328,10 +349,12 @@ class VideoUpscalePipeline(ConfigMixin):
             # the windows of one step are independent UNet evaluations: with `shard_windows` and an initialised process
             # group the units are dealt over the ranks and all-gathered (uav/dist.py:sharded_map); the blend below is
             # replayed identically on every rank.  A duplicate tail window is evaluated once.
-            uniq = [w for k, w in enumerate(wins) if w not in wins[:k]]
             units = [(w, b) for w in uniq for b in ((0, 1) if split else (None,))]
             like = ((1 if split else lin.shape[0], latents.shape[1], uniq[0][1] - uniq[0][0]) + tuple(lin.shape[3:]), lat_dtype, device)
-            res = D.sharded_map(units, eval_unit, like=like) if self.shard_windows else [eval_unit(u) for u in units]
+            if self.shard_windows:
+                res = D.sharded_map(units, eval_unit, like=like)
+            else:
+                res = overlap.map(units, eval_unit) if overlap is not None else [eval_unit(u) for u in units]
             outs = {w: (torch.cat([res[2 * k], res[2 * k + 1]]) if split else res[k]) for k, w in enumerate(uniq)}
             if len(wins) > 1:
                 eps = None
@@ -374,7 +397,10 @@ class VideoUpscalePipeline(ConfigMixin):
                     y = torch.cat([y, y.new_zeros(y.shape[:2] + (short_seq - (e - s),) + y.shape[3:])], dim=2)
                 return y.contiguous()
             like = ((1, image_dec.shape[1], short_seq, 4 * height, 4 * width), torch.float32, device)
-            chunks = D.sharded_map(starts, decode_chunk, like=like) if self.shard_windows else [decode_chunk(s) for s in starts]
+            if self.shard_windows:
+                chunks = D.sharded_map(starts, decode_chunk, like=like)
+            else:
+                chunks = overlap.map(starts, decode_chunk) if overlap is not None else [decode_chunk(s) for s in starts]
             out = torch.cat(chunks, dim=2)[:, :, :t_total]
         else:
             out = self.decode_latents_vsr(latents, image_dec, w_lr)

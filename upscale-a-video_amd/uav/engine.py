@@ -77,8 +77,18 @@ class PackedCache:
         hit = self.store.get(key)
         if hit is None or hit[0] != stamp:
             hit = (stamp, builder())
+            publish()
             self.store[key] = hit
         return hit[1]
+
+
+def publish():
+    """Called after a SHARED, lazily built device object (packed weights, tables, text K/V) was produced on the current stream
+    and before it becomes visible to other callers: host-waits for that stream, so that a caller on ANOTHER stream (the two
+    clips of the serving mode, the overlapped guidance branches / decode chunks of `uav.streams`) never reads it before the
+    kernels that fill it have run.  Once per object, not on the steady-state path."""
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        torch.cuda.current_stream().synchronize()
 
 
 class EngineModule(nn.Module):

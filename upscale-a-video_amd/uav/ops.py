@@ -101,7 +101,10 @@ _ZERO = {}
 def zero_page(device):
     key = str(device)
     if key not in _ZERO:
-        _ZERO[key] = torch.zeros(256, dtype=torch.uint8, device=device)
+        z = torch.zeros(256, dtype=torch.uint8, device=device)
+        if z.is_cuda:
+            torch.cuda.current_stream(z.device).synchronize()      # shared by every stream from here on
+        _ZERO[key] = z
     return _ZERO[key]
 
 
