@@ -176,10 +176,11 @@ def main():
                     help="clips upscaled CONCURRENTLY per GPU in one step, one HIP stream (and host thread) each: the "
                          "HBM-bound kernels of one clip run beside the MFMA-bound kernels of the other (serving mode); "
                          "per-launch HIP events are switched off because launches overlap")
-    ap.add_argument("--overlap-streams", type=int, default=int(os.environ.get("UAV_OVERLAP_STREAMS", "0")),
-                    help="ONE clip, its independent units (the two guidance branches of a DDIM step / the temporal windows of a long "
-                         "clip, the 3-frame decode chunks) issued on this many HIP streams from one host thread (uav/streams.py); "
-                         "bit-identical output.  Launches overlap, so `roofline` is then measured in one extra SERIAL step")
+    ap.add_argument("--overlap-streams", type=int, default=None,
+                    help="a clip LONGER than 8 frames: its temporal windows and decode chunks issued on this many HIP streams from one "
+                         "host thread (uav/streams.py; default: the pipeline's, 2; 0 = serial); same bits as serial.  Launches then "
+                         "overlap, so `roofline` is measured in one extra SERIAL step.  The 8-frame headline clip has one window and "
+                         "runs serially either way (unless --overlap-split-cfg)")
     ap.add_argument("--overlap-split-cfg", action="store_true",
                     help="with --overlap-streams: also split a window into its two guidance branches (batch-1 units, CFG-shared "
                          "head given up) when there are fewer windows than streams — measured slower on the 8-frame clip")
@@ -244,9 +245,11 @@ def main():
     pipe.cfg_shared_input = not args.no_cfg_share
     pipe.shard_windows = args.shard_windows
     pipe.shard_cfg = args.shard_cfg
-    pipe.overlap_streams = 0 if args.shard_windows else args.overlap_streams
+    if args.overlap_streams is not None:
+        pipe.overlap_streams = args.overlap_streams
+    n_overlap = pipe.overlap_streams
     pipe.overlap_split_cfg = args.overlap_split_cfg
-    overlapped = pipe.overlap_streams > 1
+    overlapped = n_overlap > 1 and not args.shard_windows and (args.frames > 8 or args.overlap_split_cfg)
     if args.shard_cfg and not args.shard_windows:
         raise SystemExit("--shard-cfg refines --shard-windows")
     clip = synthetic_clip(args.frames, args.height, args.width, seed=0 if args.shard_windows else rank, dev=dev)
@@ -348,7 +351,7 @@ def main():
         torch.cuda.synchronize()
         ops.PROFILER.stop()
         extra_summary = ops.PROFILER.summary()
-        pipe.overlap_streams = args.overlap_streams if overlapped else 0
+        pipe.overlap_streams = n_overlap
         if overlapped:
             timed_summary = extra_summary
     assert out.shape == (1, 3, args.frames, 4 * args.height, 4 * args.width) and bool(torch.isfinite(out).all())
@@ -377,7 +380,7 @@ def main():
                                    + (("ONE clip, (temporal window x guidance branch) units" if args.shard_cfg else "ONE clip, temporal windows")
                                       + " + decode chunks dealt over the ranks, all-gather per DDIM step (RCCL)"
                                       if args.shard_windows else
-                                      (f"the clip's {'guidance branches / ' if args.overlap_split_cfg else ''}windows and decode chunks on {pipe.overlap_streams} concurrent HIP streams, " if overlapped else "")
+                                      (f"the clip's {'guidance branches / ' if args.overlap_split_cfg else ''}windows and decode chunks on {n_overlap} concurrent HIP streams, " if overlapped else "")
                                       + f"{ncl} clip(s) per GPU per step"
                                       + (" on concurrent HIP streams" if ncl > 1 else "") + " (clip-parallel, no collective)"),
                        "clips_per_step": world * ncl, "frames_per_clip": args.frames},
@@ -424,7 +427,7 @@ def main():
                                                  "--pmc pass over this command with the SAME kernel sources — digest checked —, tools/pmc_traffic.sh); "
                                                  "not measured by this run",
                                "measured": ("one extra SERIAL step after the timed region (launches of the timed region overlap on "
-                                            f"{pipe.overlap_streams} streams)" if overlapped else "HIP events inside the timed region"),
+                                            f"{n_overlap} streams)" if overlapped else "HIP events inside the timed region"),
                                "launches": d["launches"],
                                "avg_launch_us": d["seconds"] / d["launches"] * 1e6,
                                "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,

@@ -86,12 +86,13 @@ class VideoUpscalePipeline(ConfigMixin):
         # 8) and even one 8-frame clip splits over 2 GPUs.  Only read when `shard_windows` is set; the result is
         # bit-identical for every world size (the unit decomposition does not depend on it).
         self.shard_cfg = False
-        # ONE clip on ONE GPU, its independent units on `overlap_streams` HIP streams (uav/streams.py): the temporal windows of a
-        # DDIM step (a clip longer than 8 frames) and the 3-frame decode chunks; 0 / 1 = off.  Same bits as the serial order.
-        # `overlap_split_cfg`: when there are fewer windows than streams, also evaluate the two guidance branches of a window
-        # as separate batch-1 units (the decomposition of `shard_cfg`, same bits as THAT serial order) — measured slower on
-        # the 8-frame headline clip (half-size launches, the CFG-shared head given up: -2.4 %), so off by default.
-        self.overlap_streams = int(os.environ.get("UAV_OVERLAP_STREAMS", "0"))
+        # ONE clip on ONE GPU, its independent units on `overlap_streams` HIP streams (uav/streams.py), issued by this one host
+        # thread: the temporal windows of a DDIM step and the 3-frame decode chunks of a clip LONGER than 8 frames (two or more
+        # unique windows) — same bits as the serial order, +2.5 % on a 32-frame clip (run 24).  An 8-frame clip has
+        # one window and stays serial: its decode chunks on two streams measured neutral, and `overlap_split_cfg` (its two
+        # guidance branches as separate batch-1 units, the decomposition of `shard_cfg`) measured 2.4 % SLOWER — half-size
+        # launches, CFG-shared head given up — so that one is opt-in.  0 / 1 = always serial.
+        self.overlap_streams = int(os.environ.get("UAV_OVERLAP_STREAMS", "2"))
         self.overlap_split_cfg = os.environ.get("UAV_OVERLAP_SPLIT_CFG", "0") == "1"
         self.latents_trace = None          # test hook: set to a list to collect the latents after every DDIM step
         self.cache_prompt_embeds = True
@@ -317,7 +318,8 @@ class VideoUpscalePipeline(ConfigMixin):
 
         wins = window_schedule(t_total)
         overlap = None
-        if self.overlap_streams > 1 and not self.shard_windows and torch.device(device).type == "cuda":
+        if (self.overlap_streams > 1 and not self.shard_windows and torch.device(device).type == "cuda"
+                and (len(set(wins)) > 1 or (self.overlap_split_cfg and do_cfg))):
             overlap = streams.stream_set(device, self.overlap_streams)
         # per-branch text rows as stable objects: the UNet's text K/V caches are keyed on tensor identity
         # (and kept across calls for the same prompt tensor, so those caches also hit on the next clip / tile)
