@@ -313,3 +313,116 @@ def test_pack_conv_with_shortcut_layout(cpu_engine):
             torch.nn.functional.conv2d(xs.reshape(n_img, h, w, cs).permute(0, 3, 1, 2), ws, bs)
         assert rel_l2(y, ref.permute(0, 2, 3, 1).reshape(-1, o)) < 1e-5
     assert rel_l2(hi.float() + lo.float(), x32) < 1e-6                                         # the pair carries x to ~22 bits
+
+
+def test_stream_set_ordering_rules(monkeypatch):
+    """uav/streams.py without a GPU: the ORDER of waits and launches StreamSet.map issues (fake stream objects record it).  Every
+    side stream waits for the caller's stream before its first unit, unit k goes to side stream k % n, the caller's stream waits
+    for every side stream that was used before map returns, and a single unit never leaves the caller's stream."""
+    import contextlib
+    from uav import streams
+    log = []
+
+    class FakeStream:
+        def __init__(self, name="side", device=None):
+            self.name = name if name != "side" else f"s{len([e for e in log if e[0] == 'new'])}"
+            self.cuda_stream = id(self)
+            log.append(("new", self.name))
+
+        def wait_stream(self, other):
+            log.append(("wait", self.name, other.name))
+
+    cur = FakeStream("cur")
+    state = {"current": cur}
+
+    @contextlib.contextmanager
+    def fake_ctx(st):
+        prev, state["current"] = state["current"], st
+        try:
+            yield
+        finally:
+            state["current"] = prev
+    monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: FakeStream(device=device))
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: cur)
+    monkeypatch.setattr(torch.cuda, "stream", fake_ctx)
+    ss = streams.StreamSet("cuda:0", 2)
+    log.clear()
+    out = ss.map([10, 11, 12], lambda it: (log.append(("unit", it, state["current"].name)), it * 2)[1])
+    assert out == [20, 22, 24]
+    assert log == [("wait", "s1", "cur"), ("unit", 10, "s1"), ("wait", "s2", "cur"), ("unit", 11, "s2"), ("unit", 12, "s1"),
+                   ("wait", "cur", "s1"), ("wait", "cur", "s2")]
+    log.clear()
+    assert ss.map([7], lambda it: (log.append(("unit", it, state["current"].name)), it)[1]) == [7]
+    assert log == [("unit", 7, "cur")]                       # one unit: stays on the caller's stream, no waits
+    log.clear()
+    assert ss.map([], lambda it: it) == [] and log == []
+    # one StreamSet per (device, n, calling stream): two host threads on their own streams do not share side streams
+    monkeypatch.setattr(streams, "_SETS", {})
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    a = streams.stream_set("cuda:0", 2)
+    assert streams.stream_set("cuda:0", 2) is a and streams.stream_set("cuda:0", 3) is not a
+    other = FakeStream("cur2")
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: other)
+    assert streams.stream_set("cuda:0", 2) is not a
+
+
+def test_pipeline_overlap_units_host_side(cpu_engine, unet_and_sd, monkeypatch):
+    """Which units the pipeline hands to the stream set (`_stream_set`, `overlap_streams`, `overlap_split_cfg`) — on CPU with a
+    recording stand-in for uav.streams.StreamSet that evaluates serially: T = 14 gives its 2 unique windows per DDIM step and 5
+    decode chunks; an 8-frame clip stays serial unless the guidance branches are asked for, which gives 2 batch-1 units per
+    step (the shard_cfg decomposition) and 3 decode chunks.  Results equal the serial call's."""
+    from models_video.autoencoder_kl_cond_video import AutoencoderKLVideo
+    from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
+    from models_video.scheduling_ddim import DDIMScheduler, DDPMScheduler
+    from uav import streams
+    from uav.standin_text import StandInTextEncoder, StandInTokenizer
+    unet, _ = unet_and_sd
+    vae = AutoencoderKLVideo.from_config(dict(GC.VAE3D_TINY))
+    vae.load_state_dict(synth.synth_state_dict(vae.state_dict(), seed=4321), strict=True)
+    tok = StandInTokenizer()
+    pipe = VideoUpscalePipeline(text_encoder=StandInTextEncoder(tok, GC.UNET_TINY["cross_attention_dim"], dtype=torch.float32),
+                                tokenizer=tok, low_res_scheduler=DDPMScheduler(), scheduler=DDIMScheduler(**GC.SCHED),
+                                vae=vae.eval(), unet=unet, propagator=None).to("cpu")
+    calls = []
+
+    class Recorder:
+        streams = [0, 1]
+
+        def map(self, items, fn):
+            items = list(items)
+            calls.append(items)
+            return [fn(it) for it in items]
+    # the decision itself (a torch.device("cuda") can be named without a GPU)
+    monkeypatch.setattr(streams, "stream_set", lambda device, n: Recorder())
+    cuda = torch.device("cuda", 0)
+    assert pipe.overlap_streams == 2 and not pipe.overlap_split_cfg
+    assert pipe._stream_set(cuda, 1, True) is None and pipe._stream_set(torch.device("cpu"), 3, True) is None
+    assert isinstance(pipe._stream_set(cuda, 2, True), Recorder)
+    pipe.overlap_split_cfg = True
+    assert isinstance(pipe._stream_set(cuda, 1, True), Recorder) and pipe._stream_set(cuda, 1, False) is None
+    pipe.shard_windows = True
+    assert pipe._stream_set(cuda, 3, True) is None
+    pipe.shard_windows, pipe.overlap_split_cfg, pipe.overlap_streams = False, False, 0
+    assert pipe._stream_set(cuda, 3, True) is None
+    pipe.overlap_streams = 2
+
+    def run(t, overlapped, split=False):
+        pipe.overlap_split_cfg = split
+        clip = synth.synth_clip(1, t, 16, 16, seed=14)
+        if overlapped:
+            monkeypatch.setattr(pipe, "_stream_set", lambda device, n_windows, do_cfg: Recorder() if (n_windows > 1 or split) else None)
+        else:
+            monkeypatch.setattr(pipe, "_stream_set", lambda device, n_windows, do_cfg: None)
+        calls.clear()
+        return pipe("p", image=clip, generator=torch.Generator().manual_seed(10), num_inference_steps=2, guidance_scale=6.0,
+                    noise_level=120, negative_prompt="n", return_dict=False)
+    ref = run(14, False)
+    assert calls == []
+    got = run(14, True)
+    assert calls == [[((0, 8), None), ((6, 14), None)]] * 2 + [[0, 3, 6, 9, 12]]
+    assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1])
+    ref8 = run(8, False)
+    assert run(8, True)[0].shape == ref8[0].shape and calls == []            # one window, no split: serial
+    got8 = run(8, True, split=True)
+    assert calls == [[((0, 8), 0), ((0, 8), 1)]] * 2 + [[0, 3, 6]]
+    assert rel_l2(got8[1], ref8[1]) < 5e-3          # batch-1 units vs the batch-2 evaluation: ATen's CPU convs block differently (see above)

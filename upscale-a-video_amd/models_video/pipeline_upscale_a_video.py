@@ -212,6 +212,16 @@ class VideoUpscalePipeline(ConfigMixin):
             self._prompt_cache[key] = hit
         return hit[0]
 
+    def _stream_set(self, device, n_windows, do_cfg):
+        """The side streams this call issues its independent units on (uav/streams.py), or None = everything on the caller's
+        stream: GPU only, not together with the multi-GPU sharding, and only when there is something to overlap — two or more
+        unique temporal windows, or the guidance branches when `overlap_split_cfg` asks for them."""
+        if self.overlap_streams <= 1 or self.shard_windows or torch.device(device).type != "cuda":
+            return None
+        if n_windows > 1 or (self.overlap_split_cfg and do_cfg):
+            return streams.stream_set(device, self.overlap_streams)
+        return None
+
     def check_inputs(self, prompt, image, noise_level, negative_prompt=None, prompt_embeds=None,
                      negative_prompt_embeds=None):
         if prompt is not None and prompt_embeds is not None:
@@ -317,10 +327,7 @@ class VideoUpscalePipeline(ConfigMixin):
                              f" `num_channels_image`: {image.shape[1]}")
 
         wins = window_schedule(t_total)
-        overlap = None
-        if (self.overlap_streams > 1 and not self.shard_windows and torch.device(device).type == "cuda"
-                and (len(set(wins)) > 1 or (self.overlap_split_cfg and do_cfg))):
-            overlap = streams.stream_set(device, self.overlap_streams)
+        overlap = self._stream_set(device, len(set(wins)), do_cfg)
         # per-branch text rows as stable objects: the UNet's text K/V caches are keyed on tensor identity
         # (and kept across calls for the same prompt tensor, so those caches also hit on the next clip / tile)
         pe_branch = None
