@@ -26,7 +26,12 @@ def timeit(fn, iters=6, warm=2):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
+ONLY = sys.argv[1:]          # optional: run only the cases whose name contains one of these substrings
+
+
 def case(name, n_img, t_len, h, w, cin, cout, k3, *, res=None, out_f32=False, rowbias=False, gn=None, geglu=False, iters=6):
+    if ONLY and not any(o in name for o in ONLY):
+        return
     m = n_img * h * w
     x = torch.randn(m, cin, device=dev).half()
     wt = torch.randn(cout, cin, *k3) * (cin * k3[0] * k3[1] * k3[2]) ** -0.5
@@ -68,6 +73,9 @@ def main():
     case("3x3 256->256 @16x320x320 bias+res16+gn", **C, h=320, w=320, cin=256, cout=256, k3=(1, 3, 3), res="f16", gn=32, iters=4)
     case("3x3 256->256 @16x320x320 bias+res32->f32+gn", **C, h=320, w=320, cin=256, cout=256, k3=(1, 3, 3), res="f32", out_f32=True, gn=32, iters=4)
     case("t3 512->512 @16x160x160 bias+res16+gn", **C, h=160, w=160, cin=512, cout=512, k3=(3, 1, 1), res="f16", gn=32)
+    case("1x1 512->512 @16x160x160 bias+res32->f32", **C, h=160, w=160, cin=512, cout=512, k3=(1, 1, 1), res="f32", out_f32=True)
+    case("1x1 512->512 @16x160x160 bias+res32->f32+gn", **C, h=160, w=160, cin=512, cout=512, k3=(1, 1, 1), res="f32", out_f32=True, gn=32)
+    case("1x1 512->512 @16x160x160 bias+res16+gn", **C, h=160, w=160, cin=512, cout=512, k3=(1, 1, 1), res="f16", gn=32)
     case("1x1 256->256 @16x320x320 bias+res32->f32+gn", **C, h=320, w=320, cin=256, cout=256, k3=(1, 1, 1), res="f32", out_f32=True, gn=32, iters=4)
 
 
