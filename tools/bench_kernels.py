@@ -3,7 +3,6 @@ Prints one JSON line per case: achieved TFLOP/s (MFMA-bound kernels) or GB/s (HB
 import json
 import os
 import sys
-import time
 
 import torch
 

@@ -40,8 +40,7 @@ class _FakeHalf(torch.Tensor):
 
 
 def main():
-    import json
-    from models_video.unet_video import UNetVideoModel
+        from models_video.unet_video import UNetVideoModel
     from uav import engine as E
     torch.set_num_threads(int(os.environ.get("UAV_THREADS", "4")))
     from uav import configs

@@ -16,7 +16,6 @@ HIP kernel library:
 """
 import math
 from dataclasses import dataclass
-from typing import Optional
 
 import torch
 import torch.nn as nn

@@ -5,10 +5,9 @@ state-dict keys; `decode(z, img, w_lr).sample` returns (B,3,T,4H,4W) fp32 like t
 Tiled / sliced decoding of the reference are never enabled by the CLI and are not built.
 """
 from dataclasses import dataclass
-from typing import Optional, Tuple, Union
+from typing import Tuple
 
 import torch
-import torch.nn as nn
 
 from uav import engine as E
 

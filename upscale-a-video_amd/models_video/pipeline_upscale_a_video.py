@@ -20,10 +20,9 @@ What differs inside (results unchanged up to fp rounding):
 Multi-GPU: `UAV_RANKS` style clip/chunk sharding lives in bench.py / uav.dist — a pipeline object
 always drives ONE GPU, like the reference.
 """
-import inspect
 import os
 from dataclasses import dataclass
-from typing import List, Optional, Union
+from typing import List, Optional
 
 import torch
 

@@ -9,7 +9,7 @@ pipeline_upscale_a_video.py:643-645), computed in fp32 and rounded once, and `ti
 the host so the loop never synchronises.
 """
 from dataclasses import dataclass
-from typing import List, Optional, Tuple, Union
+from typing import Optional
 
 import numpy as np
 import torch

@@ -13,7 +13,6 @@ MFMA path, and the fp16-vs-fp32 difference is reported in DESIGN.md.
 from dataclasses import dataclass
 from typing import Optional
 
-import numpy as np
 import torch
 import torch.nn as nn
 

@@ -7,7 +7,6 @@ the output buffers.  Activations are channels-last fp16 matrices [rows][C], rows
 """
 import ctypes as C
 import functools
-import math
 import os
 from dataclasses import dataclass
 from typing import Optional
