@@ -15,6 +15,7 @@ dev = torch.device("cuda:0")
 
 
 def timeit(fn, iters=6, warm=2):
+    iters *= int(os.environ.get("UAV_EPI_ITERS_X", "1"))
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
