@@ -199,7 +199,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--all-kernel-events", action="store_true",
-                    help="HIP events around EVERY kernel family inside the timed region (costs ~2 %: 50 k event records of ~3 us "
+                    help="HIP events around EVERY kernel family inside the timed region (costs ~2 %%: 50 k event records of ~3 us "
                          "of GPU time per clip).  Default: only the dominant kernel (conv_gemm, what `roofline` needs) is timed there "
                          "and the per-kernel table comes from one extra, untimed, fully instrumented step")
     args = ap.parse_args()

@@ -131,6 +131,16 @@ def test_bench_self_launch_refuses_without_enough_gpus(capsys):
     assert "only 0 GPU(s) are visible" in capsys.readouterr().err
 
 
+def test_bench_help_renders():
+    """argparse %-formats every help string: an unescaped `%` in one of them breaks `python bench.py --help` only."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-800:]
+    for flag in ("--gpus", "--steps", "--warmup", "--unet-stream", "--shard-windows", "--overlap-streams", "--clips-per-step"):
+        assert flag in r.stdout
+
+
 def test_oracle_ddim_vs_golden():
     rec = json.load(open(os.path.join(GOLD, "ddim.json")))
     sch = O.DDIM(**GC.SCHED)
