@@ -671,4 +671,9 @@ def only(section):
 
 
 if __name__ == "__main__":
+    _known = ("--raft", "--unet", "--tiles", "--pipe14", "--vaewlr", "--colorfix", "--pipehalf", "--prophalf", "--fullvideo", "--full30", "--full")
+    if any(a not in _known for a in sys.argv[1:]):
+        # no flag = regenerate the quarter-width fixtures (minutes); an unknown flag (e.g. --help) must not start that
+        print("usage: make_golden.py [" + " | ".join(_known) + "]   (no flag: all quarter-width fixtures)")
+        sys.exit(0 if sys.argv[1:] in (["--help"], ["-h"]) else 2)
     only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else only("tiles") if "--tiles" in sys.argv else only("pipe14") if "--pipe14" in sys.argv else only("vaewlr") if "--vaewlr" in sys.argv else only("colorfix") if "--colorfix" in sys.argv else only("pipehalf") if "--pipehalf" in sys.argv else only("prophalf") if "--prophalf" in sys.argv else only("fullvideo") if "--fullvideo" in sys.argv else only("full30") if "--full30" in sys.argv else only("full") if "--full" in sys.argv else main()
