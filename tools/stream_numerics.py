@@ -40,7 +40,7 @@ class _FakeHalf(torch.Tensor):
 
 
 def main():
-        from models_video.unet_video import UNetVideoModel
+    from models_video.unet_video import UNetVideoModel
     from uav import engine as E
     torch.set_num_threads(int(os.environ.get("UAV_THREADS", "4")))
     from uav import configs
@@ -122,6 +122,20 @@ def main():
                             x2 = torch.cat([x2, x2])
                         return y, _FakeHalf(x1.float() if x2 is None else torch.cat([x1.float(), x2.float()], dim=-1))
                     ops.groupnorm = gn_raw_exact
+            # "-gnin16" / "-lnin16": GroupNorm / LayerNorm passes read the fp32 stream through an fp16 rounding (what a stream
+            # stored as an fp16 hi|lo plane pair would allow: the norm passes read the hi plane only, 2 instead of 4 B/element)
+            def rounded_input(fn):
+                def wrap(x, *a, **kw):
+                    if x.dtype == torch.float32:
+                        x = x.half().float()
+                    if kw.get("x2") is not None and kw["x2"].dtype == torch.float32:
+                        kw["x2"] = kw["x2"].half().float()
+                    return fn(x, *a, **kw)
+                return wrap
+            if "-gnin16" in mode:
+                ops.groupnorm = rounded_input(ops.groupnorm)
+            if "-lnin16" in mode:
+                ops.layernorm = rounded_input(ops.layernorm)
             t0 = time.time()
             with torch.no_grad():
                 out = unet(sample.half(), ts, low.half(), encoder_hidden_states=ehs.half(), class_labels=cl).sample
