@@ -126,11 +126,13 @@ def main():
             # stored as an fp16 hi|lo plane pair would allow: the norm passes read the hi plane only, 2 instead of 4 B/element)
             def rounded_input(fn):
                 def wrap(x, *a, **kw):
-                    if x.dtype == torch.float32:
-                        x = x.half().float()
+                    xr = x.half().float() if x.dtype == torch.float32 else x
+                    kwr = dict(kw)
                     if kw.get("x2") is not None and kw["x2"].dtype == torch.float32:
-                        kw["x2"] = kw["x2"].half().float()
-                    return fn(x, *a, **kw)
+                        kwr["x2"] = kw["x2"].half().float()
+                    if kw.get("want_raw"):               # the raw hi|lo operand copy still comes from the exact stream
+                        return fn(xr, *a, **kwr)[0], fn(x, *a, **kw)[1]
+                    return fn(xr, *a, **kwr)
                 return wrap
             if "-gnin16" in mode:
                 ops.groupnorm = rounded_input(ops.groupnorm)
