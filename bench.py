@@ -287,9 +287,17 @@ def main():
             pipes.append(sh)
         clips = [synthetic_clip(args.frames, args.height, args.width, seed=rank * ncl + j, dev=dev) for j in range(ncl)]
 
+    def new_generator(seed):
+        # a DEVICE generator, like the reference CLI's `torch.Generator(device=UAV_device).manual_seed(10)` (inference_upscale_a_video.py
+        # :197): the two noise tensors of a clip (5.7 M normals) are drawn on the GPU inside the timed region.  A host generator
+        # (UAV_BENCH_CPU_GENERATOR=1, what rounds 1-3 timed) draws them in fp16 on the host cores and copies them: ~0.1-0.2 s per clip
+        if os.environ.get("UAV_BENCH_CPU_GENERATOR") == "1":
+            return torch.Generator().manual_seed(seed)
+        return torch.Generator(device=dev).manual_seed(seed)
+
     def one_step(seed):
         if ncl == 1:
-            gen = torch.Generator().manual_seed(seed)
+            gen = new_generator(seed)
             return pipe(prompt, generator=gen, **kw).images
         outs = [None] * ncl
         errs = []
@@ -297,7 +305,7 @@ def main():
         def work(j):
             try:
                 with torch.cuda.stream(streams[j]):
-                    gen = torch.Generator().manual_seed(seed * ncl + j)
+                    gen = new_generator(seed * ncl + j)
                     outs[j] = pipes[j](prompt, generator=gen, **{**kw, "image": clips[j]}).images
             except Exception as e:       # noqa: BLE001 — re-raised on the main thread
                 errs.append(e)
