@@ -205,7 +205,21 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
             if class_labels.device.type == "cpu" and bool((class_labels > self.config.max_noise_level).any()):
                 raise ValueError(f"`noise_level` has to be <= {self.config.max_noise_level} but is {class_labels}")
             tab = E.f32_param(self, "class_emb", self.class_embedding.weight)
-            ce = tab.index_select(0, class_labels.to(dev).reshape(-1))           # embedding lookup (gather)
+            if class_labels.device.type == "cpu" and torch.device(dev).type != "cpu":
+                # the pipeline hands the noise level as a host tensor on every call: a pageable host->device copy waits for the
+                # stream to drain, i.e. one host/GPU rendezvous per UNet forward.  Keep the device copy per label value.
+                key = (tuple(int(v) for v in class_labels.reshape(-1).tolist()), str(dev))
+                cache = self.__dict__.setdefault("_class_label_dev", {})
+                idx = cache.get(key)
+                if idx is None:
+                    if len(cache) >= 16:
+                        cache.clear()
+                    idx = class_labels.to(dev).reshape(-1)
+                    E.publish()
+                    cache[key] = idx
+            else:
+                idx = class_labels.to(dev).reshape(-1)
+            ce = tab.index_select(0, idx)                                        # embedding lookup (gather)
             emb = emb + ce                                                       # broadcast (1|B, D)
         return emb.contiguous()
 
