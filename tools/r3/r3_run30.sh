@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 3, GPU call 30: the persistent form of the 256x256 kernel (round-1 loop, one workgroup per CU walks its tiles and issues the
+# round 3, GPU call 30: VOID (UAV_CONV_PERSIST is shadowed by the default UAV_CONV_DMAV=1: both legs ran conv_gemm256i_kernel<1>; needs UAV_CONV_DMAV=0)
 # first DMA stage of the NEXT tile before the epilogue of the current one; UAV_CONV_PERSIST=1) on the short-K linears with the
 # round-3 epilogues, vs the default (round-2 interleaved-DMA loop, one tile per workgroup), same box, 30-iteration timings
 cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
