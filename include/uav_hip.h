@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UAV_ABI_VERSION 4
+#define UAV_ABI_VERSION 5
 
 #define UAV_EINVAL   (-1)   /* bad argument (null pointer, size not supported) */
 #define UAV_EALIGN   (-2)   /* pointer / stride alignment requirement violated */
@@ -303,6 +303,13 @@ int uav_propagate_step_f16(const void* feat_prev, const void* feat_cur, const vo
                            int64_t flow_chan_stride, /* elements between the x and y flow planes */
                            int32_t nearest,
                            int32_t coord_f16, /* 1: replay fp16 grid arithmetic; 0: fp32 */
+                           float fuse_scale, float alpha1, float alpha2, void* stream);
+/* ABI v5.  The same step on fp32 planes, fp32 flows and fp32 grid arithmetic — what the reference computes when its latents are
+ * fp32 (pipeline_upscale_a_video.py:651 casts the flows `.to(latents)`; flow_warp builds the grid `.type_as(x)`,
+ * propagation_module.py:123).  Used by the pipeline when the UNet runs on an fp32 residual stream. */
+int uav_propagate_step_f32(const float* feat_prev, const float* feat_cur, const float* flow_prop,
+                           const float* flow_check, float* out, int32_t c, int32_t h, int32_t w,
+                           int64_t feat_chan_stride, int64_t flow_chan_stride, int32_t nearest,
                            float fuse_scale, float alpha1, float alpha2, void* stream);
 
 

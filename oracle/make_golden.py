@@ -430,6 +430,14 @@ def make_prop_half_goldens(ns, pin):
                               "fraction_differing_from_fp32_coordinates": ((ref16.float() - ref32).abs() > 1e-2).float().mean().item()}
         torch.save(ref16, os.path.join(GOLD, name + ".pt"))
         print(name, pin["cases"][name], flush=True)
+        if kind == "ties":
+            # round 4: the same inputs through the reference in fp32 (flows `.to(latents)`, grid `.type_as(x)`): what an
+            # fp32-latent pipeline is held to (`uav_propagate_step_f32`); differs from the half run on ~half of the tie pixels
+            name32 = name.replace("_half", "_f32")
+            pin["cases"][name32] = {"changed_fraction": (ref32 != x).float().mean().item(),
+                                    "fraction_differing_from_half_run": pin["cases"][name]["fraction_differing_from_fp32_coordinates"]}
+            torch.save(ref32, os.path.join(GOLD, name32 + ".pt"))
+            print(name32, pin["cases"][name32], flush=True)
 
 
 def _full_models(ns):

@@ -485,11 +485,13 @@ def window_schedule(t_total, short_seq=8, overlap=2):
 
 def pipeline_call(unet_sd, unet_cfg, vae_sd, vae_cfg, image, prompt_embeds, *, num_inference_steps, guidance_scale,
                   noise_level, lr_noise, latents, flows_bi=None, propagation_steps=(), w_lr=1.0, scheduler_kwargs=None,
-                  decode=True, return_trace=False):
+                  decode=True, return_trace=False, resume=None):
     """VideoUpscalePipeline.__call__ (pipeline_upscale_a_video.py:436-716) in fp32.
     image (1,3,T,h,w) in [-1,1]; prompt_embeds (2,77,C) = [negative, positive]; lr_noise and
     latents are the two randn draws of the reference (:547, :567), injected so that RNG order does
-    not matter.  Returns (images (1,3,T,4h,4w) clamped, latents_out)."""
+    not matter.  Returns (images (1,3,T,4h,4w) clamped, latents_out).
+    `resume=(i0, lat)` (test economy): start the loop at step index i0 from the latents a previous call traced after step
+    i0 - 1 — the steps before a first propagation step are shared by a run with and a run without propagation."""
     sch = DDIM(**(scheduler_kwargs or {}))
     do_cfg = guidance_scale > 1.0
     image_dec = image.clone()
@@ -500,7 +502,11 @@ def pipeline_call(unet_sd, unet_cfg, vae_sd, vae_cfg, image, prompt_embeds, *, n
     timesteps = sch.set_timesteps(num_inference_steps)
     lat = latents * sch.init_noise_sigma
     trace = []
+    if resume is not None:
+        lat = resume[1].clone()
     for i, t in enumerate(timesteps):                                           # :607
+        if resume is not None and i < resume[0]:
+            continue
         lin = torch.cat([lat] * 2) if do_cfg else lat
         wins = window_schedule(t_total)
         if len(wins) > 1:                                                       # :619-635

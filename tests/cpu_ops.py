@@ -258,7 +258,8 @@ def propagate_step(feat_prev, feat_cur, flow_prop, flow_check, out, *, c, h, w, 
     cur = feat_cur.float()[None]
     warped = _warp(feat_prev.float()[None], fp, "nearest" if nearest else "bilinear")
     fused = fuse_scale * warped + (1.0 - fuse_scale) * cur
-    out.copy_(_h(mask * fused + (1.0 - mask) * cur)[0])
+    res = mask * fused + (1.0 - mask) * cur
+    out.copy_((_h(res) if out.dtype == HALF else res)[0])
     return out
 
 

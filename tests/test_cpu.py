@@ -108,6 +108,21 @@ def test_oracle_propagation_vs_golden():
         assert (out - gold).abs().max().item() < 2e-3
 
 
+def test_oracle_propagation_fp32_on_rounding_ties_vs_golden():
+    """Round 4: fp32 latents are held to the reference's fp32 propagation run; inputs ON the .5 ties of the nearest warp
+    (tests/golden/propagation_*_f32_*.pt, reference `Propagation` on CPU fp32 tensors).  The half-run fixture of the same
+    inputs differs on ~half of the tie pixels, so the pair discriminates the two coordinate modes."""
+    for name in ("propagation_nearest_f32_ties", "propagation_nearest_f32_wide", "propagation_bilinear_f32_wide"):
+        kind, t, h, w, interp = GC.PROP_HALF_CASES[name.replace("_f32", "_half")]
+        x, ff, fb = GC.prop_half_inputs(kind, t, h, w)
+        out = O.propagation(x, ff, fb, interp, 0.5, 0.001, 0.05)
+        gold = torch.load(os.path.join(GOLD, name + ".pt"))
+        assert gold.dtype == torch.float32
+        assert (out - gold).abs().max().item() < 1e-5, name
+        half = torch.load(os.path.join(GOLD, name.replace("_f32", "_half") + ".pt")).float()
+        assert ((half - gold).abs() > 1e-2).float().mean().item() > 0.1, name
+
+
 def test_oracle_colorfix_vs_golden():
     """Oracle restatement of the colour fix against the reference's own outputs (tests/golden/colorfix.pt)."""
     lr, content = GC.colorfix_inputs()
@@ -213,7 +228,7 @@ def test_cabi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/uav_hip.h but not exported"
     assert declared == set(_lib.SIGNATURES), (declared ^ set(_lib.SIGNATURES))
-    assert lib.uav_version() == 4
+    assert lib.uav_version() == _lib.EXPECTED_ABI == int(re.search(r"#define UAV_ABI_VERSION (\d+)", hdr).group(1))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -730,6 +745,7 @@ def test_pipeline_host_logic_with_propagation_vs_reference_fixture(unet_sd):
 
     class OraclePropagator(torch.nn.Module):
         def forward(self, x0, flows_f, flows_b, interpolation="nearest", mode="fuse", fuse_scale=0.5, alpha1=0.001, alpha2=0.05):
+            assert flows_f.dtype == flows_b.dtype == x0.dtype       # reference :651: `flows_bi[k].to(latents)`
             seen.append((interpolation, mode, fuse_scale, alpha1, alpha2, tuple(flows_f.shape)))
             with torch.no_grad():
                 return O.propagation(x0.float(), flows_f.float(), flows_b.float(), interpolation, fuse_scale, alpha1, alpha2).half()

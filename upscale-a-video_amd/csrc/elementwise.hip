@@ -200,8 +200,8 @@ UAV_DEVINL void warp_coords(int x, int y, float fx, float fy, int w, int h, floa
     iy = R::r(((gy + 1.f) / 2.f) * (float)(h - 1));
 }
 
-template <typename R>
-UAV_DEVINL float sample_bilinear(const half_t* __restrict__ plane, int w, int h, float ix, float iy) {
+template <typename R, typename T>
+UAV_DEVINL float sample_bilinear(const T* __restrict__ plane, int w, int h, float ix, float iy) {
     const float fx0 = floorf(ix), fy0 = floorf(iy);
     const int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
     const float nw = R::r(R::r((float)x1 - ix) * R::r((float)y1 - iy));
@@ -216,10 +216,10 @@ UAV_DEVINL float sample_bilinear(const half_t* __restrict__ plane, int w, int h,
     return acc;
 }
 
-template <typename R>
-__global__ __launch_bounds__(256) void propagate_step_kernel(const half_t* __restrict__ prev, const half_t* __restrict__ cur,
-                                                             const half_t* __restrict__ fprop, const half_t* __restrict__ fchk,
-                                                             half_t* __restrict__ out, int c, int h, int w, long long fcs,
+template <typename R, typename T>
+__global__ __launch_bounds__(256) void propagate_step_kernel(const T* __restrict__ prev, const T* __restrict__ cur,
+                                                             const T* __restrict__ fprop, const T* __restrict__ fchk,
+                                                             T* __restrict__ out, int c, int h, int w, long long fcs,
                                                              long long wcs, int nearest, float fuse, float a1, float a2) {
     // fcs / wcs: channel strides (elements) of the feature planes / flow planes
     const long long hw = (long long)h * w;
@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256) void propagate_step_kernel(const half_t* __res
     float ix, iy;
     warp_coords<R>(x, y, fx, fy, w, h, ix, iy);
     // forward-backward consistency (fbConsistencyCheck)
-    const float bx = sample_bilinear<R>(fchk, w, h, ix, iy);
-    const float by = sample_bilinear<R>(fchk + wcs, w, h, ix, iy);
+    const float bx = sample_bilinear<R, T>(fchk, w, h, ix, iy);
+    const float by = sample_bilinear<R, T>(fchk + wcs, w, h, ix, iy);
     const float dx = R::r(fx + bx), dy = R::r(fy + by);
     const float ldiff = R::r(R::r(dx * dx) + R::r(dy * dy));
     const float lf = R::r(R::r(fx * fx) + R::r(fy * fy));
@@ -250,10 +250,10 @@ __global__ __launch_bounds__(256) void propagate_step_kernel(const half_t* __res
         if (valid) {
             float wv;
             if (nearest) wv = inb ? (float)prev[ch * fcs + (long long)yn * w + xn] : 0.f;
-            else wv = sample_bilinear<R>(prev + ch * fcs, w, h, ix, iy);
+            else wv = sample_bilinear<R, T>(prev + ch * fcs, w, h, ix, iy);
             o = R::r(R::r(wv * fuse) + R::r(cv * (1.0f - fuse)));
         }
-        out[ch * fcs + i] = (half_t)o;
+        out[ch * fcs + i] = (T)o;
     }
 }
 
@@ -403,12 +403,28 @@ extern "C" int uav_propagate_step_f16(const void* feat_prev, const void* feat_cu
     if (feat_chan_stride < hw || flow_chan_stride < hw) return UAV_ESHAPE;
     hipStream_t s = (hipStream_t)stream;
     if (coord_f16)
-        hipLaunchKernelGGL(propagate_step_kernel<RoundF16>, dim3(nblk(hw, 256)), dim3(256), 0, s, (const half_t*)feat_prev,
+        hipLaunchKernelGGL((propagate_step_kernel<RoundF16, half_t>), dim3(nblk(hw, 256)), dim3(256), 0, s, (const half_t*)feat_prev,
                            (const half_t*)feat_cur, (const half_t*)flow_prop, (const half_t*)flow_check, (half_t*)out, c, h,
                            w, (long long)feat_chan_stride, (long long)flow_chan_stride, nearest, fuse_scale, alpha1, alpha2);
     else
-        hipLaunchKernelGGL(propagate_step_kernel<RoundF32>, dim3(nblk(hw, 256)), dim3(256), 0, s, (const half_t*)feat_prev,
+        hipLaunchKernelGGL((propagate_step_kernel<RoundF32, half_t>), dim3(nblk(hw, 256)), dim3(256), 0, s, (const half_t*)feat_prev,
                            (const half_t*)feat_cur, (const half_t*)flow_prop, (const half_t*)flow_check, (half_t*)out, c, h,
                            w, (long long)feat_chan_stride, (long long)flow_chan_stride, nearest, fuse_scale, alpha1, alpha2);
+    return uav_launch_status();
+}
+
+// fp32 planes, fp32 flows, fp32 coordinates: the arithmetic of the reference's fp32 run (pipeline:651 casts the flows to the
+// latent dtype, so an fp32 pipeline warps fp32 values on fp32 grids).
+extern "C" int uav_propagate_step_f32(const float* feat_prev, const float* feat_cur, const float* flow_prop,
+                                      const float* flow_check, float* out, int32_t c, int32_t h, int32_t w,
+                                      int64_t feat_chan_stride, int64_t flow_chan_stride, int32_t nearest, float fuse_scale,
+                                      float alpha1, float alpha2, void* stream) {
+    if (!feat_prev || !feat_cur || !flow_prop || !flow_check || !out) return UAV_EINVAL;
+    if (c <= 0 || h <= 0 || w <= 0) return UAV_ESHAPE;
+    const long long hw = (long long)h * w;
+    if (feat_chan_stride < hw || flow_chan_stride < hw) return UAV_ESHAPE;
+    hipLaunchKernelGGL((propagate_step_kernel<RoundF32, float>), dim3(nblk(hw, 256)), dim3(256), 0, (hipStream_t)stream,
+                       feat_prev, feat_cur, flow_prop, flow_check, out, c, h, w, (long long)feat_chan_stride,
+                       (long long)flow_chan_stride, nearest, fuse_scale, alpha1, alpha2);
     return uav_launch_status();
 }

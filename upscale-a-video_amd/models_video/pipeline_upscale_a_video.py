@@ -338,8 +338,9 @@ class VideoUpscalePipeline(ConfigMixin):
                 self.__dict__["_pe_branch"] = hit
             pe_branch = hit[2]
         if flows_bi is not None and len(propagation_steps) > 0:
-            flows_f = flows_bi[0].to(device=device, dtype=torch.float16)
-            flows_b = flows_bi[1].to(device=device, dtype=torch.float16)
+            # reference :651: `flows_bi[k].to(latents)` — the flows follow the latent dtype
+            flows_f = flows_bi[0].to(device=device, dtype=lat_dtype)
+            flows_b = flows_bi[1].to(device=device, dtype=lat_dtype)
 
         for i, t in enumerate(timesteps):
             lin = torch.cat([latents] * 2) if do_cfg else latents
@@ -385,8 +386,9 @@ class VideoUpscalePipeline(ConfigMixin):
             else:
                 guided, x0 = self.scheduler.cfg_step_v0(eps, None, 1.0, t, latents)
             if flows_bi is not None and i in propagation_steps:
-                # the propagation kernel replays the reference's fp16 warp (bit-exact against it on half tensors)
-                x0 = self.propagator(x0.to(torch.float16), flows_f, flows_b, interpolation="nearest", mode="fuse",
+                # fp16 latents: the kernel replays the reference's fp16 warp (bit-exact against it on half tensors);
+                # fp32 latents: fp32 values on fp32 grids, held to the reference's fp32 run (no rounding of the trajectory)
+                x0 = self.propagator(x0, flows_f, flows_b, interpolation="nearest", mode="fuse",
                                      fuse_scale=0.5, alpha1=0.001, alpha2=0.05).to(lat_dtype).contiguous()
             latents = self.scheduler.step_vt(x0, guided, t, latents).prev_sample
             if self.latents_trace is not None:        # test hook: per-step latents (error-vs-step curves)

@@ -9,7 +9,9 @@ warp of the propagated frame, fuse, mask blend) is ONE kernel launch `uav_propag
 working in place on frame planes of the (1,C,T,H,W) tensor: 2*(T-1) launches per call instead of
 ~25 ATen ops per step.  For fp16 latents the grid arithmetic is replayed in fp16 exactly as the
 reference's GPU path evaluates it (grid built in the latent dtype, :123-132), because the
-nearest-neighbour index is discontinuous in the coordinates.
+nearest-neighbour index is discontinuous in the coordinates; fp32 latents (the UNet on an fp32
+residual stream) are warped unrounded on fp32 grids (`uav_propagate_step_f32`), which is what the
+reference's fp32 run computes.
 """
 import torch
 import torch.nn as nn
@@ -51,10 +53,15 @@ class Propagation(nn.Module):
             fuse_scale = 1.0
         elif mode != "fuse":
             raise ValueError(mode)
+        # The reference casts the flows to the latent dtype (pipeline:651) and builds the grid in it (:123): a half
+        # pipeline warps fp16 values on fp16 grids, an fp32 one fp32 values on fp32 grids.  Same here: fp32 latents go
+        # through `uav_propagate_step_f32` unrounded; `coord_f16 = True` on fp32 input forces the fp16 replay (values
+        # rounded to fp16 as well — what round 3 did unconditionally).
         coord_f16 = (x.dtype == torch.float16) if self.coord_f16 is None else self.coord_f16
-        xin = x.half().contiguous()
-        ff = flows_forward.half().contiguous()
-        fb = flows_backward.half().contiguous()
+        work = torch.float32 if (x.dtype == torch.float32 and not coord_f16) else torch.float16
+        xin = x.to(work).contiguous()
+        ff = flows_forward.to(work).contiguous()
+        fb = flows_backward.to(work).contiguous()
         nearest = interpolation == "nearest"
         fcs, wcs = t * h * w, (t - 1) * h * w
         kw = dict(c=c, h=h, w=w, feat_chan_stride=fcs, flow_chan_stride=wcs, nearest=nearest, coord_f16=coord_f16,

@@ -91,7 +91,10 @@ SIGNATURES = {
     "uav_corr_lookup_f32": (C.c_int, [C.POINTER(c_p), C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), c_p, i32, c_p, i32, i64, i32, c_p]),
     "uav_convex_upsample_f32": (C.c_int, [c_p, i32, c_p, c_p, i32, i32, i32, c_p]),
     "uav_propagate_step_f16": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i64, i64, i32, i32, f32, f32, f32, c_p]),
+    "uav_propagate_step_f32": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i64, i64, i32, f32, f32, f32, c_p]),
 }
+
+EXPECTED_ABI = 5          # include/uav_hip.h UAV_ABI_VERSION this binding was written against
 
 
 class UavError(RuntimeError):
@@ -126,6 +129,11 @@ def load(build_if_missing=True):
         fn = getattr(lib, name)          # AttributeError if an exported symbol is missing
         fn.restype = res
         fn.argtypes = args
+    lib.uav_version.restype = C.c_int
+    if lib.uav_version() != EXPECTED_ABI:
+        # a stale build or a UAV_HIP_LIB override of another ABI would read past the parameter structs it knows
+        raise UavError(f"{path}: ABI version {lib.uav_version()} != {EXPECTED_ABI} expected by this binding — rebuild "
+                       "(python __graft_entry__.py)")
     _LIB = lib
     return lib
 

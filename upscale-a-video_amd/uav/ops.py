@@ -735,11 +735,20 @@ def sft_fuse(dec, scale, shift, w, out_f32=False):
 def propagate_step(feat_prev, feat_cur, flow_prop, flow_check, out, *, c, h, w, feat_chan_stride, flow_chan_stride,
                    nearest, coord_f16, fuse_scale, alpha1, alpha2):
     """One recurrence step of the flow-guided propagation.  The tensors are (possibly strided) views
-    of (C,T,H,W) fp16 buffers: frame planes are addressed in place through the channel strides."""
+    of (C,T,H,W) fp16 buffers — or all-fp32 ones (fp32 values, flows and grid arithmetic: the reference's fp32 run) —
+    frame planes are addressed in place through the channel strides."""
     lib = _lib.load()
+    dt = out.dtype
     for t_ in (feat_prev, feat_cur, flow_prop, flow_check, out):
-        if not t_.is_cuda or t_.dtype != HALF:
-            raise _lib.UavError("propagate_step: fp16 GPU tensors expected")
+        if not t_.is_cuda or t_.dtype != dt or dt not in (HALF, torch.float32):
+            raise _lib.UavError("propagate_step: fp16 (or all-fp32) GPU tensors expected")
+    if dt == torch.float32:
+        if coord_f16:
+            raise _lib.UavError("propagate_step: fp32 planes are warped on fp32 grids (coord_f16 is the fp16-latent replay)")
+        rc = lib.uav_propagate_step_f32(_p(feat_prev), _p(feat_cur), _p(flow_prop), _p(flow_check), _p(out), c, h, w,
+                                        feat_chan_stride, flow_chan_stride, int(nearest), fuse_scale, alpha1, alpha2, _stream())
+        _lib.check(rc, "uav_propagate_step_f32")
+        return out
     rc = lib.uav_propagate_step_f16(_p(feat_prev), _p(feat_cur), _p(flow_prop), _p(flow_check), _p(out), c, h, w,
                                     feat_chan_stride, flow_chan_stride, int(nearest), int(coord_f16), fuse_scale,
                                     alpha1, alpha2, _stream())
