@@ -261,6 +261,10 @@ int uav_axpby_f16(const void* x, const void* z, void* y, int64_t n, float a, flo
 
 /* fp32 rows -> fp16 rows (fp32 residual stream of the VAE decoder feeding a conv operand; x, y 16-B aligned) */
 int uav_cast_f32_f16(const float* x, void* y, int64_t n, void* stream);
+/* ABI v5.  fp32 rows [rows][c] -> fp16 rows [rows][2c] = [hi | lo], hi = fp16(x), lo = fp16(x - hi): the fp32 residual stream as
+ * two MFMA operands (K doubled, weights repeated along C_in) for the convs that read it directly — the down / up samplers
+ * (resnet.py:104-197) with UAV_SAMPLER_HILO=1; c % 8 == 0. */
+int uav_cast_f32_hilo(const float* x, void* y, int64_t rows, int32_t c, void* stream);
 /* SFT fusion of the video VAE (Fuse_sft_block, resnet.py:76-78): out = dec + w*(dec*scale + shift), elementwise;
  * in_f32 / out_f32 select fp32 instead of fp16 for the three inputs / the output */
 int uav_sft_fuse(const void* dec, const void* scale, const void* shift, void* out, int64_t n, float w,

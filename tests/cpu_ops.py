@@ -272,6 +272,11 @@ def cast_f16(x):
     return x if x.dtype == HALF else _h(x)
 
 
+def cast_hilo(x):
+    hi = _h(x)
+    return torch.cat([hi, _h(x.float() - hi.float())], dim=-1)
+
+
 def sft_fuse(dec, scale, shift, w, out_f32=False):
     assert dec.dtype == scale.dtype == shift.dtype
     d = dec.float()
@@ -279,7 +284,7 @@ def sft_fuse(dec, scale, shift, w, out_f32=False):
     return y if out_f32 else _h(y)
 
 
-_OPS = ("ln_fold_ok", "resize_area_f32", "cast_f16", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "temporal_attention", "linear_small",
+_OPS = ("ln_fold_ok", "resize_area_f32", "cast_f16", "cast_hilo", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "temporal_attention", "linear_small",
         "timestep_embedding", "pack_nhwc", "unpack_ncthw", "axpby", "cfg_ddim_v0", "ddim_vt")
 
 

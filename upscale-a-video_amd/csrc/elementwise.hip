@@ -172,6 +172,24 @@ __global__ __launch_bounds__(256) void cast_f32_f16_kernel(const float* __restri
     }
 }
 
+// fp32 rows [M][C] -> fp16 rows [M][2C] = [hi | lo], hi = fp16(x), lo = fp16(x - hi): the stream as TWO MFMA operands (K
+// doubled, weights repeated) where a conv reads it directly (down / up samplers); 8 elements per thread, C % 8 == 0.
+__global__ __launch_bounds__(256) void cast_f32_hilo_kernel(const float* __restrict__ x, half_t* __restrict__ y, long long rows, int c) {
+    const int per_row = c / 8;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * per_row) return;
+    const long long r = i / per_row;
+    const int k = (int)(i % per_row) * 8;
+    const float* src = x + r * c + k;
+    const float4_t a = *(const float4_t*)src, b = *(const float4_t*)(src + 4);
+    const float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    half8_t hi, lo;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { hi[j] = (half_t)v[j]; lo[j] = (half_t)(v[j] - (float)hi[j]); }
+    *(half8_t*)(y + r * 2 * c + k) = hi;
+    *(half8_t*)(y + r * 2 * c + c + k) = lo;
+}
+
 // SFT fusion of the video VAE (Fuse_sft_block, resnet.py:76-78): out = dec + w*(dec*scale + shift) = dec*(1 + w*scale) + w*shift
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void sft_fuse_kernel(const TI* __restrict__ dec, const TI* __restrict__ scale,
@@ -374,6 +392,15 @@ extern "C" int uav_cast_f32_f16(const float* x, void* y, int64_t n, void* stream
     if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return UAV_EALIGN;
     hipLaunchKernelGGL(cast_f32_f16_kernel, dim3(nblk((n + 7) / 8, 256)), dim3(256), 0, (hipStream_t)stream, x, (half_t*)y,
                        (long long)n);
+    return uav_launch_status();
+}
+
+extern "C" int uav_cast_f32_hilo(const float* x, void* y, int64_t rows, int32_t c, void* stream) {
+    if (!x || !y || rows <= 0 || c <= 0) return UAV_EINVAL;
+    if (c % 8) return UAV_ESHAPE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)y & 15)) return UAV_EALIGN;
+    hipLaunchKernelGGL(cast_f32_hilo_kernel, dim3(nblk(rows * (c / 8), 256)), dim3(256), 0, (hipStream_t)stream, x, (half_t*)y,
+                       (long long)rows, c);
     return uav_launch_status();
 }
 

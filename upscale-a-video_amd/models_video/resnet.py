@@ -42,10 +42,11 @@ class InflatedConv3d(nn.Conv2d, E.EngineModule):
     """Per-frame 2-D convolution on a video tensor (reference resnet.py:94-101)."""
 
     def run(self, x, g: E.Geom, *, x2=None, residual=None, out_scale=1.0, upsample=False, out_f32=False, rowbias=None,
-            out_hw=None, out=None, gn_groups=None):
+            out_hw=None, out=None, gn_groups=None, hilo=False):
         """gn_groups: the output is (probably) normalised next by a GroupNorm of that many groups — the epilogue then
-        reduces its statistics partials where it can (ops.conv_gemm); a wrong guess only costs the unused partials."""
-        cw = E.packed_conv(self, "w", self)
+        reduces its statistics partials where it can (ops.conv_gemm); a wrong guess only costs the unused partials.
+        hilo: x carries [hi | lo] fp16 halves of fp32 rows (2*C_in channels per pixel), the weights are repeated along C_in."""
+        cw = E.packed_conv_dup(self, "w", self) if hilo else E.packed_conv(self, "w", self)
         return ops.conv_gemm(x, cw, a2=x2, n_img=g.n_img, t_len=g.t, hi=g.h, wi=g.w, stride=self.stride[0],
                              pad=(0, self.padding[0], self.padding[1]), upsample=upsample, residual=residual,
                              out_scale=out_scale, out_f32=out_f32, rowbias=rowbias, rows_per_batch=g.rows_per_batch,
@@ -92,13 +93,14 @@ class Upsample3D(E.EngineModule):
     def run(self, x, g: E.Geom, output_size=None):
         conv = self.conv if self.name == "conv" else self.Conv2d_0
         s32 = x.dtype == torch.float32           # fp32 residual stream (VAE decoder): x is also this conv's operand
-        x = ops.cast_f16(x)
+        hilo = s32 and E.SAMPLER_HILO and self.channels % 64 == 0
+        x = E.hilo_rows(x) if hilo else ops.cast_f16(x)
         if output_size is None or tuple(output_size[-2:]) == (2 * g.h, 2 * g.w):
             g2 = g.with_hw(2 * g.h, 2 * g.w)
             if not PHASE_UPSAMPLE or tuple(conv.kernel_size) != (3, 3) or tuple(conv.padding) != (1, 1):
-                return conv.run(x, g, upsample=True, out_f32=s32, gn_groups=E.GN_GROUPS_HINT), g2
+                return conv.run(x, g, upsample=True, out_f32=s32, gn_groups=E.GN_GROUPS_HINT, hilo=hilo), g2
             # four 2x2 convs on the low-resolution rows, each writing its sub-pixel phase of the output in place
-            cws = E.packed_upsample_phases(conv, "w", conv)
+            cws = E.packed_upsample_phases(conv, "w", conv, dup=hilo)
             out = torch.empty((g2.rows, self.out_channels), dtype=torch.float32 if s32 else torch.float16, device=x.device)
             for py in range(2):
                 for px in range(2):
@@ -113,7 +115,7 @@ class Upsample3D(E.EngineModule):
         ho, wo = int(output_size[-2]), int(output_size[-1])
         idx = self._nearest_rows(g, ho, wo, x.device)
         g2 = g.with_hw(ho, wo)
-        return conv.run(x.index_select(0, idx), g2, out_f32=s32, gn_groups=E.GN_GROUPS_HINT), g2
+        return conv.run(x.index_select(0, idx), g2, out_f32=s32, gn_groups=E.GN_GROUPS_HINT, hilo=hilo), g2
 
     def _nearest_rows(self, g, ho, wo, device):
         key = (g.n_img, g.h, g.w, ho, wo, str(device))
@@ -150,13 +152,14 @@ class Downsample3D(E.EngineModule):
 
     def run(self, x, g: E.Geom):
         s32 = x.dtype == torch.float32           # fp32 residual stream: x is this conv's MFMA operand, the output is stream
-        x = ops.cast_f16(x)
+        hilo = s32 and E.SAMPLER_HILO and self.channels % 64 == 0
+        x = E.hilo_rows(x) if hilo else ops.cast_f16(x)
         if self.padding == 0:
             # reference pads (0,1,0,1) then convolves with pad 0 (resnet.py:188-192): the right /
             # bottom taps that fall outside read zeros in the gather, no padded copy is made
             g2 = g.with_hw((g.h + 1 - 3) // 2 + 1, (g.w + 1 - 3) // 2 + 1)
-            return self.conv.run(x, g, out_hw=(g2.h, g2.w), out_f32=s32, gn_groups=E.GN_GROUPS_HINT), g2
-        return self.conv.run(x, g, out_f32=s32, gn_groups=E.GN_GROUPS_HINT), self.conv.out_geom(g)
+            return self.conv.run(x, g, out_hw=(g2.h, g2.w), out_f32=s32, gn_groups=E.GN_GROUPS_HINT, hilo=hilo), g2
+        return self.conv.run(x, g, out_f32=s32, gn_groups=E.GN_GROUPS_HINT, hilo=hilo), self.conv.out_geom(g)
 
     def forward(self, hidden_states):
         rows, g = E.to_rows(hidden_states, c_pad=self.channels)

@@ -73,6 +73,7 @@ SIGNATURES = {
     "uav_ddim_vt_f32": (C.c_int, [c_p, c_p, c_p, c_p, i64, f32, f32, f32, f32, f32, i32, f32, c_p]),
     "uav_axpby_f16": (C.c_int, [c_p, c_p, c_p, i64, f32, f32, c_p]),
     "uav_cast_f32_f16": (C.c_int, [c_p, c_p, i64, c_p]),
+    "uav_cast_f32_hilo": (C.c_int, [c_p, c_p, i64, i32, c_p]),
     "uav_sft_fuse": (C.c_int, [c_p, c_p, c_p, c_p, i64, f32, i32, i32, c_p]),
     "uav_plane_stats_workspace_bytes": (i64, [i32]),
     "uav_plane_stats_f32": (C.c_int, [c_p, i32, i64, c_p, c_p, c_p, i64, c_p]),

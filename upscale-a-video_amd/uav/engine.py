@@ -173,6 +173,22 @@ def packed_conv_hilo(mod: EngineModule, name, conv: nn.Module):
     return mod._cache().get(("conv_hilo", name), build, (conv.weight, conv.bias))
 
 
+def packed_conv_dup(mod: EngineModule, name, conv: nn.Module):
+    """Any conv whose operand arrives as [hi | lo] halves per pixel (2*C_in channels): the weights repeated along C_in."""
+    def build():
+        dev = _dev(conv.weight)
+        w = conv.weight.detach()
+        cw = ops.pack_conv(torch.cat([w, w], dim=1), conv.bias, device=dev)
+        cw.cin = w.shape[1]
+        return cw
+    return mod._cache().get(("conv_dup", name), build, (conv.weight, conv.bias))
+
+
+def hilo_rows(x):
+    """fp32 rows [M][C] -> fp16 rows [M][2C] = [fp16(x) | fp16(x - fp16(x))]."""
+    return ops.cast_hilo(x)
+
+
 def packed_conv_with_shortcut(mod: EngineModule, name, conv: nn.Module, shortcut: nn.Module, repeat_short):
     """conv2 of a ResNet block with its 1x1 shortcut conv folded in as extra K (ops.pack_conv_with_shortcut)."""
     def build():
@@ -181,13 +197,15 @@ def packed_conv_with_shortcut(mod: EngineModule, name, conv: nn.Module, shortcut
     return mod._cache().get(("conv+shortcut", name, repeat_short), build, (conv.weight, conv.bias, shortcut.weight, shortcut.bias))
 
 
-def packed_upsample_phases(mod: EngineModule, name, conv: nn.Module):
+def packed_upsample_phases(mod: EngineModule, name, conv: nn.Module, dup=False):
     """The four 2x2 sub-pixel phase convs of an upsampler's 3x3 conv, packed ([py][px], see ops.upsample_phase_weights)."""
     def build():
         dev = _dev(conv.weight)
         ph = ops.upsample_phase_weights(conv.weight)
+        if dup:
+            ph = [[torch.cat([ph[py][px]] * 2, dim=1) for px in range(2)] for py in range(2)]
         return [[ops.pack_conv(ph[py][px], conv.bias, device=dev) for px in range(2)] for py in range(2)]
-    return mod._cache().get(("up_phases", name), build, (conv.weight, conv.bias))
+    return mod._cache().get(("up_phases", name, dup), build, (conv.weight, conv.bias))
 
 
 def packed_cat(mod: EngineModule, name, linears):
@@ -236,6 +254,9 @@ SHORTCUT_HILO = _os.environ.get("UAV_SHORTCUT_HILO", "1") != "0"
 # ... and is that shortcut conv folded into the block's conv2 (one implicit GEMM over K = 9*C + C_in: no separate launch, no fp32
 # shortcut tensor written and read back as the residual) (1) or a launch of its own (0)?  UAV_FUSE_SHORTCUT, default 1.
 FUSE_SHORTCUT = _os.environ.get("UAV_FUSE_SHORTCUT", "1") != "0"
+# ... and do the down / up SAMPLER convs (3x3 stride 2; nearest-2x + 3x3 as four 2x2 phase convs), the other place where the
+# stream itself is an MFMA operand, read it as the same hi + lo pair (K doubled on 6 convs per forward)?  UAV_SAMPLER_HILO.
+SAMPLER_HILO = _os.environ.get("UAV_SAMPLER_HILO", "0") != "0"
 
 
 # Group count a conv assumes for the GroupNorm that (probably) consumes its output when the caller cannot name that

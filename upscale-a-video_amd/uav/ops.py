@@ -719,6 +719,18 @@ def cast_f16(x):
     return y
 
 
+def cast_hilo(x):
+    """fp32 rows [M][C] -> fp16 rows [M][2C] = [fp16(x) | fp16(x - fp16(x))]."""
+    lib = _lib.load()
+    _req(x, torch.float32, "x")
+    m, c = x.shape
+    y = torch.empty((m, 2 * c), dtype=HALF, device=x.device)
+    ev = PROFILER.begin("cast_f16")
+    _lib.check(lib.uav_cast_f32_hilo(_p(x), _p(y), m, c, _stream()), "uav_cast_f32_hilo")
+    PROFILER.end(ev, "cast_f16", 0.0, 8.0 * x.numel())
+    return y
+
+
 def sft_fuse(dec, scale, shift, w, out_f32=False):
     """dec + w*(dec*scale + shift) (Fuse_sft_block); inputs all fp16 or all fp32."""
     lib = _lib.load()
