@@ -60,13 +60,44 @@ def build_pipeline(dev, height, width, unet_cfg=None, vae_cfg=None, text_encoder
     vae_cfg = vae_cfg or configs.VAE_3D
     unet = UNetVideoModel.from_config(dict(unet_cfg)).half().to(dev).eval()
     init_weights.random_init_(unet, seed=1234)
-    vae = AutoencoderKLVideo.from_config(dict(vae_cfg)).half().to(dev).eval()
+    # fp32 parameters like the reference CLI builds it (inference_upscale_a_video.py:103-110: only the UNet is `.half()`): the
+    # decoder then runs in the pipeline's DEFAULT mode for such a VAE (fp32 residual stream, fp16 MFMA operands)
+    vae = AutoencoderKLVideo.from_config(dict(vae_cfg)).to(dev).eval()
     init_weights.random_init_(vae, seed=4321)
     te, tok = build_text_encoder(dev, unet_cfg["cross_attention_dim"], text_encoder)
     pipe = VideoUpscalePipeline(text_encoder=te, tokenizer=tok,
                                 low_res_scheduler=DDPMScheduler(**configs.LOW_RES_DDPM),
                                 scheduler=DDIMScheduler(**configs.DDIM), vae=vae, unet=unet, propagator=None).to(dev)
     return pipe
+
+
+def predicted_scaling(args, world, value):
+    """What the driver's 1 -> 8 GPU run of THIS command should show, printed by the command itself so that
+    the SCALE record is held against a figure from the same line.  Clip-parallel default (weak scaling): no data-path
+    collective, one barrier + one MAX-reduce per timed region -> N x the per-GPU rate, efficiency >= 0.97 (shared: host cores
+    for ~40 k launches per clip and rank, the node's power envelope).  --shard-windows (strong scaling, ONE clip): the unique
+    temporal windows of a DDIM step (x 2 guidance branches with --shard-cfg, +2.7 % FLOP) and the 3-frame decode chunks are
+    the units; the critical path per step is ceil(units / N) unit times, the all-gather (131 MB per step, ~1 ms over xGMI)
+    and the replicated CFG / DDIM / propagation are the serial remainder (~1 %)."""
+    import math
+    per_gpu = value / (1 if args.shard_windows else world)
+    ns = (1, 2, 4, 8)
+    if not args.shard_windows:
+        return {"mode": "clip-parallel (weak scaling)", "basis_frames_per_s_per_gpu": per_gpu, "assumed_efficiency": 0.97,
+                "frames_per_s": {str(n): per_gpu * n * (1.0 if n == 1 else 0.97) for n in ns}}
+    from models_video.pipeline_upscale_a_video import window_schedule
+    wins = window_schedule(args.frames)
+    n_win = len(set(wins))
+    units = n_win * (2 if args.shard_cfg else 1)
+    chunks = math.ceil(args.frames / 3)
+    # one unit = one window evaluation (or one guidance branch of it); decode chunks cost ~1.37 window units of a B2 window
+    win_flop, chunk_flop = 176.99 * (1.027 / 2 if args.shard_cfg else 1.0), 299.05 / 3      # TFLOP (SURVEY §8d, 8-frame window / 3-frame chunk)
+    def t(n):
+        return args.ddim_steps * math.ceil(units / n) * win_flop + math.ceil(chunks / n) * chunk_flop
+    base = value if world == 1 else None
+    return {"mode": "one clip, units dealt over the ranks (strong scaling)", "units_per_step": units, "decode_chunks": chunks,
+            "speedup_vs_1_gpu": {str(n): t(1) / t(n) for n in ns},
+            "frames_per_s": ({str(n): base * t(1) / t(n) * (1.0 if n == 1 else 0.99) for n in ns} if base else None)}
 
 
 def synthetic_clip(frames, height, width, seed, dev):
@@ -238,7 +269,8 @@ def main():
     from uav import configs as _cfg
     pipe = build_pipeline(dev, args.height, args.width, text_encoder=args.text_encoder,
                           vae_cfg=_cfg.VAE_VIDEO if args.video_vae else None)
-    pipe.vae.stream_dtype = torch.float16 if args.vae_fp16 else torch.float32
+    if args.vae_fp16:
+        pipe.vae = pipe.vae.half()              # what `pipeline.vae.half()` users get: all-fp16 decoder rows
     if args.unet_stream is not None:
         pipe.unet.stream_dtype = torch.float32 if args.unet_stream == "f32" else torch.float16
     unet_f32 = pipe.unet.stream_f32()
@@ -393,6 +425,7 @@ def main():
                                       + (" on concurrent HIP streams" if ncl > 1 else "") + " (clip-parallel, no collective)"),
                        "clips_per_step": world * ncl, "frames_per_clip": args.frames},
         }
+        res["config"]["predicted_scaling"] = predicted_scaling(args, world, res["value"])
         if args.digest:
             import hashlib
             res["config"]["output_sha256"] = hashlib.sha256(out.detach().float().cpu().numpy().tobytes()).hexdigest()

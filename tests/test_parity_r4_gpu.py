@@ -4,8 +4,8 @@ against the fp32 oracle pipeline executed on the same GPU (oracle/gpu_shim.py: A
 exact-fp32 GEMMs; test infrastructure, never the product path).
 
   * configs[1]: per-step latents curve over the whole schedule, `.images` as all-pixel AND unsaturated rel-L2;
-  * configs[2]: the same with flow-guided propagation at DDIM steps 24/26/28; the flows come from the engine's own RAFT_bi
-    and are fed to BOTH sides (RAFT itself is pinned in tests/test_raft_gpu.py), the oracle replays steps 0..23 from the
+  * configs[2]: the same with flow-guided propagation at DDIM steps 24/26/28 on consistent synthetic flows fed to BOTH
+    sides (RAFT itself is pinned in tests/test_raft_gpu.py; see build_flows), the oracle replays steps 0..23 from the
     configs[1] run (identical until the first propagation step) — reference pipeline_upscale_a_video.py:651-657,
     propagation_module.py:104-135,194-281 in fp32, which is the run an fp32-latent engine is held to.
 
@@ -65,19 +65,18 @@ def build_models(dev):
     return unet, usd, vae, vsd
 
 
-def build_flows(dev, clip):
-    """Flows of the engine's own RAFT_bi (seeded weights, flow head damped so the flows stay in a few-pixel range)."""
-    import synth
-    from models_video.RAFT.raft_bi import RAFT_bi
-    rb = RAFT_bi(model_path=None, device="cpu")
-    rsd = synth.synth_state_dict(rb.fix_raft.state_dict(), seed=777)
-    for k in ("update_block.flow_head.conv2.weight", "update_block.flow_head.conv2.bias"):
-        rsd[k] = rsd[k] * 0.05
-    rb.fix_raft.load_state_dict(rsd)
-    rb = rb.to(dev)
-    with torch.no_grad():
-        ff, fb = rb.forward_slicing(clip.to(dev), iters=20)
-    return [ff.float().contiguous(), fb.float().contiguous()]
+def build_flows(dev):
+    """Bidirectional flows at the latent resolution that are CONSISTENT (so the forward-backward check passes and frames are
+    actually warped): the clip's (2.3, 1.3) px/frame translation with small noise, fp16-representable, plus a band where the
+    backward flow contradicts the forward one (mask = 0 there).  Round 4, call 1 measured that flows of a random-weight
+    RAFT (what bench.py --propagation feeds) fail the consistency check everywhere — the propagation is then the identity
+    and tests nothing; RAFT itself is pinned in tests/test_raft_gpu.py against the reference's fixtures."""
+    g = torch.Generator().manual_seed(4242)
+    ff = torch.zeros(1, 2, T - 1, H, W); fb = torch.zeros(1, 2, T - 1, H, W)
+    ff[:, 0] = 2.3; ff[:, 1] = 1.3; fb[:, 0] = -2.3; fb[:, 1] = -1.3
+    ff = ff + 0.02 * torch.randn(ff.shape, generator=g); fb = fb + 0.02 * torch.randn(fb.shape, generator=g)
+    fb[:, :, :, H // 3: H // 2] += 3.0
+    return [ff.half().float().to(dev).contiguous(), fb.half().float().to(dev).contiguous()]
 
 
 def engine_run(dev, unet, vae, clip, flows=None, prop_steps=()):
@@ -140,7 +139,7 @@ def headline(dev):
     import synth
     clip = synth.synth_clip(1, T, H, W, seed=3, motion=(2, 1))
     unet, usd, vae, vsd = build_models(dev)
-    flows = build_flows(dev, clip)
+    flows = build_flows(dev)
     eng1 = engine_run(dev, unet, vae, clip)
     eng2 = engine_run(dev, unet, vae, clip, flows=flows, prop_steps=PROP_STEPS)
     torch.cuda.empty_cache()
@@ -170,13 +169,15 @@ def _check(name, eng, ora, bars):
 
 def test_headline_configs1_end_to_end_vs_gpu_oracle(headline):
     """BASELINE configs[1] (pipeline_upscale_a_video.py:436-716): latents after 30 steps inside the stated 1e-3."""
-    _check("r4_headline_configs1_8x320x320_30steps", headline["eng1"], headline["ora"]["c1"], bars=(1.0e-3, 2.0e-3))
+    # measured (round 4, call 1): latents 9.0e-4, images 1.075e-3 (all pixels) / 1.39e-3 (unsaturated) without the samplers'
+    # hi|lo operands; with them (default since) 8.2e-4, 9.5e-4 / 1.23e-3.  Both bars are BASELINE.json's stated 1e-3.
+    _check("r4_headline_configs1_8x320x320_30steps", headline["eng1"], headline["ora"]["c1"], bars=(1.0e-3, 1.0e-3))
 
 
 def test_headline_configs2_propagation_end_to_end_vs_gpu_oracle(headline):
     """BASELINE configs[2]: + RAFT flows and fp32 flow-guided propagation at steps 24/26/28 (same flows on both sides)."""
     eng, ora = headline["eng2"], headline["ora"]["c2"]
-    curve, e_lat, e_all, e_unsat = _check("r4_headline_configs2_8x320x320_30steps_propagation", eng, ora, bars=(1.0e-3, 2.0e-3))
+    curve, e_lat, e_all, e_unsat = _check("r4_headline_configs2_8x320x320_30steps_propagation", eng, ora, bars=(1.0e-3, 1.0e-3))
     # the propagation did something (vs the no-propagation run), and a nearest-neighbour index flip would show as an O(1)
     # difference on single elements: count them
     moved = rel_l2(eng["latents"], headline["eng1"]["latents"])
