@@ -4,7 +4,7 @@
 #   2. micro-benchmarks with the round-3 epilogues (tools/bench_epilogue.py), 30-iteration timings
 #   3. the headline clip, both kernels, same box
 cd "$(dirname "$0")/../.." && mkdir -p gpurun_out
-export TMPDIR=/tmp UAV_HIP_LIB=$PWD/tools/ab/libuav_hip_8phase.so UAV_CONV_TILE=256
+export TMPDIR=/tmp UAV_HIP_LIB=$PWD/tools/ab/libuav_hip_variant.so UAV_CONV_TILE=256
 L=gpurun_out/ab_conv_8phase.log
 : > $L
 for v in 1 8; do echo "digests UAV_CONV_DMAV=$v" | tee -a $L; UAV_CONV_DMAV=$v timeout 120 python tools/conv_digest.py 2>&1 | tail -1 | tee -a $L; done

@@ -85,6 +85,7 @@ def main():
             unet.stream_dtype = torch.float32 if mode.startswith("f32") else torch.float16      # "f32-bf16": fp32 stream, bf16 operands
             E.BRANCH_F32 = "branch16" not in mode
             E.TOKEN_F32 = "-tok16" not in mode
+            E.TAIL_HILO = "-hilotail" in mode
             E.SAMPLER_HILO = "down" if "-hilodown" in mode else "up" if "-hiloup" in mode else ("-hilosamp" in mode)   # product knob
             E.TOKEN_F32_MAX_HW = 256 if "toponly16" in mode else 0      # 64x64 input: levels 32x32 / 16x16 / 8x8 tokens per frame
             keep = set(mode.split("+")[1:])

@@ -1174,18 +1174,8 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
 //     path works while the matrix pipe does, and M0 (LDS destination) is written by s_add right before each.
 // Stage hand-over is unchanged (2 stages, vmcnt(0) + barrier per k-step), so the numerics and the tile walk are
 // bit-identical to the round-1 kernel (tests/test_fullsize_gpu.py compares them).
-//
-// V = 4 — EARLY RELEASE (round 4).  With two 64-KiB stages and ONE hand-over point per k-step the DMA of stage k+1 cannot be
-// issued before the barrier that opens k-step k and has to land before the next one: its round trip (~1.3 us from the L2
-// under this load, 64 x 1 KiB through the CU's 64 B/clk vector-memory path included) is LONGER than the 2 048 matrix-pipe
-// cycles of a k-step (~1.1 us), so the loop ran at the DMA latency, not at the MFMA rate (k-step 2.05 us, pipe 42-47 % busy).
-// Here a second barrier at 3/4 of the k-step — all fragment reads of the stage are complete by then, the last 8 MFMAs run on
-// registers — RELEASES the stage buffer early: the DMA of stage k+2 goes into it during the last quarter of k-step k, i.e. a
-// full k-step + a quarter ahead of its first read, and the loop-top wait becomes `vmcnt(8)` (stage k+1 may still fly), never 0
-// before the last k-step.  Same LDS image, fragment reads, accumulation order and epilogue: bit-identical results.
 template <int V, int GNK = 0, int LNF = 0>
 __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
-    constexpr bool ER = V == 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1307,25 +1297,18 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
     const unsigned ldsepi = ldsb + 2 * LSTAGE;
     float4_t stg = {0.f, 0.f, 0.f, 0.f};
     unsigned stg_dst = 0;                                // 0 = this thread stages nothing
-    const float* stg_src = nullptr;
     if (tid < 64) {
-        if (p.bias) { stg_src = p.bias + n0 + 4 * tid; stg_dst = ldsepi + tid * 16; }
+        if (p.bias) { stg = *(const float4_t*)(p.bias + n0 + 4 * tid); stg_dst = ldsepi + tid * 16; }
     } else if (LNF == 2 && tid < 128) {              // LayerNorm-fold consumer: colsum(W') of the tile's columns takes row block 0
         const int piece = tid - 64;
-        stg_src = p.lnc_colsum + n0 + 4 * piece;
+        stg = *(const float4_t*)(p.lnc_colsum + n0 + 4 * piece);
         stg_dst = ldsepi + 1024 + piece * 16;
     } else if (tid < 320 && p.rowbias) {
         const int blk = (tid - 64) >> 6, piece = (tid - 64) & 63;
         long long mrow = m0 + blk * 64; if (mrow >= p.M) mrow = 0;
         const int col = n0 + 4 * piece;
-        if (col + 4 <= p.n) stg_src = p.rowbias + (long long)((int)(mrow / p.rows_per_batch)) * p.rowbias_stride + col;
+        if (col + 4 <= p.n) stg = *(const float4_t*)(p.rowbias + (long long)((int)(mrow / p.rows_per_batch)) * p.rowbias_stride + col);
         stg_dst = ldsepi + 1024 + blk * 1024 + piece * 16;
-    }
-    if (stg_src) {
-        // ER: by inline asm — hipcc must not know this load, or it puts `s_waitcnt vmcnt(0)` in front of the LDS store below
-        // and drains the two stages of DMA issued in between (the kernel counts vmcnt itself)
-        if (ER) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stg) : "v"(stg_src) : "memory");
-        else stg = *(const float4_t*)stg_src;
     }
 
     // LDS-DMA pieces of one stage: X rows ps*64.. -> +ps*8 KiB, W rows likewise behind the 32-KiB X tile.  M0 carries
@@ -1356,20 +1339,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
                      : [m0s] "=&s"(m0s) : DMA_OPERANDS : "memory", "scc", "vcc");
     }
     if (nk > 1) COMPUTE_ADDR()
-    if (ER) {
-        if (nk > 1) {                                    // stage 1 -> buffer 1, then the addresses of stage 2 (issued in k-step 0)
-            const char* gw0 = wtile + wkb; const char* gw1 = gw0 + wps; const char* gw2 = gw1 + wps; const char* gw3 = gw2 + wps;
-            const unsigned ldsn = ldsw + LSTAGE, dodma = __builtin_amdgcn_readfirstlane(1u);
-            unsigned m0s;
-            asm volatile("s_mov_b32 %[m0s], m0\n" "s_cmp_lg_u32 %[dodma], 0\n" "s_cselect_b64 vcc, -1, 0\n"
-                         D0 D1 D2 D3 D4 D5 D6 D7 "s_mov_b32 m0, %[m0s]\n"
-                         : [m0s] "=&s"(m0s) : DMA_OPERANDS : "memory", "scc", "vcc");
-            if (nk > 2) COMPUTE_ADDR()
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");        // the epilogue constants (older than both stages) have arrived
-        } else {
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        }
-    }
     if (stg_dst) *(__attribute__((address_space(3))) float4_t*)(size_t)stg_dst = stg;
 
 #define RD(D, A, OFF) "ds_read_b128 %[" #D "], %[" #A "] offset:" #OFF "\n"
@@ -1395,27 +1364,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
 #define RD_OPERANDS                                                                                              \
     [aw0] "v"(aw0), [aw1] "v"(aw1), [aw2] "v"(aw2), [aw3] "v"(aw3), [ax0] "v"(ax0), [ax1] "v"(ax1), [ax2] "v"(ax2), [ax3] "v"(ax3)
 
-    // early release: k-step with the stage's second barrier after the third MFMA slice and the DMA of stage k+2 behind it
-#define KSTEP_ER(E0, E1, E2, E3)                                                               \
-    "s_waitcnt lgkmcnt(0)\n" RDSET(0, aw0, ax0) RDSET(1, aw1, ax1)                             \
-    MFSETD(0, 10, 9, 8, 7, 6, NO, NO, NO, NO) RDSET(0, aw2, ax2)                               \
-    MFSETD(1, 10, 9, 8, 7, 6, NO, NO, NO, NO) RDSET(1, aw3, ax3)                               \
-    MFSETD(0, 10, 9, 8, 7, 6, NO, NO, NO, NO)                                                  \
-    "s_waitcnt lgkmcnt(0)\n" "s_barrier\n"                                                     \
-    MFSETD(1, 0, 0, 0, 0, 0, E0, E1, E2, E3)
     int cur = 0;
     for (int ks = 0; ks < nk; ++ks) {
-        if (ER) {
-            // stage ks has landed; the 8 pieces of stage ks+1 (issued in the last quarter of k-step ks-1, or by the prologue) may
-            // still be in flight.  A bare s_barrier: __syncthreads() would bring hipcc's own vmcnt(0) with it.
-            if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
         const unsigned sb = cur * LSTAGE;
         const unsigned aw0 = bW + sb + so[0], aw1 = bW + sb + so[1], aw2 = bW + sb + so[2], aw3 = bW + sb + so[3];
         const unsigned ax0 = bX + sb + so[0], ax1 = bX + sb + so[1], ax2 = bX + sb + so[2], ax3 = bX + sb + so[3];
@@ -1423,19 +1375,14 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
         // ONE asm statement for every k-step (two statements in an if/else made the register allocator shuffle the 128
         // accumulators between them: 373 spilled VGPRs); the last k-step skips its DMA slots through VCC.
         const char* gw0 = wtile + wkb; const char* gw1 = gw0 + wps; const char* gw2 = gw1 + wps; const char* gw3 = gw2 + wps;
-        // ER: stage ks+2 goes into THIS k-step's buffer (released by the in-step barrier); else stage ks+1 into the other one
-        const unsigned ldsn = ldsw + (ER ? cur : (cur ^ 1)) * LSTAGE;
-        const unsigned dodma = __builtin_amdgcn_readfirstlane(ks + (ER ? 2 : 1) < nk ? 1u : 0u);      // must reach the asm in an SGPR
+        const unsigned ldsn = ldsw + (cur ^ 1) * LSTAGE;
+        const unsigned dodma = __builtin_amdgcn_readfirstlane(ks + 1 < nk ? 1u : 0u);      // must reach the asm in an SGPR
         unsigned m0s;
 #define KSTEP_STMT(...)                                                                                          \
         asm volatile("s_mov_b32 %[m0s], m0\n" "s_cmp_lg_u32 %[dodma], 0\n" "s_cselect_b64 vcc, -1, 0\n"         \
                      KSTEP(__VA_ARGS__) "s_mov_b32 m0, %[m0s]\n"                                                 \
                      : ACC_OPERANDS, [m0s] "=&s"(m0s) : RD_OPERANDS, DMA_OPERANDS : "memory", "scc", "vcc");
-        if constexpr (ER) {                // early release: all 8 pieces of stage ks+2 in the last quarter, two per MFMA pair
-            asm volatile("s_mov_b32 %[m0s], m0\n" "s_cmp_lg_u32 %[dodma], 0\n" "s_cselect_b64 vcc, -1, 0\n"
-                         KSTEP_ER(D0 D1, D2 D3, D4 D5, D6 D7) "s_mov_b32 m0, %[m0s]\n"
-                         : ACC_OPERANDS, [m0s] "=&s"(m0s) : RD_OPERANDS, DMA_OPERANDS : "memory", "scc", "vcc");
-        } else if constexpr (V == 1) {     // front-loaded: 2 while the first fragments are in flight, then one per MFMA pair
+        if constexpr (V == 1) {            // front-loaded: 2 while the first fragments are in flight, then one per MFMA pair
             KSTEP_STMT(D0 D1, D2, D3, D4, D5, D6, D7, NO, NO, NO, NO, NO, NO, NO, NO, NO, NO)
         } else if constexpr (V == 2) {     // one DMA every 4 MFMAs over the first 28
             KSTEP_STMT(D0, NO, D1, NO, D2, NO, D3, NO, D4, NO, D5, NO, D6, NO, D7, NO, NO)
@@ -1443,11 +1390,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
             KSTEP_STMT(D0, D1, D2, D3, NO, D4, NO, D5, NO, D6, NO, D7, NO, NO, NO, NO, NO)
         }
 #undef KSTEP_STMT
-        // addresses of stage ks+2 (ER: ks+3): VALU beside the matrix pipe's drain, off the post-barrier critical path
-        if (ks + (ER ? 3 : 2) < nk) COMPUTE_ADDR()
+        // addresses of stage ks+2: VALU beside the matrix pipe's drain, off the post-barrier critical path
+        if (ks + 2 < nk) COMPUTE_ADDR()
         cur ^= 1;
     }
-#undef KSTEP_ER
 #undef RD
 #undef RDSET
 #undef MF
@@ -1649,9 +1595,7 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
                                  (const void*)conv_gemm256i_kernel<1>, (const void*)conv_gemm256i_kernel<2>,
                                  (const void*)conv_gemm256i_kernel<3>, (const void*)conv_gemm256i_kernel<1, 1>,
                                  (const void*)conv_gemm256i_kernel<1, 2>, (const void*)conv_gemm256i_kernel<1, 3>,
-                                 (const void*)conv_gemm256i_kernel<1, 0, 1>, (const void*)conv_gemm256i_kernel<1, 0, 2>,
-                                 (const void*)conv_gemm256i_kernel<4>, (const void*)conv_gemm256i_kernel<4, 1>,
-                                 (const void*)conv_gemm256i_kernel<4, 2>, (const void*)conv_gemm256i_kernel<4, 3>};
+                                 (const void*)conv_gemm256i_kernel<1, 0, 1>, (const void*)conv_gemm256i_kernel<1, 0, 2>};
             for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE + LEPI_BYTES);
             hipDeviceProp_t prop;
             dev_ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
@@ -1661,12 +1605,7 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         a.ntiles = (unsigned)grid256;
         if (a.lnp_raw) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 0, 1>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
         else if (a.lnc_stat) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 0, 2>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
-        else if (a.gn_ws && env.dmav == 4) {       // early-release k-loop (UAV_CONV_DMAV=4), statistics-reducing instances
-            const int gnm = gn_mode_of(a.gn_cpg_log2);
-            if (gnm == 1) hipLaunchKernelGGL((conv_gemm256i_kernel<4, 1>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
-            else if (gnm == 2) hipLaunchKernelGGL((conv_gemm256i_kernel<4, 2>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
-            else hipLaunchKernelGGL((conv_gemm256i_kernel<4, 3>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
-        } else if (a.gn_ws) {              // statistics-reducing instances of the production kernel (other env A/B switches do not apply)
+        else if (a.gn_ws) {                // statistics-reducing instances of the production kernel (env A/B switches do not apply)
             const int gnm = gn_mode_of(a.gn_cpg_log2);
             if (gnm == 1) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 1>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
             else if (gnm == 2) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 2>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
@@ -1677,7 +1616,6 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         else if (dbg == 3) hipLaunchKernelGGL(conv_gemm256_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 5) hipLaunchKernelGGL(conv_gemm256_kernel<5>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 6) hipLaunchKernelGGL(conv_gemm256_kernel<6>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
-        else if (env.dmav == 4) hipLaunchKernelGGL(conv_gemm256i_kernel<4>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
         else if (env.dmav == 1) hipLaunchKernelGGL(conv_gemm256i_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
         else if (env.dmav == 2) hipLaunchKernelGGL(conv_gemm256i_kernel<2>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
         else if (env.dmav == 3) hipLaunchKernelGGL(conv_gemm256i_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);

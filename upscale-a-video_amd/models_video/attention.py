@@ -264,8 +264,13 @@ class Transformer3DModel(ModelMixin, ConfigMixin, E.EngineModule):
         tok32 = s32 and E.TOKEN_F32 and (E.TOKEN_F32_MAX_HW <= 0 or g.hw <= E.TOKEN_F32_MAX_HW)
         tok = ops.linear(n, E.packed_conv(self, "proj_in", self.proj_in), out_f32=tok32, ln_produce=tok32 and E.LN_FOLD)
         last = len(self.transformer_blocks) - 1
+        tail_hilo = tok32 and E.TAIL_HILO
         for i, blk in enumerate(self.transformer_blocks):
-            tok = blk.run(tok, g, ehs_rows, n_text, out_f32=False if i == last else None)   # proj_out reads it as an operand
+            # proj_out reads the last block's output as an operand: fp16, or (TAIL_HILO) the fp32 rows as a hi | lo pair
+            tok = blk.run(tok, g, ehs_rows, n_text, out_f32=False if (i == last and not tail_hilo) else None)
+        if tail_hilo:
+            return ops.linear(E.hilo_rows(tok), E.packed_conv_hilo(self, "proj_out", self.proj_out), residual=res, out_f32=s32,
+                              gn_groups=self.norm.num_groups)
         return ops.linear(tok, E.packed_conv(self, "proj_out", self.proj_out), residual=res, out_f32=s32,
                           gn_groups=self.norm.num_groups)
 

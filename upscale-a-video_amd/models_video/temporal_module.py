@@ -43,9 +43,13 @@ class TemporalModule3D(E.EngineModule):
     def run(self, x, g: E.Geom, temb=None, w=1.0):
         s32 = x.dtype == torch.float32           # fp32 residual stream (UNetVideoModel.stream_dtype)
         h = self.resblocks_3d_temporal.run(x, g, temb)
-        h = self.resblocks_3d_spatial.run(h, g, temb, out_f32=False)      # only read as shift_conv's MFMA operand
+        tail_hilo = s32 and E.TAIL_HILO and self.in_channels % 64 == 0
+        # the tail block's output is only read as shift_conv's MFMA operand: fp16, or (TAIL_HILO) fp32 rows as a hi | lo pair
+        h = self.resblocks_3d_spatial.run(h, g, temb, out_f32=None if tail_hilo else False)
         if w != 1.0:
             raise NotImplementedError("w != 1 is never used by the pipeline")
+        if tail_hilo:
+            return self.shift_conv.run(E.hilo_rows(h), g, residual=x, out_f32=s32, gn_groups=E.GN_GROUPS_HINT, hilo=True)
         return self.shift_conv.run(h, g, residual=x, out_f32=s32, gn_groups=E.GN_GROUPS_HINT)
 
     def forward(self, hidden_states, w=1, encoder_hidden_states=None, timesteps=None, temb=None, attention_mask=None):

@@ -260,6 +260,10 @@ FUSE_SHORTCUT = _os.environ.get("UAV_FUSE_SHORTCUT", "1") != "0"
 # profiles/r04_parity_precision_knobs_at_headline_shape_run1.jsonl) latents 9.0e-4 -> 8.2e-4 and `.images` (all pixels)
 # 1.075e-3 -> 9.5e-4, i.e. what puts the OUTPUT of the pipeline call inside the stated 1e-3.
 # "down" / "up" restrict it to one kind (numerics experiments).
+# ... and the block TAILS — the last feed-forward output of a Transformer3DModel (operand of proj_out) and the tail ResNet of a
+# TemporalModule3D (operand of shift_conv), fp16 tensors that carry a whole residual sum — as fp32 rows read through the same
+# hi | lo pair by their 1x1 consumer?  UAV_TAIL_HILO (CPU emulation: 7.5e-4 -> 6.5e-4 per forward).
+TAIL_HILO = _os.environ.get("UAV_TAIL_HILO", "0") != "0"
 SAMPLER_HILO = {"0": False, "1": True}.get(_os.environ.get("UAV_SAMPLER_HILO", "1"), _os.environ.get("UAV_SAMPLER_HILO", "1"))
 
 
