@@ -228,6 +228,8 @@ def main():
     ap.add_argument("--text-encoder", choices=["clip", "standin"], default="clip",
                     help="clip: ViT-H/14 text tower (random init) on the HIP kernels, run once per distinct prompt pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-throughput-mode", action="store_true",
+                    help="skip the extra two-clips-per-GPU measurement (`throughput_mode` object) that follows the serial timed region")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--all-kernel-events", action="store_true",
                     help="HIP events around EVERY kernel family inside the timed region (costs ~2 %%: 50 k event records of ~3 us "
@@ -305,19 +307,26 @@ def main():
     prompt = "best quality, extremely detailed"
 
     ncl = max(1, args.clips_per_step)
+    if ncl > 1 and args.shard_windows:
+        raise SystemExit("--clips-per-step > 1 and --shard-windows are exclusive")
     if ncl > 1:
-        import copy
-        import threading
-        if args.shard_windows:
-            raise SystemExit("--clips-per-step > 1 and --shard-windows are exclusive")
         args.no_kernel_events = True
-        streams = [torch.cuda.Stream(device=dev) for _ in range(ncl)]
-        pipes = []
-        for _ in range(ncl):             # own pipeline shell + scheduler per stream; UNet / VAE / text encoder are shared
-            sh = copy.copy(pipe)
-            sh.scheduler = copy.deepcopy(pipe.scheduler)
-            pipes.append(sh)
-        clips = [synthetic_clip(args.frames, args.height, args.width, seed=rank * ncl + j, dev=dev) for j in range(ncl)]
+    _multi = {}
+
+    def multi_setup(n):
+        """n clips upscaled CONCURRENTLY on this GPU: one HIP stream + host thread + pipeline shell (own scheduler) each; UNet /
+        VAE / text encoder are shared."""
+        if n not in _multi:
+            import copy
+            streams = [torch.cuda.Stream(device=dev) for _ in range(n)]
+            pipes = []
+            for _ in range(n):
+                sh = copy.copy(pipe)
+                sh.scheduler = copy.deepcopy(pipe.scheduler)
+                pipes.append(sh)
+            clips = [synthetic_clip(args.frames, args.height, args.width, seed=rank * n + j, dev=dev) for j in range(n)]
+            _multi[n] = (streams, pipes, clips)
+        return _multi[n]
 
     def new_generator(seed):
         # a DEVICE generator, like the reference CLI's `torch.Generator(device=UAV_device).manual_seed(10)` (inference_upscale_a_video.py
@@ -327,24 +336,27 @@ def main():
             return torch.Generator().manual_seed(seed)
         return torch.Generator(device=dev).manual_seed(seed)
 
-    def one_step(seed):
-        if ncl == 1:
+    def one_step(seed, n=None):
+        n = ncl if n is None else n
+        if n == 1:
             gen = new_generator(seed)
             return pipe(prompt, generator=gen, **kw).images
-        outs = [None] * ncl
+        import threading
+        streams, pipes, clips = multi_setup(n)
+        outs = [None] * n
         errs = []
 
         def work(j):
             try:
                 with torch.cuda.stream(streams[j]):
-                    gen = new_generator(seed * ncl + j)
+                    gen = new_generator(seed * n + j)
                     outs[j] = pipes[j](prompt, generator=gen, **{**kw, "image": clips[j]}).images
             except Exception as e:       # noqa: BLE001 — re-raised on the main thread
                 errs.append(e)
         cur = torch.cuda.current_stream()
         for st in streams:
             st.wait_stream(cur)
-        th = [threading.Thread(target=work, args=(j,)) for j in range(ncl)]
+        th = [threading.Thread(target=work, args=(j,)) for j in range(n)]
         for t in th:
             t.start()
         for t in th:
@@ -394,6 +406,19 @@ def main():
         pipe.overlap_streams = n_overlap
         if overlapped:
             timed_summary = extra_summary
+    # Throughput mode BESIDE the serial headline: two clips per GPU on concurrent HIP streams — the HBM-bound
+    # kernels of one clip (GroupNorm / LayerNorm passes, the epilogue-bound short-K linears) run beside the power-limited MFMA
+    # kernels of the other.  Measured after the timed region (1 warm-up step + 2 timed steps of 2 clips); never the headline value.
+    two_clip = None
+    if world == 1 and ncl == 1 and not args.no_throughput_mode and not args.shard_windows:
+        one_step(300, 2)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        for i in range(2):
+            one_step(310 + i, 2)
+        torch.cuda.synchronize(); e2 = time.perf_counter() - t2
+        two_clip = {"clips_per_step": 2, "steps": 2, "ms_per_step": e2 / 2 * 1e3, "frames_per_s": 2 * 2 * args.frames / e2,
+                    "note": "two clips per GPU on concurrent HIP streams (serving mode, `--clips-per-step 2` times it as the main "
+                            "line); reported beside the serial headline, not instead of it"}
     assert out.shape == (1, 3, args.frames, 4 * args.height, 4 * args.width) and bool(torch.isfinite(out).all())
     if world > 1:
         import torch.distributed as dist
@@ -426,6 +451,8 @@ def main():
                        "clips_per_step": world * ncl, "frames_per_clip": args.frames},
         }
         res["config"]["predicted_scaling"] = predicted_scaling(args, world, res["value"])
+        if two_clip is not None:
+            res["throughput_mode"] = two_clip
         if args.digest:
             import hashlib
             res["config"]["output_sha256"] = hashlib.sha256(out.detach().float().cpu().numpy().tobytes()).hexdigest()

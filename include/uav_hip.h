@@ -96,7 +96,7 @@ typedef struct {
     /* Strided output rows (the four sub-pixel phases of "nearest 2x, then 3x3 conv", resnet.py:144-158, each a 2x2 conv on
      * the low-resolution input — 16 instead of 36 multiply-adds per output pixel and channel pair): with out_map_w > 0
      * output row m = Y*out_map_w + x (x < out_map_w) is stored at row Y*out_map_sy + x*out_map_sx + out_map_off of `out`
-     * instead of row m.  residual and gn_partials must be NULL, no GEGLU.  0: rows in order. */
+     * instead of row m.  residual must be NULL, no GEGLU; gn_partials only with gn_chunk_cpi (below).  0: rows in order. */
     int32_t      out_map_w, out_map_sy, out_map_sx, out_map_off;
     /* Source 2 read batch-broadcast: a2 holds a2_images = n_img/2 images and images a2_images .. n_img-1 read the pixels
      * of images 0 .. a2_images-1 (the skip tensors of the CFG-shared UNet head exist once, unet_blocks.py:563 concatenates
@@ -122,6 +122,14 @@ typedef struct {
     const float* ln_colsum;
     int32_t      ln_chunks, ln_n;
     float        ln_eps;
+    /* ABI v5.  GroupNorm partials of SEVERAL launches in one workspace (the four sub-pixel phase convs of an up-sampler write
+     * interleaved rows of ONE output tensor, resnet.py:144-158): with gn_chunk_cpi > 0 the launch's chunk index k = m / rows is
+     * stored at (k / gn_chunk_cpi) * gn_chunk_stride + gn_chunk_off + k % gn_chunk_cpi of a workspace that holds
+     * gn_chunks_total chunks per (statistic, group) — e.g. cpi = chunks per frame of this launch, stride = 4 * cpi, off = phase *
+     * cpi: every frame of the output then owns one contiguous run of chunks and uav_groupnorm_finalize_partials reads the
+     * workspace as if one launch had written it.  Lifts the "no out_map" rule of gn_partials.  0: chunk k is stored at k. */
+    int32_t      gn_chunk_cpi, gn_chunk_stride, gn_chunk_off;
+    int64_t      gn_chunks_total;
 } uav_conv_params;
 
 int uav_conv_gemm_f16(const uav_conv_params* p, void* stream);

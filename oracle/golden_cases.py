@@ -85,6 +85,18 @@ def prop_inputs_ties(t, h, w, seed=310):
     return x, ff.half().float(), fb.half().float()
 
 
+def consistent_flows(t, h, w, seed=4242):
+    """Bidirectional flows (1,2,t-1,h,w) x 2 that PASS the forward-backward check (frames really are warped): a (2.3, 1.3)
+    px/frame translation with small noise, fp16-representable, plus a band where the backward flow contradicts the forward one
+    (mask = 0 there).  Flows of a random-weight RAFT fail the check everywhere (round 4, GPU call 1): propagation = identity."""
+    g = _g(seed)
+    ff = torch.zeros(1, 2, t - 1, h, w); fb = torch.zeros(1, 2, t - 1, h, w)
+    ff[:, 0] = 2.3; ff[:, 1] = 1.3; fb[:, 0] = -2.3; fb[:, 1] = -1.3
+    ff = ff + 0.02 * torch.randn(ff.shape, generator=g); fb = fb + 0.02 * torch.randn(fb.shape, generator=g)
+    fb[:, :, :, h // 3: h // 2] += 3.0
+    return ff.half().float(), fb.half().float()
+
+
 # reference Propagation run on CPU *half* tensors (the dtype the pipeline hands it, pipeline:651): name -> (inputs fn, t, h, w, interp)
 PROP_HALF_CASES = {
     "propagation_nearest_half": ("plain", 8, 24, 32, "nearest"),
@@ -141,4 +153,9 @@ FULL_CASES = {
     # the FULL 30-step schedule of BASELINE configs[1] at the released width, 64x64 so the CPU reference finishes in minutes
     "pipe_full30_64": dict(t=8, h=64, w=64, steps=30, guidance=6.0, noise_level=120, clip_seed=43,
                            prompt="best quality, extremely detailed", negative="blur, worst quality"),
+    # BASELINE configs[2] at the released width: the same run with flow-guided propagation at DDIM steps 24, 26, 28 (0-based
+    # loop indices, inference_upscale_a_video.py `-p 24,26,28`) on consistent_flows(8, 64, 64)
+    "pipe_full30_64_prop": dict(t=8, h=64, w=64, steps=30, guidance=6.0, noise_level=120, clip_seed=43,
+                                prompt="best quality, extremely detailed", negative="blur, worst quality",
+                                propagation_steps=(24, 26, 28)),
 }

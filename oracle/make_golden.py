@@ -620,6 +620,72 @@ def make_full30_golden(ns, pin):
     print("pipe_full30_64", pin["cases"]["pipe_full30_64"], flush=True)
 
 
+FULL30_PROP_KEEP = (20, 24, 25, 26, 27, 28, 29, 30)  # DDIM steps (1-based) whose latents are stored
+
+
+def make_full30_prop_golden(ns, pin):
+    """BASELINE configs[2] at the released width — the reference's own pipeline in fp32 (full-width UNet +
+    vae_3d, 8 frames 64x64 -> 256x256, 30 DDIM steps, guidance 6) WITH its `Propagation` module (learnable=False) at loop
+    indices 24, 26, 28 on consistent flows (golden_cases.consistent_flows; the pipeline casts them to the latent dtype, :651).
+    Latents after the steps in FULL30_PROP_KEEP + the decoded frames (sub-sampled 2x) are stored; the oracle is pinned on the
+    same run by resuming its pipeline from the reference's latents after step 24 (6 steps incl. all three propagation sweeps +
+    the decode: minutes instead of 11)."""
+    from golden_cases import consistent_flows
+    unet, usd, ucfg, vae, vsd, vcfg = _full_models(ns)
+    pc = FULL_CASES["pipe_full30_64_prop"]
+    dim = ucfg["cross_attention_dim"]
+    clip = synth.synth_clip(1, pc["t"], pc["h"], pc["w"], seed=pc["clip_seed"])
+    ff, fb = consistent_flows(pc["t"], pc["h"], pc["w"])
+    tok = _Tok()
+    sch = ns.scheduling_ddim.DDIMScheduler(**SCHED)
+    trace = []
+    inner = sch.step_vt
+
+    def rec(*a, _inner=inner, **kw):
+        r = _inner(*a, **kw)
+        trace.append(r.prev_sample.detach().clone())
+        return r
+    sch.step_vt = rec
+    prop = ns.propagation.Propagation(4, learnable=False)
+    pipe = ns.pipeline.VideoUpscalePipeline(
+        text_encoder=_TextEnc(tok, dim, dtype=torch.float32), tokenizer=tok,
+        low_res_scheduler=ref_stubs.DDPMScheduler(beta_schedule="scaled_linear", beta_start=0.0001, beta_end=0.02),
+        scheduler=sch, vae=vae, unet=unet, propagator=prop)
+    gen = torch.Generator().manual_seed(10)
+    t0 = time.time()
+    with torch.no_grad():
+        img, lat = pipe(pc["prompt"], image=clip, flows_bi=[ff, fb], generator=gen, num_inference_steps=pc["steps"],
+                        guidance_scale=pc["guidance"], noise_level=pc["noise_level"], negative_prompt=pc["negative"],
+                        propagation_steps=list(pc["propagation_steps"]), return_dict=False)
+    secs = time.time() - t0
+    assert len(trace) == pc["steps"]
+    # the oracle on the same run, resumed at the first propagation step from the reference's own latents
+    i0 = pc["propagation_steps"][0]
+    gen = torch.Generator().manual_seed(10)
+    lr_noise = torch.randn(clip.shape, generator=gen); lat0 = torch.randn((1, 4, pc["t"], pc["h"], pc["w"]), generator=gen)
+    pe = torch.cat([synth.synth_prompt_embeds(pc["negative"], dim), synth.synth_prompt_embeds(pc["prompt"], dim)])
+    t1 = time.time()
+    with torch.no_grad():
+        oimg, olat = O.pipeline_call(usd, ucfg, vsd, vcfg, clip, pe, num_inference_steps=pc["steps"], guidance_scale=pc["guidance"],
+                                     noise_level=pc["noise_level"], lr_noise=lr_noise, latents=lat0, flows_bi=[ff, fb],
+                                     propagation_steps=tuple(pc["propagation_steps"]), scheduler_kwargs=SCHED,
+                                     resume=(i0, trace[i0 - 1]))
+    osecs = time.time() - t1
+    base = torch.load(os.path.join(GOLD, "pipe_full30_64.pt"))
+    k20 = list(base["steps"]).index(20)
+    pin["cases"]["pipe_full30_64_prop"] = {
+        "kept_steps": list(FULL30_PROP_KEEP), "propagation_steps": list(pc["propagation_steps"]),
+        "latents_rel_l2_vs_no_propagation_run_at_step_20": rel_l2(trace[19], base["latents_fp32"][k20]),
+        "latents_rel_l2_vs_no_propagation_run_at_step_30": rel_l2(trace[29], base["latents_fp32"][list(base["steps"]).index(30)]),
+        "oracle_resumed_at_step_24_latents_maxabs_vs_reference": (olat - lat).abs().max().item(),
+        "oracle_resumed_at_step_24_latents_rel_l2_vs_reference": rel_l2(olat, lat),
+        "oracle_resumed_at_step_24_image_maxabs_vs_reference": (oimg - img).abs().max().item(),
+        "image_saturated_fraction": (img.abs() >= 0.999).float().mean().item(), "ref_seconds": secs, "oracle_resume_seconds": osecs}
+    torch.save({"steps": list(FULL30_PROP_KEEP), "latents_fp32": torch.stack([trace[k - 1] for k in FULL30_PROP_KEEP]).float().clone(),
+                "images_fp32_sub2": img[..., ::2, ::2].half().clone()}, os.path.join(GOLD, "pipe_full30_64_prop.pt"))
+    print("pipe_full30_64_prop", pin["cases"]["pipe_full30_64_prop"], flush=True)
+
+
 def make_pipe_half_golden(ns, pin):
     """The reference pipeline in the precision mix the CLI really runs (inference_upscale_a_video.py:101-118): UNet
     `.half()`, text-encoder dtype fp16 -> both randn draws, the latents, CFG, DDIM and the flow-guided propagation
@@ -674,14 +740,14 @@ def only(section):
     pin = json.load(open(os.path.join(GOLD, "PINNING.json")))
     {"raft": make_raft_goldens, "unet": make_unet_goldens, "tiles": make_tile_goldens, "pipe14": make_dup_tail_golden,
      "vaewlr": make_vae_wlr_golden, "prophalf": make_prop_half_goldens, "pipehalf": make_pipe_half_golden, "colorfix": make_colorfix_golden, "full": make_fullwidth_goldens,
-     "full30": make_full30_golden, "fullvideo": make_vaevideo_full_golden}[section](ns, pin)
+     "full30": make_full30_golden, "full30prop": make_full30_prop_golden, "fullvideo": make_vaevideo_full_golden}[section](ns, pin)
     json.dump(pin, open(os.path.join(GOLD, "PINNING.json"), "w"), indent=1)
 
 
 if __name__ == "__main__":
-    _known = ("--raft", "--unet", "--tiles", "--pipe14", "--vaewlr", "--colorfix", "--pipehalf", "--prophalf", "--fullvideo", "--full30", "--full")
+    _known = ("--raft", "--unet", "--tiles", "--pipe14", "--vaewlr", "--colorfix", "--pipehalf", "--prophalf", "--fullvideo", "--full30", "--full30prop", "--full")
     if any(a not in _known for a in sys.argv[1:]):
         # no flag = regenerate the quarter-width fixtures (minutes); an unknown flag (e.g. --help) must not start that
         print("usage: make_golden.py [" + " | ".join(_known) + "]   (no flag: all quarter-width fixtures)")
         sys.exit(0 if sys.argv[1:] in (["--help"], ["-h"]) else 2)
-    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else only("tiles") if "--tiles" in sys.argv else only("pipe14") if "--pipe14" in sys.argv else only("vaewlr") if "--vaewlr" in sys.argv else only("colorfix") if "--colorfix" in sys.argv else only("pipehalf") if "--pipehalf" in sys.argv else only("prophalf") if "--prophalf" in sys.argv else only("fullvideo") if "--fullvideo" in sys.argv else only("full30") if "--full30" in sys.argv else only("full") if "--full" in sys.argv else main()
+    only("raft") if "--raft" in sys.argv else only("unet") if "--unet" in sys.argv else only("tiles") if "--tiles" in sys.argv else only("pipe14") if "--pipe14" in sys.argv else only("vaewlr") if "--vaewlr" in sys.argv else only("colorfix") if "--colorfix" in sys.argv else only("pipehalf") if "--pipehalf" in sys.argv else only("prophalf") if "--prophalf" in sys.argv else only("fullvideo") if "--fullvideo" in sys.argv else only("full30prop") if "--full30prop" in sys.argv else only("full30") if "--full30" in sys.argv else only("full") if "--full" in sys.argv else main()

@@ -24,7 +24,7 @@ def _h(x):
 # ---------------------------------------------------------------------------------------------------------------------
 def conv_gemm(a1, wt, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None, rowbias=None, rows_per_batch=0,
               residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None, persistent=False, act=None, gn_groups=None,
-              out_map=None, a2_center=False, ln_produce=False, ln_consume=None):
+              out_map=None, a2_center=False, ln_produce=False, ln_consume=None, gn_shared=None):
     c1 = a1.shape[-1]
     c2 = 0 if a2 is None else a2.shape[-1]
     assert c1 + c2 == wt.cin_p, (c1, c2, wt.cin_p)

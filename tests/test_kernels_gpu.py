@@ -610,6 +610,49 @@ def test_upsample_as_subpixel_phase_convs(ops, dev, cin, cout, n_img, t_len, h, 
     assert rel_l2(out, fused) < 1e-3
 
 
+@pytest.mark.parametrize("f32,per_frame", [(True, False), (True, True), (False, False)])
+def test_upsampler_phase_convs_share_one_statistics_workspace(ops, dev, f32, per_frame):
+    """Round 4: the four sub-pixel phase launches of `Upsample3D` write their GroupNorm partials into ONE workspace
+    (uav_conv_params.gn_chunk_*: every output frame owns a contiguous run of chunks), so the GroupNorm that reads the up-sampled
+    tensor needs no statistics pass: scale / shift from the shared partials == those of the stand-alone pass over the same
+    tensor (fp64 finalize on both sides; 5-D instance and per-frame instance), and the partials ride on the returned tensor."""
+    from uav import engine as E
+    from models_video.resnet import Upsample3D
+    g = torch.Generator().manual_seed(77)
+    cout = 512
+    up = Upsample3D(256, use_conv=True, out_channels=cout).to(dev)
+    with torch.no_grad():
+        up.conv.weight.copy_(h16(cout, 256, 3, 3, dev=dev, scale=(9 * 256) ** -0.5, gen=g))
+        up.conv.bias.copy_(torch.randn(cout, generator=g).to(dev))
+    geom = E.Geom(2, 4, 64, 64)                          # 8 frames of 64x64 -> 128x128: 128 x 2 tiles per phase -> the 256x256 kernel
+    x = torch.randn(geom.rows, 256, generator=g).to(dev)
+    x = x if f32 else x.half()
+    saved = E.SAMPLER_HILO
+    E.SAMPLER_HILO = False
+    try:
+        y, g2 = up.run(x, geom)
+    finally:
+        E.SAMPLER_HILO = saved
+    gn = getattr(y, "_uav_gn", None)
+    assert gn is not None and gn.filled == 4 and gn.ws.shape == (2, 32, g2.rows // 64), "the phase launches did not write the shared partials"
+    gamma = (1 + 0.1 * torch.randn(cout, generator=g)).to(dev); beta = (0.1 * torch.randn(cout, generator=g)).to(dev)
+    n_inst, rpi = (g2.n_img, g2.hw) if per_frame else (g2.b, g2.rows_per_batch)
+    kw = dict(n_inst=n_inst, rows_per_inst=rpi, groups=32, eps=1e-6)
+    sc_f, sh_f = ops.groupnorm_scale_shift(y, gamma, beta, **kw)                  # from the shared partials
+    y2 = y.clone()                                                                # a plain tensor: stand-alone statistics pass
+    assert getattr(y2, "_uav_gn", None) is None
+    sc_s, sh_s = ops.groupnorm_scale_shift(y2, gamma, beta, **kw)
+    assert rel_l2(sc_f, sc_s) < 1e-6 and (sh_f - sh_s).abs().max().item() < 1e-5 * (1 + sh_s.abs().max().item())
+    # and against torch on the NCHW view
+    y4 = from_rows(y.float(), g2.n_img, g2.h, g2.w)                               # (B*T, C, H, W)
+    y4 = y4 if per_frame else y4.reshape(g2.b, g2.t, cout, g2.h, g2.w).permute(0, 2, 1, 3, 4)
+    ref = F.group_norm(y4.float(), 32, gamma, beta, eps=1e-6)
+    rows = ops.groupnorm(y, gamma, beta, silu=False, **kw).float()
+    out4 = from_rows(rows, g2.n_img, g2.h, g2.w)
+    ref4 = ref if per_frame else ref.permute(0, 2, 1, 3, 4).reshape(g2.n_img, cout, g2.h, g2.w)
+    assert rel_l2(out4, ref4) < 2e-3
+
+
 # ------------------------------------------------------------------------------------------------
 # second source read batch-broadcast (uav_conv_params.a2_images, x2_rows of the GroupNorm entry points)
 @pytest.mark.parametrize("h,w,k3", [(48, 40, (1, 1, 1)), (24, 20, (1, 3, 3)), (160, 160, (1, 1, 1)), (128, 128, (1, 3, 3))])

@@ -65,21 +65,17 @@ def build_models(dev):
     return unet, usd, vae, vsd
 
 
-def build_flows(dev):
-    """Bidirectional flows at the latent resolution that are CONSISTENT (so the forward-backward check passes and frames are
-    actually warped): the clip's (2.3, 1.3) px/frame translation with small noise, fp16-representable, plus a band where the
-    backward flow contradicts the forward one (mask = 0 there).  Round 4, call 1 measured that flows of a random-weight
-    RAFT (what bench.py --propagation feeds) fail the consistency check everywhere — the propagation is then the identity
-    and tests nothing; RAFT itself is pinned in tests/test_raft_gpu.py against the reference's fixtures."""
-    g = torch.Generator().manual_seed(4242)
-    ff = torch.zeros(1, 2, T - 1, H, W); fb = torch.zeros(1, 2, T - 1, H, W)
-    ff[:, 0] = 2.3; ff[:, 1] = 1.3; fb[:, 0] = -2.3; fb[:, 1] = -1.3
-    ff = ff + 0.02 * torch.randn(ff.shape, generator=g); fb = fb + 0.02 * torch.randn(fb.shape, generator=g)
-    fb[:, :, :, H // 3: H // 2] += 3.0
-    return [ff.half().float().to(dev).contiguous(), fb.half().float().to(dev).contiguous()]
+def build_flows(dev, t=T, h=H, w=W):
+    """Consistent bidirectional flows at the latent resolution (golden_cases.consistent_flows: the forward-backward check
+    passes, frames really are warped, one band is masked out).  Round 4, call 1 measured that flows of a random-weight RAFT
+    (what bench.py --propagation feeds) fail the consistency check everywhere — the propagation is then the identity and tests
+    nothing; RAFT itself is pinned in tests/test_raft_gpu.py against the reference's fixtures."""
+    import golden_cases as GC
+    ff, fb = GC.consistent_flows(t, h, w)
+    return [ff.to(dev).contiguous(), fb.to(dev).contiguous()]
 
 
-def engine_run(dev, unet, vae, clip, flows=None, prop_steps=()):
+def engine_run(dev, unet, vae, clip, flows=None, prop_steps=(), steps=STEPS):
     import golden_cases as GC
     from uav import configs
     from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
@@ -95,7 +91,7 @@ def engine_run(dev, unet, vae, clip, flows=None, prop_steps=()):
     pipe.latents_trace = []
     torch.cuda.synchronize(); t0 = time.time()
     out, lat = pipe(PROMPT, image=clip.to(dev), flows_bi=flows, generator=torch.Generator().manual_seed(10),
-                    num_inference_steps=STEPS, guidance_scale=GUIDANCE, noise_level=NOISE_LEVEL, negative_prompt=NEGATIVE,
+                    num_inference_steps=steps, guidance_scale=GUIDANCE, noise_level=NOISE_LEVEL, negative_prompt=NEGATIVE,
                     propagation_steps=list(prop_steps), return_dict=False)
     torch.cuda.synchronize()
     return dict(images=out, latents=lat, trace=pipe.latents_trace, seconds=time.time() - t0)
@@ -217,3 +213,32 @@ def test_propagation_fp32_latents_vs_reference_fp32_run(dev, name):
     if interp == "nearest":
         assert identical > 0.9998, identical
         assert off16 > 0.3, off16                           # the fp16 replay is a different function on tie pixels
+
+
+# ------------------------------------------------------------------------------------------------
+def test_configs2_full_width_30_steps_vs_reference_pipeline(dev):
+    """BASELINE configs[2] against the REFERENCE'S OWN pipeline (not the oracle): full width, 8 frames 64x64 -> 256x256, 30 DDIM
+    steps, guidance 6, the reference `Propagation` at loop indices 24 / 26 / 28 on consistent flows, everything fp32
+    (tests/golden/pipe_full30_64_prop.pt, `oracle/make_golden.py --full30prop`; pipeline_upscale_a_video.py:651-657,
+    propagation_module.py:194-281).  Common noise: fp32 draws from one CPU generator."""
+    import golden_cases as GC
+    import synth
+    path = os.path.join(ROOT, "tests", "golden", "pipe_full30_64_prop.pt")
+    if not os.path.exists(path):
+        pytest.skip("fixture pipe_full30_64_prop.pt not generated")
+    gold = torch.load(path)
+    pc = GC.FULL_CASES["pipe_full30_64_prop"]
+    assert (pc["prompt"], pc["negative"], pc["guidance"], pc["noise_level"]) == (PROMPT, NEGATIVE, GUIDANCE, NOISE_LEVEL)
+    unet, usd, vae, vsd = build_models(dev)
+    clip = synth.synth_clip(1, pc["t"], pc["h"], pc["w"], seed=pc["clip_seed"])
+    flows = build_flows(dev, pc["t"], pc["h"], pc["w"])
+    eng = engine_run(dev, unet, vae, clip, flows=flows, prop_steps=pc["propagation_steps"], steps=pc["steps"])
+    steps = list(gold["steps"])
+    curve = [rel_l2(eng["trace"][k - 1], gold["latents_fp32"][i]) for i, k in enumerate(steps)]
+    g = gold["images_fp32_sub2"].float()
+    img = eng["images"].float().cpu()[..., ::2, ::2]
+    e_all, e_unsat, sat = image_errors(img, g)
+    report("r4_pipe_full30_64_prop_vs_reference_pipeline", steps=steps, latents_rel_l2_at_kept_steps=curve,
+           images_rel_l2_all_pixels=e_all, images_rel_l2_unsaturated=e_unsat, images_saturated_fraction=sat)
+    assert curve[-1] < 1.0e-3, curve                    # latents after the whole schedule incl. the three propagation sweeps
+    assert e_all < 1.3e-3, (e_all, e_unsat)             # 64x64 proxy (the headline-shape bars are the stated 1e-3, above)

@@ -35,6 +35,9 @@ def main():
         ("sampler_hilo", {"SAMPLER_HILO": True}),
         ("sampler_hilo+branch_f32", {"SAMPLER_HILO": True, "BRANCH_F32": True}),
         ("no_shortcut_hilo", {"SHORTCUT_HILO": False}),
+        ("no_sampler_hilo", {"SAMPLER_HILO": False}),
+        ("tail_hilo", {"TAIL_HILO": True}),
+        ("tail_hilo+branch_f32", {"TAIL_HILO": True, "BRANCH_F32": True}),
     ]
     # the decoder alone: engine decode of the oracle's final latents, chunk by chunk like the pipeline
     from models_video.pipeline_upscale_a_video import VideoUpscalePipeline

@@ -46,6 +46,7 @@ struct ConvArgs {
     int korder, tile_order;
     unsigned ntiles;
     float* gn_ws; int gn_groups, gn_cpg_log2; long long gn_chunks;     // fused GroupNorm statistics (see conv_gn_store)
+    int gn_cpi, gn_cstride, gn_coff;                                   // chunk placement in a workspace shared by several launches (uav_conv_params.gn_chunk_*)
     int omw, omsy, omsx, omoff;                                        // strided output rows (uav_conv_params.out_map_*)
     int a2_pix;                                                        // pixels of source 2 when it is read batch-broadcast (0: off)
     int a2_ctr;                                                        // source 2 multiplies the centre tap only (uav_conv_params.a2_center_tap)
@@ -129,6 +130,12 @@ __host__ __device__ inline int gn_mode_of(int cpg_log2) { return cpg_log2 <= 3 ?
 // CL = log2(channels per group), 2..7.  After the half-wave reductions every lane 16..31 of a half holds the totals;
 // lane 16+i keeps value i, so ONE store instruction per statistic leaves the wave (vector memory instructions, not
 // VALU, are what the epilogue is short of).
+// Chunk index of the wave tile that starts at row mw0 (64 rows per chunk); remapped when several launches share one workspace.
+UAV_DEVINL long long gn_chunk_index(const ConvArgs& p, long long mw0, int rows) {
+    long long k = mw0 / rows;
+    if (p.gn_cpi) { const int ki = (int)k, inst = ki / p.gn_cpi; k = (long long)inst * p.gn_cstride + p.gn_coff + (ki - inst * p.gn_cpi); }
+    return k;
+}
 template <int NI, int MI, int GNM, int CL>
 UAV_DEVINL void conv_gn_store_cl(const ConvArgs& p, float (&st)[NI][GnAcc<GNM>::NG], float (&sq)[NI][GnAcc<GNM>::NG],
                                  long long mw0, int nw0, int l32, int hi32) {
@@ -157,7 +164,7 @@ UAV_DEVINL void conv_gn_store_cl(const ConvArgs& p, float (&st)[NI][GnAcc<GNM>::
     const int grp = CL == 2 ? (nw0 >> 2) + 2 * i + hi32 : (nw0 >> CL) + i;
     const bool writer = i >= 0 && i < NV && (CL == 2 || hi32 == 1) && grp < p.gn_groups;
     if (writer) {
-        float* ws_s = p.gn_ws + (long long)grp * p.gn_chunks + mw0 / (MI * 32);
+        float* ws_s = p.gn_ws + (long long)grp * p.gn_chunks + gn_chunk_index(p, mw0, MI * 32);
         ws_s[0] = vs;
         ws_s[(long long)p.gn_groups * p.gn_chunks] = vq;
     }
@@ -187,7 +194,7 @@ UAV_DEVINL void conv_gn_store(const ConvArgs& p, float (&st)[NI][GnAcc<GNM>::NG]
         const int nv = 4 >> (cl - 5);
         const int grp = (nw0 >> cl) + i;
         if (i >= 0 && i < nv && hi32 == 1 && grp < p.gn_groups) {
-            float* ws_s = p.gn_ws + (long long)grp * p.gn_chunks + mw0 / (MI * 32);
+            float* ws_s = p.gn_ws + (long long)grp * p.gn_chunks + gn_chunk_index(p, mw0, MI * 32);
             ws_s[0] = vs;
             ws_s[(long long)p.gn_groups * p.gn_chunks] = vq;
         }
@@ -1446,7 +1453,8 @@ bool conv_uses_big_tile(const uav_conv_params* q) {
 // Fused GroupNorm statistics are produced by the fast epilogues of the 256x256 kernel only: every wave tile (64 rows x
 // 128 channels) must lie inside M x N and qualify for a fast path, and a group must not straddle wave tiles.
 int conv_gn_cpg_log2(const uav_conv_params* q) {
-    if (q->gn_groups <= 0 || (q->n % q->gn_groups) || q->out_map_w) return -1;     // chunks are runs of consecutive output rows
+    // chunks are runs of consecutive output rows — or, for strided output rows (out_map), placed by gn_chunk_* in a shared workspace
+    if (q->gn_groups <= 0 || (q->n % q->gn_groups) || (q->out_map_w && q->gn_chunk_cpi <= 0)) return -1;
     const int cpg = q->n / q->gn_groups;
     int cl = -1;
     for (int k = 2; k <= 7; ++k) if (cpg == (1 << k)) cl = k;
@@ -1556,16 +1564,23 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     }
     a.omw = 0; a.omsy = 0; a.omsx = 0; a.omoff = 0;
     if (q->out_map_w > 0) {
-        if (q->residual || q->gn_partials || (q->flags & UAV_CONV_GEGLU) || q->out_map_sy < 0 || q->out_map_sx <= 0 ||
-            q->out_map_off < 0)
+        if (q->residual || (q->gn_partials && q->gn_chunk_cpi <= 0) || (q->flags & UAV_CONV_GEGLU) || q->out_map_sy < 0 ||
+            q->out_map_sx <= 0 || q->out_map_off < 0)
             return UAV_ESHAPE;
         a.omw = q->out_map_w; a.omsy = q->out_map_sy; a.omsx = q->out_map_sx; a.omoff = q->out_map_off;
     } else if (q->out_map_w < 0) return UAV_ESHAPE;
-    a.gn_ws = nullptr; a.gn_groups = 0; a.gn_cpg_log2 = 0; a.gn_chunks = 0;
+    a.gn_ws = nullptr; a.gn_groups = 0; a.gn_cpg_log2 = 0; a.gn_chunks = 0; a.gn_cpi = 0; a.gn_cstride = 0; a.gn_coff = 0;
     if (q->gn_partials) {
         const int cl = conv_gn_cpg_log2(q);
         if (cl < 0) return UAV_ESHAPE;             // ask uav_conv_gemm_gn_chunk_rows() first
         a.gn_ws = (float*)q->gn_partials; a.gn_groups = q->gn_groups; a.gn_cpg_log2 = cl; a.gn_chunks = a.M / 64;
+        if (q->gn_chunk_cpi > 0) {
+            const long long k = a.M / 64;
+            if ((k % q->gn_chunk_cpi) || q->gn_chunk_off < 0 || q->gn_chunk_off + q->gn_chunk_cpi > q->gn_chunk_stride ||
+                (k / q->gn_chunk_cpi) * (long long)q->gn_chunk_stride > q->gn_chunks_total)
+                return UAV_ESHAPE;
+            a.gn_cpi = q->gn_chunk_cpi; a.gn_cstride = q->gn_chunk_stride; a.gn_coff = q->gn_chunk_off; a.gn_chunks = q->gn_chunks_total;
+        }
     }
     // One-time setup.  The dynamic-LDS attribute of the 256x256 kernels and the CU count are PER DEVICE (std::call_once
     // per device index), so a second GPU, or a second host thread driving the library (bench --clips-per-step), never

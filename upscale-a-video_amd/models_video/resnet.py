@@ -28,6 +28,8 @@ from uav import ops
 # "nearest 2x + 3x3 conv" as four 2x2 sub-pixel phase convs (2.25x fewer multiply-adds; ops.upsample_phase_weights).
 # UAV_PHASE_UPSAMPLE=0 keeps the fused-gather form (upsampling folded into the 3x3 conv's addressing).
 PHASE_UPSAMPLE = os.environ.get("UAV_PHASE_UPSAMPLE", "1") != "0"
+# GroupNorm statistics of an up-sampled tensor from its four phase launches (shared workspace; 0: stand-alone statistics pass)
+FUSE_UPSAMPLE_GN = os.environ.get("UAV_FUSE_UPSAMPLE_GN", "1") != "0"
 
 
 def _temb_rows(mod, temb):
@@ -102,11 +104,20 @@ class Upsample3D(E.EngineModule):
             # four 2x2 convs on the low-resolution rows, each writing its sub-pixel phase of the output in place
             cws = E.packed_upsample_phases(conv, "w", conv, dup=hilo)
             out = torch.empty((g2.rows, self.out_channels), dtype=torch.float32 if s32 else torch.float16, device=x.device)
+            # GroupNorm statistics of the output (its consumers: the next block's norm1, a TemporalModule3D): the four phase
+            # launches write their partials into ONE workspace in which every output frame owns a contiguous run of chunks
+            # (phase-major inside the frame) — the stand-alone statistics pass over the 4x larger tensor goes away
+            sh, cpi = None, g.hw // 64
+            if FUSE_UPSAMPLE_GN and ops.FUSE_GN_STATS and g.hw % 64 == 0 and self.out_channels % E.GN_GROUPS_HINT == 0:
+                sh = ops.SharedGnPartials(g2.rows, E.GN_GROUPS_HINT, self.out_channels, x.device)
             for py in range(2):
                 for px in range(2):
                     ops.conv_gemm(x, cws[py][px], n_img=g.n_img, t_len=g.t, hi=g.h, wi=g.w, pad=(0, 1 - py, 1 - px),
                                   out_hw=(g.h, g.w), out_f32=s32, rows_per_batch=g.rows_per_batch, out=out,
-                                  out_map=(g.w, 4 * g.w, 2, py * 2 * g.w + px))
+                                  out_map=(g.w, 4 * g.w, 2, py * 2 * g.w + px),
+                                  gn_shared=None if sh is None else (sh, cpi, 4 * cpi, (2 * py + px) * cpi))
+            if sh is not None and sh.filled == 4:
+                ops._gn_attach(out, sh)
             return out, g2
         # Forced size (reference resnet.py:147-150, used when H, W are not multiples of 2^num_upsamplers,
         # unet_video.py:443-445,541-542): F.interpolate(size=..., mode="nearest"), i.e. src = floor(dst * in / out)

@@ -35,6 +35,7 @@ class ConvParams(C.Structure):
         ("a2_images", i32), ("a2_center_tap", i32),
         ("ln_raw_out", c_p), ("ln_stat_out", c_p), ("ln_stat_in", c_p), ("ln_colsum", c_p),
         ("ln_chunks", i32), ("ln_n", i32), ("ln_eps", f32),
+        ("gn_chunk_cpi", i32), ("gn_chunk_stride", i32), ("gn_chunk_off", i32), ("gn_chunks_total", i64),
     ]
 
 

@@ -245,7 +245,8 @@ def upsample_phase_weights(weight):
 
 def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None,
               rowbias=None, rows_per_batch=0, residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None,
-              persistent=False, act=None, gn_groups=None, out_map=None, a2_center=False, ln_produce=False, ln_consume=None):
+              persistent=False, act=None, gn_groups=None, out_map=None, a2_center=False, ln_produce=False, ln_consume=None,
+              gn_shared=None):
     """out[M][n_out] = scale*(conv(a1|a2, W) + bias + rowbias[m//rows_per_batch] + residual).
 
     ln_produce: the fp32 output feeds a LayerNorm whose consumer folds it (`LnFold`): the launch also writes the fp16 rounding of
@@ -257,7 +258,10 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
     them (`GnPartials`, attribute `_uav_gn`); `groupnorm_scale_shift` then skips its pass over the tensor.
 
     out_map = (w, sy, sx, off) with `out`: GEMM row m = Y*w + x lands in row Y*sy + x*sx + off of `out` (sub-pixel phases
-    of the upsampling convs, `upsample_phase_weights`)."""
+    of the upsampling convs, `upsample_phase_weights`).
+    gn_shared = (SharedGnPartials, cpi, stride, off) with out_map: this launch's statistics chunks go into a workspace shared
+    with the other phase launches of the same output tensor (uav_conv_params.gn_chunk_*); the caller attaches the partials
+    to `out` when every launch reported success (`SharedGnPartials.filled`)."""
     lib = _lib.load()
     _req(a1, HALF, "a1")
     c1 = a1.shape[-1]
@@ -338,7 +342,16 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
         if not lib.uav_conv_gemm_ln_ok(C.byref(p)):
             raise _lib.UavError("conv_gemm: this launch cannot fold the LayerNorm (ask ln_fold_ok first)")
     gn = None
-    if gn_groups and FUSE_GN_STATS and out_map is None and lnop is None:
+    if gn_shared is not None and FUSE_GN_STATS and lnop is None:
+        sh, cpi, cstride, coff = gn_shared
+        p.gn_groups = int(sh.groups)
+        p.gn_chunk_cpi, p.gn_chunk_stride, p.gn_chunk_off, p.gn_chunks_total = int(cpi), int(cstride), int(coff), int(sh.ws.shape[-1])
+        if lib.uav_conv_gemm_gn_chunk_rows(C.byref(p)) == sh.rows and (m // sh.rows) % cpi == 0:
+            p.gn_partials = _p(sh.ws)
+            sh.filled += 1
+        else:
+            p.gn_groups = 0; p.gn_chunk_cpi = 0
+    elif gn_groups and FUSE_GN_STATS and out_map is None and lnop is None:
         p.gn_groups = int(gn_groups)
         rows = lib.uav_conv_gemm_gn_chunk_rows(C.byref(p))
         if rows > 0:
@@ -422,6 +435,17 @@ class GnPartials:
 
     def __init__(self, ws, rows, groups, c):
         self.ws, self.rows, self.groups, self.c, self.version = ws, rows, groups, c, None
+
+
+class SharedGnPartials(GnPartials):
+    """One statistics workspace filled by several launches that write interleaved rows of one tensor (the four sub-pixel phase
+    convs of an up-sampler): `filled` counts the launches that did write their chunks."""
+    __slots__ = ("filled",)
+
+    def __init__(self, rows_out, groups, c, device, chunk_rows=64):
+        super().__init__(torch.empty((2, int(groups), rows_out // chunk_rows), dtype=torch.float32, device=device), chunk_rows,
+                         int(groups), c)
+        self.filled = 0
 
 
 def _gn_attach(t, gn):
