@@ -386,11 +386,13 @@ def main():
         ops.PROFILER.detail = bool(os.environ.get("UAV_BENCH_DETAIL"))
         if not overlapped:              # per-launch events mean nothing while launches of two streams share the chip
             ops.PROFILER.start(only=None if all_events else {"conv_gemm"})
+    torch.cuda.reset_peak_memory_stats(dev)
     t0 = time.perf_counter()
     for i in range(args.steps):
         out = one_step(10 + i)
     barrier()
     elapsed = time.perf_counter() - t0
+    peak_alloc, peak_reserved = torch.cuda.max_memory_allocated(dev), torch.cuda.max_memory_reserved(dev)
     ops.PROFILER.stop()
     timed_summary = ops.PROFILER.summary() if use_events else None
     extra_summary = None
@@ -451,6 +453,9 @@ def main():
                        "clips_per_step": world * ncl, "frames_per_clip": args.frames},
         }
         res["config"]["predicted_scaling"] = predicted_scaling(args, world, res["value"])
+        # device memory of the timed region (torch caching allocator, rank 0): peak bytes in live tensors / held by the allocator's
+        # pools — side streams (overlap_streams, clips_per_step) own pools of their own
+        res["config"]["peak_memory_gb"] = {"allocated": round(peak_alloc / 2 ** 30, 2), "reserved": round(peak_reserved / 2 ** 30, 2)}
         if two_clip is not None:
             res["throughput_mode"] = two_clip
         if args.digest:

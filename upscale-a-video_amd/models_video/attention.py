@@ -208,9 +208,8 @@ class BasicTransformerBlock(E.EngineModule):
         wstamp = E._stamp((attn.to_k.weight, attn.to_v.weight))      # in-place weight edits invalidate the projection too
         for hit in hits:
             if hit[0] is ehs_rows and hit[1] == ehs_rows._version and hit[3] == wstamp:
-                return hit[2]
-        kv = attn.project_text(ehs_rows)
-        E.publish()
+                return E.acquire(hit[2])
+        kv = E.publish(attn.project_text(ehs_rows))
         # a few entries: the guidance branches evaluated one by one (pipeline.shard_cfg / overlap_streams) alternate between
         # two prompt tensors
         c.store[("textkv", tag)] = ((ehs_rows, ehs_rows._version, kv, wstamp),) + tuple(hits)[:TEXT_KV_ENTRIES - 1]

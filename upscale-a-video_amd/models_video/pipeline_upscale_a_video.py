@@ -93,6 +93,7 @@ class VideoUpscalePipeline(ConfigMixin):
         # launches, CFG-shared head given up — so that one is opt-in.  0 / 1 = always serial.
         self.overlap_streams = int(os.environ.get("UAV_OVERLAP_STREAMS", "2"))
         self.overlap_split_cfg = os.environ.get("UAV_OVERLAP_SPLIT_CFG", "0") == "1"
+        self.overlap_min_free_fraction = 0.35        # serial fallback below this share of free device memory
         self.latents_trace = None          # test hook: set to a list to collect the latents after every DDIM step
         self.cache_prompt_embeds = True
         self._prompt_cache = {}
@@ -214,8 +215,16 @@ class VideoUpscalePipeline(ConfigMixin):
     def _stream_set(self, device, n_windows, do_cfg):
         """The side streams this call issues its independent units on (uav/streams.py), or None = everything on the caller's
         stream: GPU only, not together with the multi-GPU sharding, and only when there is something to overlap — two or more
-        unique temporal windows, or the guidance branches when `overlap_split_cfg` asks for them."""
+        unique temporal windows, or the guidance branches when `overlap_split_cfg` asks for them.  Every side stream owns a
+        caching-allocator pool (blocks freed there are not reusable by the caller's stream) and two units are live at once, so
+        the overlap is skipped when less than `overlap_min_free_fraction` of the device memory is free."""
         if self.overlap_streams <= 1 or self.shard_windows or torch.device(device).type != "cuda":
+            return None
+        try:
+            free, total = torch.cuda.mem_get_info(device)
+        except (RuntimeError, AssertionError):       # no HIP runtime (host-logic tests with stand-in streams): nothing to gate on
+            free, total = 1, 1
+        if free < self.overlap_min_free_fraction * total:
             return None
         if n_windows > 1 or (self.overlap_split_cfg and do_cfg):
             return streams.stream_set(device, self.overlap_streams)
@@ -301,6 +310,15 @@ class VideoUpscalePipeline(ConfigMixin):
         # stream (UNetVideoModel.stream_dtype): the UNet's fp32 output rows, the guided output (CFG multiplies the
         # rounding error of its two inputs by ~2*guidance), x0 and the latents then stay fp32 from step to step.
         lat_dtype = torch.float32 if getattr(self.unet, "stream_f32", lambda: False)() else torch.float16
+        if self.__dict__.get("_logged_mode") != lat_dtype:          # once per mode: users of the released CLI expect `.half()` arithmetic
+            self.__dict__["_logged_mode"] = lat_dtype
+            import logging
+            logging.getLogger("uav").info(
+                "VideoUpscalePipeline: UNet residual stream / latents in %s (%s); set unet.stream_dtype = torch.float16 or "
+                "UAV_UNET_STREAM=f16 before building the UNet for the reference's all-fp16 `.half()` arithmetic",
+                "fp32" if lat_dtype == torch.float32 else "fp16",
+                "default: fp16 MFMA operands on fp32 rows, inside 1e-3 of the reference's fp32 run" if lat_dtype == torch.float32
+                else "the reference CLI's precision mix")
 
         # 4/5. LR frames: fp32 copy for the VAE conditioning, fp16 + noise for the UNet (:542-551)
         image_dec = image.clone().to(dtype=torch.float32, device=device)
@@ -333,10 +351,10 @@ class VideoUpscalePipeline(ConfigMixin):
         if do_cfg:
             hit = self.__dict__.get("_pe_branch")
             if hit is None or hit[0] is not prompt_embeds or hit[1] != prompt_embeds._version:
-                hit = (prompt_embeds, prompt_embeds._version, [prompt_embeds[b:b + 1].contiguous() for b in range(prompt_embeds.shape[0])])
-                E.publish()
+                hit = (prompt_embeds, prompt_embeds._version,
+                       E.publish([prompt_embeds[b:b + 1].contiguous() for b in range(prompt_embeds.shape[0])]))
                 self.__dict__["_pe_branch"] = hit
-            pe_branch = hit[2]
+            pe_branch = E.acquire(hit[2])
         if flows_bi is not None and len(propagation_steps) > 0:
             # reference :651: `flows_bi[k].to(latents)` — the flows follow the latent dtype
             flows_f = flows_bi[0].to(device=device, dtype=lat_dtype)

@@ -227,7 +227,9 @@ class _ResnetBase(E.EngineModule):
         osc = 1.0 / self.output_scale_factor
         if self.conv_shortcut is not None and raw16 is not None and E.FUSE_SHORTCUT and isinstance(self.conv2, InflatedConv3d) \
                 and tuple(self.conv2.stride) == (1, 1) and tuple(self.conv_shortcut.kernel_size) == (1, 1) \
-                and raw16.shape[-1] % 64 == 0:
+                and raw16.shape[-1] % 64 == 0 and self.conv2.in_channels % 64 == 0 and h.shape[-1] == self.conv2.in_channels:
+            # (the packed shortcut weights sit at K offset conv2.in_channels: only when the branch rows carry exactly that many
+            # channels — no channel padding — do the two sources line up with the packing; otherwise the unfused path below)
             # conv_shortcut([x | x2]) + conv2(h) in ONE implicit GEMM: the raw copy (fp16, or hi | lo halves) is the second
             # source and multiplies the centre tap only; no fp32 shortcut tensor is written and read back as the residual
             cw = E.packed_conv_with_shortcut(self, "conv2+shortcut", self.conv2, self.conv_shortcut, 2 if want_raw == "hilo" else 1)

@@ -181,6 +181,7 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
         # arithmetic of the reference's `.half()` UNet (inference_upscale_a_video.py:113-118).  None: UAV_UNET_STREAM
         # (f32 | f16), see DESIGN.md §4 for the measured parity / cost of both.
         self.stream_dtype = None
+        self.__dict__["_env_stream"] = os.environ.get("UAV_UNET_STREAM", DEFAULT_STREAM)      # read once, at construction
 
     # ------------------------------------------------------------------------------------------
     def _embedding(self, timestep, class_labels, bsz, dev):
@@ -214,9 +215,9 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
                 if idx is None:
                     if len(cache) >= 16:
                         cache.clear()
-                    idx = class_labels.to(dev).reshape(-1)
-                    E.publish()
+                    idx = E.publish(class_labels.to(dev).reshape(-1))
                     cache[key] = idx
+                E.acquire(idx)
             else:
                 idx = class_labels.to(dev).reshape(-1)
             ce = tab.index_select(0, idx)                                        # embedding lookup (gather)
@@ -224,9 +225,11 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
         return emb.contiguous()
 
     def stream_f32(self):
+        """Residual-stream precision of this model: `stream_dtype` when set, else UAV_UNET_STREAM as it stood when the model was
+        BUILT (resolved once in __init__, not per forward), else DEFAULT_STREAM."""
         sd = self.stream_dtype
         if sd is None:
-            return os.environ.get("UAV_UNET_STREAM", DEFAULT_STREAM) == "f32"
+            return self.__dict__.get("_env_stream", DEFAULT_STREAM) == "f32"
         return sd == torch.float32
 
     @E.guarded
@@ -253,11 +256,10 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
         srcs = self.__dict__.get("_ehs_src", ())
         src = next((s_ for s_ in srcs if s_[0] is ehs and s_[1] == ehs._version), None)
         if src is None:
-            rows = ehs.to(device=dev, dtype=torch.float16).reshape(-1, ehs.shape[-1]).contiguous()
-            E.publish()
+            rows = E.publish(ehs.to(device=dev, dtype=torch.float16).reshape(-1, ehs.shape[-1]).contiguous())
             src = (ehs, ehs._version, rows)
             self.__dict__["_ehs_src"] = (src,) + tuple(srcs)[:3]
-        ehs_rows = src[2]                      # the local tuple, not the attribute: another stream's thread may have replaced it
+        ehs_rows = E.acquire(src[2])           # the local tuple, not the attribute: another stream's thread may have replaced it
         n_text = ehs.shape[1]
 
         # Classifier-free guidance feeds the same latents / low_res / timestep to both batch entries and only the

@@ -76,19 +76,45 @@ class PackedCache:
         stamp = _stamp(src)
         hit = self.store.get(key)
         if hit is None or hit[0] != stamp:
-            hit = (stamp, builder())
-            publish()
+            hit = (stamp, publish(builder()))
             self.store[key] = hit
-        return hit[1]
+        return acquire(hit[1])
 
 
-def publish():
-    """Called after a SHARED, lazily built device object (packed weights, tables, text K/V) was produced on the current stream
-    and before it becomes visible to other callers: host-waits for that stream, so that a caller on ANOTHER stream (the two
-    clips of the serving mode, the overlapped guidance branches / decode chunks of `uav.streams`) never reads it before the
-    kernels that fill it have run.  Once per object, not on the steady-state path."""
-    if torch.cuda.is_available() and torch.cuda.is_initialized():
+# Shared, lazily built device objects (packed weights, tables, text K/V, prompt rows) are produced on whatever stream first needs
+# them and then used from any stream (the two clips of the serving mode, the overlapped windows / decode chunks of `uav.streams`).
+# Ordering without a host rendezvous: the builder records an EVENT behind the kernels that fill the object
+# (`publish(obj)`); until that event has completed, every user makes its own current stream wait for it (`acquire(obj)`) — a
+# device-side dependency, the host never blocks.  `_PENDING` is empty in the steady state, so the check is one dict truth test.
+_PENDING = {}          # id(obj) -> (obj, event): objects whose build may still be in flight
+
+
+def publish(obj=None):
+    """Call right after the kernels that fill the shared object `obj` were issued on the current stream."""
+    if not (torch.cuda.is_available() and torch.cuda.is_initialized()):
+        return obj
+    if obj is None:                                  # no handle to hang the event on: host-wait (legacy form)
         torch.cuda.current_stream().synchronize()
+        return obj
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream())
+    if len(_PENDING) > 256:                          # builds that nobody asked for again: retire the completed ones
+        for k in [k for k, (_, e) in list(_PENDING.items()) if e.query()]:
+            _PENDING.pop(k, None)
+    _PENDING[id(obj)] = (obj, ev)
+    return obj
+
+
+def acquire(obj):
+    """Call before using a shared object that some stream may still be building; returns `obj`."""
+    if _PENDING:
+        hit = _PENDING.get(id(obj))
+        if hit is not None and hit[0] is obj:
+            if hit[1].query():
+                _PENDING.pop(id(obj), None)
+            else:
+                torch.cuda.current_stream().wait_event(hit[1])
+    return obj
 
 
 class EngineModule(nn.Module):

@@ -13,7 +13,7 @@ Ordering rules that make this safe with torch's caching allocator (no `record_st
   * the caller's stream waits for every side stream used before `map` returns (outputs are consumed there);
   * tensors allocated while a side stream is current live in that stream's pool and are only reused by later work on the
     SAME stream; inputs freed by the caller are reused on the caller's stream, which by then waits for the side streams;
-  * shared lazily-built device objects (packed weights, tables, text K/V) are published with a host wait (`engine.publish`).
+  * shared lazily-built device objects (packed weights, tables, text K/V) carry an event of their build (`engine.publish`) that every user stream waits for on the device (`engine.acquire`) until it has completed; the host never blocks.
 Results are bit-identical to the serial evaluation: the units and their kernels are the same, only their order in time changes.
 """
 import torch
