@@ -86,6 +86,12 @@ def main():
             E.BRANCH_F32 = "branch16" not in mode
             E.TOKEN_F32 = "-tok16" not in mode
             E.TAIL_HILO = "-hilotail" in mode
+            # "-only:up8" / "-only:down64" ...: hi|lo on ONE sampler (kind + input height at this 64x64 clip)
+            E.SAMPLER_HILO_SKIP = set()
+            if "-only:" in mode:
+                keep = mode.split("-only:")[1].split("-")[0]
+                allk = [("down", 64), ("down", 32), ("down", 16), ("up", 8), ("up", 16), ("up", 32)]
+                E.SAMPLER_HILO_SKIP = {k for k in allk if f"{k[0]}{k[1]}" != keep}
             E.SAMPLER_HILO = "down" if "-hilodown" in mode else "up" if "-hiloup" in mode else ("-hilosamp" in mode)   # product knob
             E.TOKEN_F32_MAX_HW = 256 if "toponly16" in mode else 0      # 64x64 input: levels 32x32 / 16x16 / 8x8 tokens per frame
             keep = set(mode.split("+")[1:])

@@ -95,7 +95,7 @@ class Upsample3D(E.EngineModule):
     def run(self, x, g: E.Geom, output_size=None):
         conv = self.conv if self.name == "conv" else self.Conv2d_0
         s32 = x.dtype == torch.float32           # fp32 residual stream (VAE decoder): x is also this conv's operand
-        hilo = s32 and E.SAMPLER_HILO in (True, "up") and self.channels % 64 == 0
+        hilo = s32 and E.SAMPLER_HILO in (True, "up") and self.channels % 64 == 0 and ("up", g.h) not in E.SAMPLER_HILO_SKIP
         x = E.hilo_rows(x) if hilo else ops.cast_f16(x)
         if output_size is None or tuple(output_size[-2:]) == (2 * g.h, 2 * g.w):
             g2 = g.with_hw(2 * g.h, 2 * g.w)
@@ -163,7 +163,7 @@ class Downsample3D(E.EngineModule):
 
     def run(self, x, g: E.Geom):
         s32 = x.dtype == torch.float32           # fp32 residual stream: x is this conv's MFMA operand, the output is stream
-        hilo = s32 and E.SAMPLER_HILO in (True, "down") and self.channels % 64 == 0
+        hilo = s32 and E.SAMPLER_HILO in (True, "down") and self.channels % 64 == 0 and ("down", g.h) not in E.SAMPLER_HILO_SKIP
         x = E.hilo_rows(x) if hilo else ops.cast_f16(x)
         if self.padding == 0:
             # reference pads (0,1,0,1) then convolves with pad 0 (resnet.py:188-192): the right /

@@ -290,6 +290,8 @@ FUSE_SHORTCUT = _os.environ.get("UAV_FUSE_SHORTCUT", "1") != "0"
 # TemporalModule3D (operand of shift_conv), fp16 tensors that carry a whole residual sum — as fp32 rows read through the same
 # hi | lo pair by their 1x1 consumer?  UAV_TAIL_HILO (CPU emulation: 7.5e-4 -> 6.5e-4 per forward).
 TAIL_HILO = _os.environ.get("UAV_TAIL_HILO", "0") != "0"
+# samplers left on a single fp16 operand although SAMPLER_HILO is on: ("up" | "down", input height) pairs (numerics experiments)
+SAMPLER_HILO_SKIP = set()
 SAMPLER_HILO = {"0": False, "1": True}.get(_os.environ.get("UAV_SAMPLER_HILO", "1"), _os.environ.get("UAV_SAMPLER_HILO", "1"))
 
 
