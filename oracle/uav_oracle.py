@@ -417,8 +417,9 @@ class DDIM:
 
 def add_noise(x, noise, level, beta_start=0.0001, beta_end=0.02, n=1000):
     """low_res_scheduler.add_noise (DDPMScheduler, scaled_linear; math scheduling_ddim.py:524-545)."""
-    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32) ** 2
-    ac = torch.cumprod(1.0 - betas, dim=0)[level]
+    # device-explicit (the GPU shim's `torch.device` context was seen NOT to reach this factory call in a long pytest process)
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, n, dtype=torch.float32, device=x.device) ** 2
+    ac = torch.cumprod(1.0 - betas, dim=0)[level.to(x.device)]
     return ac ** 0.5 * x + (1 - ac) ** 0.5 * noise
 
 
