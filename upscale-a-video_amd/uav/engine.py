@@ -228,9 +228,14 @@ def packed_upsample_phases(mod: EngineModule, name, conv: nn.Module, dup=False):
     def build():
         dev = _dev(conv.weight)
         ph = ops.upsample_phase_weights(conv.weight)
+        cin = ph[0][0].shape[1]
         if dup:
             ph = [[torch.cat([ph[py][px]] * 2, dim=1) for px in range(2)] for py in range(2)]
-        return [[ops.pack_conv(ph[py][px], conv.bias, device=dev) for px in range(2)] for py in range(2)]
+        cws = [[ops.pack_conv(ph[py][px], conv.bias, device=dev) for px in range(2)] for py in range(2)]
+        for row in cws:
+            for cw in row:
+                cw.cin = cin          # logical channels (FLOP accounting: the lo half is implementation overhead, not algorithmic work)
+        return cws
     return mod._cache().get(("up_phases", name, dup), build, (conv.weight, conv.bias))
 
 
