@@ -1181,8 +1181,19 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
 //     path works while the matrix pipe does, and M0 (LDS destination) is written by s_add right before each.
 // Stage hand-over is unchanged (2 stages, vmcnt(0) + barrier per k-step), so the numerics and the tile walk are
 // bit-identical to the round-1 kernel (tests/test_fullsize_gpu.py compares them).
+//
+// V = 5 / 6 — ROTATED k-step (round 4).  The product loop (V = 1) hands a stage over at the k-step boundary: `vmcnt(0)` + barrier,
+// THEN the first fragment reads of the new stage, THEN the first MFMA — every k-step starts with the matrix pipe empty for one LDS
+// round trip of 8 waves x 12 reads (the waves' last MFMAs were issued before the barrier).  Here the single barrier of a k-step
+// sits after its third MFMA slice: by then all fragment reads of stage k are complete (WAR: the buffer may be overwritten) and the
+// DMA of stage k+1, issued a full k-step earlier, has landed (RAW, `vmcnt(0)`); behind the barrier the wave requests the FIRST
+// fragments of stage k+1 and issues the DMA of stage k+2, and both fly while the fourth MFMA slice of stage k — operands already in
+// registers — keeps the matrix pipe busy.  Still one barrier and one full drain per k-step, same LDS image, fragment reads,
+// per-accumulator K order and epilogue: bit-identical.  V = 5: all 8 DMA pieces behind the barrier (two per MFMA pair); V = 6: the 4
+// X pieces there, the 4 W pieces spread over the first MFMA slice of the next k-step.
 template <int V, int GNK = 0, int LNF = 0>
 __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
+    constexpr bool ROT = V == 5 || V == 6;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1304,18 +1315,25 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
     const unsigned ldsepi = ldsb + 2 * LSTAGE;
     float4_t stg = {0.f, 0.f, 0.f, 0.f};
     unsigned stg_dst = 0;                                // 0 = this thread stages nothing
+    const float* stg_src = nullptr;
     if (tid < 64) {
-        if (p.bias) { stg = *(const float4_t*)(p.bias + n0 + 4 * tid); stg_dst = ldsepi + tid * 16; }
+        if (p.bias) { stg_src = p.bias + n0 + 4 * tid; stg_dst = ldsepi + tid * 16; }
     } else if (LNF == 2 && tid < 128) {              // LayerNorm-fold consumer: colsum(W') of the tile's columns takes row block 0
         const int piece = tid - 64;
-        stg = *(const float4_t*)(p.lnc_colsum + n0 + 4 * piece);
+        stg_src = p.lnc_colsum + n0 + 4 * piece;
         stg_dst = ldsepi + 1024 + piece * 16;
     } else if (tid < 320 && p.rowbias) {
         const int blk = (tid - 64) >> 6, piece = (tid - 64) & 63;
         long long mrow = m0 + blk * 64; if (mrow >= p.M) mrow = 0;
         const int col = n0 + 4 * piece;
-        if (col + 4 <= p.n) stg = *(const float4_t*)(p.rowbias + (long long)((int)(mrow / p.rows_per_batch)) * p.rowbias_stride + col);
+        if (col + 4 <= p.n) stg_src = p.rowbias + (long long)((int)(mrow / p.rows_per_batch)) * p.rowbias_stride + col;
         stg_dst = ldsepi + 1024 + blk * 1024 + piece * 16;
+    }
+    if (stg_src) {
+        // ROT: by inline asm — hipcc must not know this load, or it puts `s_waitcnt vmcnt(0)` in front of the LDS store below and
+        // drains the two stages of DMA issued in between (the kernel counts vmcnt itself)
+        if (ROT) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(stg) : "v"(stg_src) : "memory");
+        else stg = *(const float4_t*)stg_src;
     }
 
     // LDS-DMA pieces of one stage: X rows ps*64.. -> +ps*8 KiB, W rows likewise behind the 32-KiB X tile.  M0 carries
@@ -1346,6 +1364,21 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
                      : [m0s] "=&s"(m0s) : DMA_OPERANDS : "memory", "scc", "vcc");
     }
     if (nk > 1) COMPUTE_ADDR()
+    long long wkb_head = 0;                              // ROT, V = 6: W offset of the stage whose W pieces the next k-step's head issues
+    if (ROT) {
+        if (nk > 1) {                                    // stage 1 -> buffer 1 right away, then the addresses of stage 2
+            const char* gw0 = wtile + wkb; const char* gw1 = gw0 + wps; const char* gw2 = gw1 + wps; const char* gw3 = gw2 + wps;
+            const unsigned ldsn = ldsw + LSTAGE, dodma = __builtin_amdgcn_readfirstlane(1u);
+            unsigned m0s;
+            asm volatile("s_mov_b32 %[m0s], m0\n" "s_cmp_lg_u32 %[dodma], 0\n" "s_cselect_b64 vcc, -1, 0\n"
+                         D0 D1 D2 D3 D4 D5 D6 D7 "s_mov_b32 m0, %[m0s]\n"
+                         : [m0s] "=&s"(m0s) : DMA_OPERANDS : "memory", "scc", "vcc");
+            if (nk > 2) COMPUTE_ADDR()
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");         // stage 0 (and the epilogue constants, older still) have landed
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
     if (stg_dst) *(__attribute__((address_space(3))) float4_t*)(size_t)stg_dst = stg;
 
 #define RD(D, A, OFF) "ds_read_b128 %[" #D "], %[" #A "] offset:" #OFF "\n"
@@ -1371,6 +1404,72 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
 #define RD_OPERANDS                                                                                              \
     [aw0] "v"(aw0), [aw1] "v"(aw1), [aw2] "v"(aw2), [aw3] "v"(aw3), [ax0] "v"(ax0), [ax1] "v"(ax1), [ax2] "v"(ax2), [ax3] "v"(ax3)
 
+    if constexpr (ROT) {
+        // fragment set 0 lives ACROSS k-steps: it is requested behind the barrier of k-step k-1 (here: behind the prologue's) and
+        // consumed by the first MFMA slice of k-step k
+        half8_t w00, w01, w02, w03, x00, x01, w10, w11, w12, w13, x10, x11;
+        __builtin_amdgcn_s_barrier();                    // stage 0 of every wave has landed, the epilogue constants are in LDS
+        asm volatile("" ::: "memory");
+        {
+            const unsigned aw0 = bW + so[0], ax0 = bX + so[0];
+            asm volatile(RDSET(0, aw0, ax0)
+                         : [w00] "=&v"(w00), [w01] "=&v"(w01), [w02] "=&v"(w02), [w03] "=&v"(w03), [x00] "=&v"(x00), [x01] "=&v"(x01)
+                         : [aw0] "v"(aw0), [ax0] "v"(ax0) : "memory");
+        }
+        int cur = 0;
+        for (int ks = 0; ks < nk; ++ks) {
+            const unsigned sb = cur * LSTAGE, sn = (cur ^ 1) * LSTAGE;
+            const unsigned aw1 = bW + sb + so[1], aw2 = bW + sb + so[2], aw3 = bW + sb + so[3];
+            const unsigned ax1 = bX + sb + so[1], ax2 = bX + sb + so[2], ax3 = bX + sb + so[3];
+            const unsigned aw0 = bW + sn + so[0], ax0 = bX + sn + so[0];            // first slice of the NEXT stage (other buffer)
+            // tail: DMA of stage ks+2 (X pieces; V = 5: W pieces too) into THIS k-step's buffer, released by the barrier below
+            const char* gw0 = wtile + (V == 6 ? wkb_head : wkb); const char* gw1 = gw0 + wps; const char* gw2 = gw1 + wps; const char* gw3 = gw2 + wps;
+            const unsigned ldsn = ldsw + cur * LSTAGE;                               // X pieces of stage ks+2 (and its W pieces, V = 5)
+            const unsigned ldsh = ldsw + (cur ^ 1) * LSTAGE;                         // V = 6 head: W pieces of stage ks+1
+            const unsigned dodma = __builtin_amdgcn_readfirstlane(ks + 2 < nk ? 1u : 0u);
+            const unsigned dohead = __builtin_amdgcn_readfirstlane((V == 6 && ks >= 1 && ks + 1 < nk) ? 1u : 0u);
+            const unsigned more = __builtin_amdgcn_readfirstlane(ks + 1 < nk ? 1u : 0u);
+            unsigned m0s;
+#define DWH(I, OFF) "s_cbranch_vccz .Lnh%=_" #I "\n" "s_add_u32 m0, %[ldsh], " #OFF "\n" "s_nop 0\n" "global_load_lds_dwordx4 %[woff], %[gw" #I "]\n" ".Lnh%=_" #I ":\n"
+#define ROT_OPERANDS                                                                                             \
+    [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]),                  \
+    [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]), [c30] "+v"(acc[3][0]), [c31] "+v"(acc[3][1]),                  \
+    [w00] "+v"(w00), [w01] "+v"(w01), [w02] "+v"(w02), [w03] "+v"(w03), [x00] "+v"(x00), [x01] "+v"(x01),        \
+    [w10] "=&v"(w10), [w11] "=&v"(w11), [w12] "=&v"(w12), [w13] "=&v"(w13), [x10] "=&v"(x10), [x11] "=&v"(x11), [m0s] "=&s"(m0s)
+#define ROT_INPUTS                                                                                               \
+    [aw0] "v"(aw0), [aw1] "v"(aw1), [aw2] "v"(aw2), [aw3] "v"(aw3), [ax0] "v"(ax0), [ax1] "v"(ax1), [ax2] "v"(ax2), [ax3] "v"(ax3), \
+    [ldsh] "s"(ldsh), [dohead] "s"(dohead), [more] "s"(more), DMA_OPERANDS
+#define ROT_BODY(H0, H1, H2, H3, T0, T1, T2, T3)                                                                 \
+    "s_mov_b32 %[m0s], m0\n" "s_cmp_lg_u32 %[dohead], 0\n" "s_cselect_b64 vcc, -1, 0\n"                          \
+    RDSET(1, aw1, ax1)                                                                                           \
+    MFSETD(0, 10, 9, 8, 7, 6, H0, H1, H2, H3) RDSET(0, aw2, ax2)                                                 \
+    MFSETD(1, 10, 9, 8, 7, 6, NO, NO, NO, NO) RDSET(1, aw3, ax3)                                                 \
+    MFSETD(0, 10, 9, 8, 7, 6, NO, NO, NO, NO)                                                                    \
+    "s_waitcnt lgkmcnt(0)\n"                                                                                     \
+    "s_cmp_lg_u32 %[more], 0\n" "s_cbranch_scc0 .Lnb%=\n"                                                        \
+    "s_waitcnt vmcnt(0)\n" "s_barrier\n"                                                                         \
+    RDSET(0, aw0, ax0)                                                                                           \
+    ".Lnb%=:\n"                                                                                                  \
+    "s_cmp_lg_u32 %[dodma], 0\n" "s_cselect_b64 vcc, -1, 0\n"                                                    \
+    MFSETD(1, 6, 6, 6, 6, 6, T0, T1, T2, T3)                                                                     \
+    "s_mov_b32 m0, %[m0s]\n"
+            if constexpr (V == 5) {
+                asm volatile(ROT_BODY(NO, NO, NO, NO, D0 D1, D2 D3, D4 D5, D6 D7) : ROT_OPERANDS : ROT_INPUTS : "memory", "scc", "vcc");
+            } else {
+                asm volatile(ROT_BODY(DWH(0, 32768), DWH(1, 40960), DWH(2, 49152), DWH(3, 57344), D0, D1, D2, D3)
+                             : ROT_OPERANDS : ROT_INPUTS : "memory", "scc", "vcc");
+            }
+#undef DWH
+#undef ROT_OPERANDS
+#undef ROT_INPUTS
+#undef ROT_BODY
+            // addresses of stage ks+3 (its X pieces go out behind the next barrier); V = 6 keeps the W offset of stage ks+2 for the
+            // next k-step's head
+            wkb_head = wkb;
+            if (ks + 3 < nk) COMPUTE_ADDR()
+            cur ^= 1;
+        }
+    } else {
     int cur = 0;
     for (int ks = 0; ks < nk; ++ks) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1401,6 +1500,7 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
         if (ks + 2 < nk) COMPUTE_ADDR()
         cur ^= 1;
     }
+    }   // !ROT
 #undef RD
 #undef RDSET
 #undef MF
@@ -1610,7 +1710,11 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
                                  (const void*)conv_gemm256i_kernel<1>, (const void*)conv_gemm256i_kernel<2>,
                                  (const void*)conv_gemm256i_kernel<3>, (const void*)conv_gemm256i_kernel<1, 1>,
                                  (const void*)conv_gemm256i_kernel<1, 2>, (const void*)conv_gemm256i_kernel<1, 3>,
-                                 (const void*)conv_gemm256i_kernel<1, 0, 1>, (const void*)conv_gemm256i_kernel<1, 0, 2>};
+                                 (const void*)conv_gemm256i_kernel<1, 0, 1>, (const void*)conv_gemm256i_kernel<1, 0, 2>,
+                                 (const void*)conv_gemm256i_kernel<5>, (const void*)conv_gemm256i_kernel<5, 1>,
+                                 (const void*)conv_gemm256i_kernel<5, 2>, (const void*)conv_gemm256i_kernel<5, 3>,
+                                 (const void*)conv_gemm256i_kernel<6>, (const void*)conv_gemm256i_kernel<6, 1>,
+                                 (const void*)conv_gemm256i_kernel<6, 2>, (const void*)conv_gemm256i_kernel<6, 3>};
             for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE + LEPI_BYTES);
             hipDeviceProp_t prop;
             dev_ncu[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
@@ -1620,7 +1724,13 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         a.ntiles = (unsigned)grid256;
         if (a.lnp_raw) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 0, 1>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
         else if (a.lnc_stat) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 0, 2>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
-        else if (a.gn_ws) {                // statistics-reducing instances of the production kernel (env A/B switches do not apply)
+        else if (a.gn_ws && (env.dmav == 5 || env.dmav == 6)) {       // rotated k-step, statistics-reducing instances
+            const int gnm = gn_mode_of(a.gn_cpg_log2);
+#define UAV_LAUNCH_ROT(V, G) hipLaunchKernelGGL((conv_gemm256i_kernel<V, G>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a)
+            if (env.dmav == 5) { if (gnm == 1) UAV_LAUNCH_ROT(5, 1); else if (gnm == 2) UAV_LAUNCH_ROT(5, 2); else UAV_LAUNCH_ROT(5, 3); }
+            else { if (gnm == 1) UAV_LAUNCH_ROT(6, 1); else if (gnm == 2) UAV_LAUNCH_ROT(6, 2); else UAV_LAUNCH_ROT(6, 3); }
+#undef UAV_LAUNCH_ROT
+        } else if (a.gn_ws) {              // statistics-reducing instances of the production kernel (other env A/B switches do not apply)
             const int gnm = gn_mode_of(a.gn_cpg_log2);
             if (gnm == 1) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 1>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
             else if (gnm == 2) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 2>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
@@ -1631,6 +1741,8 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         else if (dbg == 3) hipLaunchKernelGGL(conv_gemm256_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 5) hipLaunchKernelGGL(conv_gemm256_kernel<5>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 6) hipLaunchKernelGGL(conv_gemm256_kernel<6>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
+        else if (env.dmav == 5) hipLaunchKernelGGL(conv_gemm256i_kernel<5>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
+        else if (env.dmav == 6) hipLaunchKernelGGL(conv_gemm256i_kernel<6>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
         else if (env.dmav == 1) hipLaunchKernelGGL(conv_gemm256i_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
         else if (env.dmav == 2) hipLaunchKernelGGL(conv_gemm256i_kernel<2>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
         else if (env.dmav == 3) hipLaunchKernelGGL(conv_gemm256i_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
