@@ -23,7 +23,7 @@ from uav import build as _build  # noqa: E402
 out = {"kernel_sources_digest": _build.conv_kernel_digest(),     # bench.py replays this file only for the library built from these sources
        "command": "rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_WRREQ_64B_sum -- "
                   "python bench.py --no-cpu-baseline --no-kernel-events --warmup 0 --steps 1",
-       "kernels": "conv_gemm_kernel<*>, conv_gemm256i_kernel<1, *> (all fp16 implicit-GEMM launches)", "launches": launches, "counters": c,
+       "kernels": "conv_gemm_kernel<*>, conv_gemm256i_kernel<*> (all fp16 implicit-GEMM launches)", "launches": launches, "counters": c,
        "read_bytes_per_launch": rd / launches, "write_bytes_per_launch": wr / launches,
        "hbm_bytes_per_launch": (rd + wr) / launches}
 json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_conv_traffic.json"), "w"), indent=1)

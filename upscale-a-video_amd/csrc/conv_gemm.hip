@@ -1189,8 +1189,10 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256_kernel(ConvArgs p) {
 // DMA of stage k+1, issued a full k-step earlier, has landed (RAW, `vmcnt(0)`); behind the barrier the wave requests the FIRST
 // fragments of stage k+1 and issues the DMA of stage k+2, and both fly while the fourth MFMA slice of stage k — operands already in
 // registers — keeps the matrix pipe busy.  Still one barrier and one full drain per k-step, same LDS image, fragment reads,
-// per-accumulator K order and epilogue: bit-identical.  V = 5: all 8 DMA pieces behind the barrier (two per MFMA pair); V = 6: the 4
-// X pieces there, the 4 W pieces spread over the first MFMA slice of the next k-step.
+// per-accumulator K order and epilogue: bit-identical.  V = 6 (THE DEFAULT since round 4: +1.1 % per clip, `r04_ab_conv_rotated_kstep_run8.log`):
+// the 4 X pieces of stage k+2 behind the barrier, its 4 W pieces spread over the first MFMA slice of the next k-step; V = 5 (all 8
+// pieces behind the barrier, two per MFMA pair) measured the same and is not instantiated.  V = 1 (the round 2-3 loop) stays for
+// A/B (`UAV_CONV_DMAV=1`) and carries the LayerNorm-fold instances; V = 2 / 3 were round-2 DMA-slot placements.
 template <int V, int GNK = 0, int LNF = 0>
 __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
     constexpr bool ROT = V == 5 || V == 6;
@@ -1538,7 +1540,7 @@ const ConvEnv& conv_env() {
     static const ConvEnv env = [] {
         auto geti = [](const char* k, int d) { const char* e = getenv(k); return e ? atoi(e) : d; };
         return ConvEnv{geti("UAV_CONV_KORDER", 1), geti("UAV_CONV_TILE_ORDER", 1), geti("UAV_CONV_TILE", 0),
-                       geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0), geti("UAV_CONV_DMAV", 1)};
+                       geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0), geti("UAV_CONV_DMAV", 6)};      // 6: rotated k-step (round 4 default); 1: round 2-3 loop
     }();
     return env;
 }
@@ -1580,7 +1582,9 @@ bool conv_ln_ok(const uav_conv_params* q) {
     const long long M = (long long)q->n_img * q->ho * q->wo;
     const ConvEnv& env = conv_env();
     if (!conv_uses_big_tile(q) || (M % 64) || (q->n % 128) || q->out_map_w || q->gn_partials || q->rowbias || !q->bias) return false;
-    if (env.dbg || env.persist || env.dmav != 1 || (q->flags & (UAV_CONV_PERSISTENT | UAV_CONV_GELU | UAV_CONV_QUICK_GELU))) return false;
+    if (env.dbg || env.persist || (env.dmav != 1 && env.dmav != 6) ||
+        (q->flags & (UAV_CONV_PERSISTENT | UAV_CONV_GELU | UAV_CONV_QUICK_GELU)))
+        return false;                                      // (the LayerNorm-fold instances themselves run the V = 1 loop)
     const bool of32 = q->flags & UAV_CONV_OUT_F32, rf32 = q->flags & UAV_CONV_RES_F32;
     if (q->ln_raw_out) {                                   // producer: fp32 result (+ fp32 residual), rows of n = out_stride values
         if (!q->ln_stat_out || !of32 || (q->flags & UAV_CONV_GEGLU) || (q->out_stride & 3) || q->out_stride != q->n ||
@@ -1707,12 +1711,9 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
                                  (const void*)conv_gemm256_kernel<2>, (const void*)conv_gemm256_kernel<3>,
                                  (const void*)conv_gemm256_kernel<4>, (const void*)conv_gemm256_kernel<5>,
                                  (const void*)conv_gemm256_kernel<6>, (const void*)conv_gemm256_kernel<0, 1>,
-                                 (const void*)conv_gemm256i_kernel<1>, (const void*)conv_gemm256i_kernel<2>,
-                                 (const void*)conv_gemm256i_kernel<3>, (const void*)conv_gemm256i_kernel<1, 1>,
+                                 (const void*)conv_gemm256i_kernel<1>, (const void*)conv_gemm256i_kernel<1, 1>,
                                  (const void*)conv_gemm256i_kernel<1, 2>, (const void*)conv_gemm256i_kernel<1, 3>,
                                  (const void*)conv_gemm256i_kernel<1, 0, 1>, (const void*)conv_gemm256i_kernel<1, 0, 2>,
-                                 (const void*)conv_gemm256i_kernel<5>, (const void*)conv_gemm256i_kernel<5, 1>,
-                                 (const void*)conv_gemm256i_kernel<5, 2>, (const void*)conv_gemm256i_kernel<5, 3>,
                                  (const void*)conv_gemm256i_kernel<6>, (const void*)conv_gemm256i_kernel<6, 1>,
                                  (const void*)conv_gemm256i_kernel<6, 2>, (const void*)conv_gemm256i_kernel<6, 3>};
             for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE + LEPI_BYTES);
@@ -1724,12 +1725,11 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         a.ntiles = (unsigned)grid256;
         if (a.lnp_raw) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 0, 1>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
         else if (a.lnc_stat) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 0, 2>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
-        else if (a.gn_ws && (env.dmav == 5 || env.dmav == 6)) {       // rotated k-step, statistics-reducing instances
+        else if (a.gn_ws && env.dmav == 6) {       // rotated k-step (default), statistics-reducing instances
             const int gnm = gn_mode_of(a.gn_cpg_log2);
-#define UAV_LAUNCH_ROT(V, G) hipLaunchKernelGGL((conv_gemm256i_kernel<V, G>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a)
-            if (env.dmav == 5) { if (gnm == 1) UAV_LAUNCH_ROT(5, 1); else if (gnm == 2) UAV_LAUNCH_ROT(5, 2); else UAV_LAUNCH_ROT(5, 3); }
-            else { if (gnm == 1) UAV_LAUNCH_ROT(6, 1); else if (gnm == 2) UAV_LAUNCH_ROT(6, 2); else UAV_LAUNCH_ROT(6, 3); }
-#undef UAV_LAUNCH_ROT
+            if (gnm == 1) hipLaunchKernelGGL((conv_gemm256i_kernel<6, 1>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
+            else if (gnm == 2) hipLaunchKernelGGL((conv_gemm256i_kernel<6, 2>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
+            else hipLaunchKernelGGL((conv_gemm256i_kernel<6, 3>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
         } else if (a.gn_ws) {              // statistics-reducing instances of the production kernel (other env A/B switches do not apply)
             const int gnm = gn_mode_of(a.gn_cpg_log2);
             if (gnm == 1) hipLaunchKernelGGL((conv_gemm256i_kernel<1, 1>), dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
@@ -1741,11 +1741,8 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         else if (dbg == 3) hipLaunchKernelGGL(conv_gemm256_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 5) hipLaunchKernelGGL(conv_gemm256_kernel<5>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
         else if (dbg == 6) hipLaunchKernelGGL(conv_gemm256_kernel<6>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE, s, a);
-        else if (env.dmav == 5) hipLaunchKernelGGL(conv_gemm256i_kernel<5>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
         else if (env.dmav == 6) hipLaunchKernelGGL(conv_gemm256i_kernel<6>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
         else if (env.dmav == 1) hipLaunchKernelGGL(conv_gemm256i_kernel<1>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
-        else if (env.dmav == 2) hipLaunchKernelGGL(conv_gemm256i_kernel<2>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
-        else if (env.dmav == 3) hipLaunchKernelGGL(conv_gemm256i_kernel<3>, dim3((unsigned)grid256), dim3(512), 2 * LSTAGE + LEPI_BYTES, s, a);
         else if ((persist || (q->flags & UAV_CONV_PERSISTENT)) && grid256 > ncu) {
             // persistent form: one workgroup per CU walks tiles wg, wg + ncu, ... (UAV_CONV_PERSIST=0 disables)
             hipLaunchKernelGGL((conv_gemm256_kernel<0, 1>), dim3((unsigned)ncu), dim3(512), 2 * LSTAGE, s, a);
