@@ -954,3 +954,28 @@ def test_dist_gloo_world2():
         assert n_serial == 4 and n_shard == 2      # 2 unique windows x 2 steps; each rank evaluates one window per step
         assert same and n_uniq == 5 and chunk_ids == [float(s) for s in range(0, 32, 3)] and single == 5.0
     assert x0[1] == 3 and x1[1] == 2           # 5 unique windows dealt 3 / 2
+
+
+def test_bench_predicted_scaling_on_the_line():
+    """`config.predicted_scaling`: clip-parallel = N x the per-GPU rate at the assumed efficiency; sharded
+    long clip = ceil(units / N) window units + ceil(chunks / N) decode chunks per GPU, 5 (or 10 with --shard-cfg) units for 32 frames."""
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    a = types.SimpleNamespace(shard_windows=False, shard_cfg=False, frames=8, ddim_steps=30)
+    p = bench.predicted_scaling(a, 1, 1.0)
+    assert p["frames_per_s"]["1"] == 1.0 and abs(p["frames_per_s"]["8"] - 8 * 0.97) < 1e-9
+    a = types.SimpleNamespace(shard_windows=True, shard_cfg=False, frames=32, ddim_steps=30)
+    p = bench.predicted_scaling(a, 1, 0.7)
+    assert p["units_per_step"] == 5 and p["decode_chunks"] == 11
+    assert 1.6 < p["speedup_vs_1_gpu"]["2"] < 1.7 and 2.4 < p["speedup_vs_1_gpu"]["4"] < 2.6 and 4.9 < p["speedup_vs_1_gpu"]["8"] < 5.1
+    a.shard_cfg = True
+    p = bench.predicted_scaling(a, 1, 0.7)
+    assert p["units_per_step"] == 10 and 3.2 < p["speedup_vs_1_gpu"]["4"] < 3.5
+
+
+def test_publish_acquire_are_noops_without_a_gpu():
+    """uav.engine.publish / acquire (event-ordered shared objects) must not touch the HIP runtime on a CPU-only host."""
+    from uav import engine as E
+    obj = object()
+    assert E.publish(obj) is obj and E.acquire(obj) is obj and not E._PENDING
