@@ -411,6 +411,7 @@ def main():
     # Throughput mode BESIDE the serial headline: two clips per GPU on concurrent HIP streams — the HBM-bound
     # kernels of one clip (GroupNorm / LayerNorm passes, the epilogue-bound short-K linears) run beside the power-limited MFMA
     # kernels of the other.  Measured after the timed region (1 warm-up step + 2 timed steps of 2 clips); never the headline value.
+    assert out.shape == (1, 3, args.frames, 4 * args.height, 4 * args.width) and bool(torch.isfinite(out).all())
     two_clip = None
     if world == 1 and ncl == 1 and not args.no_throughput_mode and not args.shard_windows:
         one_step(300, 2)
@@ -511,7 +512,8 @@ def main():
                                "kernel_time_share": share}
             # per kernel: MFMA-bound ones against the dense fp16 peak, HBM-bound ones (algorithmic bytes: every operand
             # read / written once) against the 8 TB/s HBM3E peak
-            hbm_bound = ("groupnorm_stats", "groupnorm_finalize_fused", "groupnorm_apply", "layernorm", "temporal_attention", "attention_d64")
+            hbm_bound = ("groupnorm_stats", "groupnorm_finalize_fused", "groupnorm_apply", "layernorm", "temporal_attention", "attention_d64",
+                         "cast_f16", "cast_hilo")
             res["kernel_breakdown"] = {k: {"launches": v["launches"], "ms": round(v["seconds"] * 1e3, 2),
                                            "tflops": round(v["flops"] / v["seconds"] / 1e12, 1) if v["flops"] else None,
                                            "GBps": round(v["bytes"] / v["seconds"] / 1e9, 1),

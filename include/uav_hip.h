@@ -59,6 +59,10 @@ int  uav_device_check(int dev, char* name_out);
 #define UAV_CONV_GELU       256u /* out = gelu_erf(conv + bias + rowbias) (+ residual) * scale  (CLIP ViT-H MLP) */
 #define UAV_CONV_QUICK_GELU 512u /* x * sigmoid(1.702 x) (OpenAI CLIP MLP) */
 #define UAV_CONV_RES_F32  128u /* `residual` is fp32 [M][res_stride] (fp32 residual stream of the VAE decoder) */
+/* Round 5: 1x1 / stride-1 launches with K = c1 + c2 <= 1024 and n a multiple of 256 run in the short-K kernel (128 x 256
+ * tile, two workgroups per CU, attention.py:523-564 / resnet.py:286-292) — same results bit for bit.  This flag keeps such a
+ * launch in the general 256x256 kernel (A/B measurements and the bit-identity test). */
+#define UAV_CONV_NO_SHORTK 1024u
 
 typedef struct {
     const void*  a1;            /* fp16 source 1, rows of c1 channels */

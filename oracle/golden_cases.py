@@ -158,4 +158,13 @@ FULL_CASES = {
     "pipe_full30_64_prop": dict(t=8, h=64, w=64, steps=30, guidance=6.0, noise_level=120, clip_seed=43,
                                 prompt="best quality, extremely detailed", negative="blur, worst quality",
                                 propagation_steps=(24, 26, 28)),
+    # BASELINE configs[3]'s schedule at the released width: T = 14 -> windows [0,8), [6,14) and the re-anchored duplicate
+    # [6,14) of the reference loop (pipeline_upscale_a_video.py:601-635), epsilon blend over the shared frames, 30 steps
+    "pipe_full30_64_t14": dict(t=14, h=64, w=64, steps=30, guidance=6.0, noise_level=120, clip_seed=47,
+                               prompt="best quality, extremely detailed", negative="blur, worst quality"),
+    # BASELINE configs[4]'s path at the released width: the reference CLI's tile loop (inference_upscale_a_video.py:207-304,
+    # tile_size 64 -> two overlapping tiles 128 and 160 wide, H = 68 is not a multiple of 8) around the pipeline with the
+    # full-width `vae_video` decoder (LR-frame conditioning, SFT fuse; vae_video.py:365-405), 5 steps, one shared generator
+    "pipe_tiled_full_videovae": dict(t=3, h=68, w=160, tile=64, steps=5, guidance=6.0, noise_level=120, clip_seed=53,
+                                     prompt="best quality, extremely detailed", negative="blur, worst quality"),
 }

@@ -725,3 +725,78 @@ def test_layernorm_folded_into_projection(ops, dev, k, n, geglu, res):
     e_plain = rel_l2(y0, ref)
     assert not torch.equal(y, y0)                   # the two paths really are different kernels
     assert e_fold < 1.5e-3 and e_fold < 2.0 * e_plain + 1e-4, (e_fold, e_plain)
+
+
+# ------------------------------------------------------------------------------------------------
+# Short-K kernel (round 5, conv_gemm_sk_kernel: 128 x 256 tile, two workgroups per CU) against the general 256x256 kernel
+# (UAV_CONV_NO_SHORTK) and an fp32 reference — the linears / 1x1 convs of attention.py:523-564, resnet.py:286-292
+SHORTK_CASES = [
+    # name, c1, c2, cout, M, epilogue dict
+    ("to_out_512_f32res", 512, 0, 512, 51200, dict(res="f32", out_f32=True)),
+    ("proj_in_512_f32", 512, 0, 512, 28672 + 64 * 5, dict(out_f32=True, gn=32)),
+    ("to_q_512_f16", 512, 0, 512, 30000, dict()),                                     # M tail: 30000 % 128 = 48
+    ("short_256_res16_gn", 256, 0, 256, 57600, dict(res="f16", gn=32)),
+    ("short_cat_768_256", 512, 256, 256, 57600 + 37, dict(res="f32", out_f32=True)),  # two sources, ragged M
+    ("mid_1024_gn", 1024, 0, 1024, 25600, dict(res="f16", gn=32, scale=1.0 / 1.4)),
+    ("qkv_512_1536", 512, 0, 1536, 30000, dict(bias=False)),
+    ("geglu_512_4096", 512, 0, 4096, 25600, dict(geglu=True)),
+    ("rowbias_f32_gn", 256, 0, 512, 2 * 16384, dict(rowbias=True, out_f32=True, gn=32)),
+    ("rowbias_f16", 128, 0, 512, 2 * 16384, dict(rowbias=True, res="f16")),
+    ("k64_two_stages", 64, 0, 256, 57600, dict(res="f16")),
+    ("k128_res32_f16", 128, 0, 512, 28800, dict(res="f32")),
+    ("bcast_a2", 256, 256, 512, 2 * 16000, dict(a2_half=True, res="f16")),
+]
+
+
+@pytest.mark.parametrize("case", SHORTK_CASES, ids=[c[0] for c in SHORTK_CASES])
+def test_shortk_kernel_bit_identical_to_general_kernel(ops, dev, case):
+    """Same tile-independent per-accumulator K order -> the short-K kernel must reproduce the 256x256 kernel BIT FOR BIT
+    (outputs and fused GroupNorm partials), and both sit inside the conv tolerance against an fp32 reference."""
+    name, c1, c2, cout, M, e = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    cin = c1 + c2
+    geglu = e.get("geglu", False)
+    n_out = cout // 2 if geglu else cout
+    x1 = torch.randn(M, c1, generator=g).half().to(dev)
+    x2 = None
+    if c2:
+        rows2 = M // 2 if e.get("a2_half") else M
+        x2 = torch.randn(rows2, c2, generator=g).half().to(dev)
+    wt = h16(cout, cin, dev=dev, scale=cin ** -0.5, gen=g)
+    bias = torch.randn(cout, generator=g).to(dev) if e.get("bias", True) else None
+    cw = ops.pack_conv(wt.reshape(cout, cin, 1, 1, 1), bias, geglu=geglu, device=dev)
+    assert cw.k_pad == cin and cw.n_pad % 256 == 0
+    res = None
+    if e.get("res"):
+        res = torch.randn(M, n_out, generator=g).to(dev)
+        res = res if e["res"] == "f32" else res.half()
+    nb = 2
+    rb = torch.randn(nb, cout, generator=g).to(dev).contiguous() if e.get("rowbias") else None
+    n_img, hi = ops._factor_rows(M) if not (rb is not None or e.get("a2_half")) else (nb, M // nb)
+    kw = dict(a2=x2, n_img=n_img, t_len=1, hi=hi, wi=1, residual=res, out_scale=e.get("scale", 1.0), out_f32=e.get("out_f32", False),
+              rowbias=rb, rows_per_batch=M // nb if rb is not None else 0, gn_groups=e.get("gn"))
+    y_gen = ops.conv_gemm(x1, cw, no_shortk=True, **kw)
+    y_sk = ops.conv_gemm(x1, cw, **kw)
+    assert torch.equal(y_gen, y_sk), (name, (y_gen.float() - y_sk.float()).abs().max().item())
+    if e.get("gn"):
+        g0, g1 = getattr(y_gen, "_uav_gn", None), getattr(y_sk, "_uav_gn", None)
+        assert g0 is not None and g1 is not None and torch.equal(g0.ws, g1.ws)
+    # fp32 reference on a row sample (incl. the last rows)
+    idx = torch.cat([torch.arange(0, M, 97, device=dev), torch.arange(max(0, M - 300), M, device=dev)])
+    xs = x1[idx].float()
+    if c2:
+        i2 = idx % x2.shape[0] if e.get("a2_half") else idx
+        xs = torch.cat([xs, x2[i2].float()], dim=1)
+    ref = xs @ wt.t()
+    if bias is not None:
+        ref = ref + bias
+    if geglu:
+        hid, gate = ref.chunk(2, dim=-1)
+        ref = hid * F.gelu(gate)
+    if rb is not None:
+        ref = ref + rb[(idx // (M // nb))]
+    if res is not None:
+        ref = ref + res[idx].float()
+    ref = ref * e.get("scale", 1.0)
+    err = rel_l2(y_sk[idx], ref)
+    assert err < (1e-4 if e.get("out_f32") else 2e-3), (name, err)

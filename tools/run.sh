@@ -1,0 +1,66 @@
+#!/bin/bash
+# One parameterised script for every GPU call of a round (VERDICT r4 hygiene #9: replaces tools/r4/r4_run*.sh).
+#   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/run.sh TAG step [step ...]'
+# TAG names the output files under gpurun_out/ (copy what is kept to profiles/rNN_*).  Steps (run in the order given):
+#   ktests          conv / linear kernel tests (tests/test_kernels_gpu.py -k "conv or linear or shortk")
+#   tests           the whole GPU suite + __graft_entry__.smoke()
+#   shortk          tools/bench_shortk.py, asm-scheduled k-step;   shortk2: the compiler-scheduled one (UAV_CONV_SK=2)
+#   epi             tools/bench_epilogue.py
+#   calib           tools/calib_gemm.py (plain GEMM vs conv 1x1 vs conv 3x3);   calib_pmc: its SQ / GRBM counter passes
+#   bench           python bench.py (default line);   bench_sk0: the same with UAV_CONV_SK=0 (same-box A/B)
+#   bench1          python bench.py --steps 1 --no-cpu-baseline (quick line with the kernel breakdown)
+#   prof            rocprofv3 --kernel-trace --stats over bench.py --steps 2
+#   traffic         tools/pmc_traffic.sh (conv HBM bytes per launch, own --pmc passes)
+#   digest          tools/conv_digest.py
+# Environment: any UAV_* variable is passed through to every step.
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+TAG=$1; shift
+O=$R/gpurun_out; mkdir -p $O
+cd /tmp; export TMPDIR=/tmp
+log() { echo "== $(date +%H:%M:%S) $*" | tee -a $O/${TAG}_steps.log; }
+for step in "$@"; do
+  log "$step"
+  case $step in
+    ktests)   timeout 600 python -m pytest $R/tests/test_kernels_gpu.py -m gpu -x -q -n 2 -k "conv or linear or shortk" 2>&1 | tail -5 | tee $O/${TAG}_ktests.log ;;
+    tests)    timeout 1500 python -m pytest $R/tests -m gpu -x -q 2>&1 | tail -15 | tee $O/${TAG}_tests.log
+              (cd $R && timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee -a $O/${TAG}_tests.log) ;;
+    shortk)   timeout 400 python $R/tools/bench_shortk.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_shortk.log ;;
+    shortk2)  UAV_CONV_SK=2 timeout 400 python $R/tools/bench_shortk.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_shortk_compiler_kstep.log ;;
+    epi)      timeout 400 python $R/tools/bench_epilogue.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_epilogue.log ;;
+    calib)    timeout 300 python $R/tools/calib_gemm.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_calib.jsonl ;;
+    calib_pmc)
+      L=$O/${TAG}_calib_pmc.jsonl; : > $L
+      for arm in blas conv1x1 conv3x3; do
+        case $arm in blas) pat="%Cijk%";; *) pat="%conv_gemm256i%";; esac
+        rm -rf /tmp/pmc_c
+        UAV_CALIB_ITERS=2 timeout 240 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU \
+          -d /tmp/pmc_c -o sq -- python $R/tools/calib_gemm.py $arm > /dev/null 2>&1
+        db="$(find /tmp/pmc_c -name '*.db' | head -1)"
+        python $R/tools/pmc_reduce.py "$db" "${arm}_sq" "$pat" >> $L
+        python - "$db" >> $L <<'PY'
+import json, sqlite3, sys
+cur = sqlite3.connect(sys.argv[1]).cursor()
+try:
+    rows = list(cur.execute("select name, count(*), avg(duration) from kernels group by name order by sum(duration) desc limit 4"))
+    print(json.dumps({"top_kernels": [[r[0][:90], r[1], r[2]] for r in rows]}))
+except Exception as e:
+    print(json.dumps({"top_kernels_error": str(e)}))
+PY
+        rm -rf /tmp/pmc_c
+        UAV_CALIB_ITERS=2 timeout 240 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d /tmp/pmc_c -o g -- python $R/tools/calib_gemm.py $arm > /dev/null 2>&1
+        python $R/tools/pmc_reduce.py "$(find /tmp/pmc_c -name '*.db' | head -1)" "${arm}_clock" "$pat" >> $L
+      done
+      cat $L ;;
+    bench)    (cd $R && timeout 900 python bench.py 2> $O/${TAG}_bench.err | tee $O/${TAG}_bench.json) ;;
+    bench_sk0) (cd $R && UAV_CONV_SK=0 timeout 900 python bench.py --no-cpu-baseline 2> /dev/null | tee $O/${TAG}_bench_sk0.json) ;;
+    bench1)   (cd $R && timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2> $O/${TAG}_bench1.err | tee $O/${TAG}_bench1.json) ;;
+    bench1_sk0) (cd $R && UAV_CONV_SK=0 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2> /dev/null | tee $O/${TAG}_bench1_sk0.json) ;;
+    shape)    (cd $R && UAV_BENCH_DETAIL=1 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> $O/${TAG}_per_shape.txt > $O/${TAG}_bench_detail.json; grep -v amdgpu.ids $O/${TAG}_per_shape.txt | head -70) ;;
+    prof)     rm -rf /tmp/prof; (cd $R && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof -o b -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> /dev/null)
+              f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_rocprofv3_kernel_stats.csv && head -25 "$f" ;;
+    traffic)  (cd $R && bash tools/pmc_traffic.sh 2>&1 | tail -5); cp $O/pmc_conv_traffic.json $O/${TAG}_pmc_conv_traffic.json 2> /dev/null ;;
+    digest)   timeout 200 python $R/tools/conv_digest.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_digest.log ;;
+    *)        echo "unknown step $step" ;;
+  esac
+done
+log done

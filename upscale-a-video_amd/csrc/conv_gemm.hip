@@ -1531,16 +1531,188 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
                                         ldsepi + 1024 + (LNF == 2 ? 0 : wm * 1024) + wn * 512);
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Short-K kernel (round 5): 1x1 convs / nn.Linear with K = C_in <= a few k-steps (the q / out / proj_in / proj_out
+// projections of attention.py:523-564, the 1x1 shortcuts of resnet.py:286-292).  In the 256x256x64 tile these launches
+// spend as long in their prologue (two cold DMA stages) and epilogue (fp32 residual in, fp32 rows out: HBM-bound) as in the
+// 8 k-steps between them, and with one 128-KiB workgroup per CU nothing runs beside either: 0.15-0.23 of the MFMA peak,
+// 60-65 % of the HBM rate the epilogue alone could reach.  Here
+//   * the tile is 128(m) x 256(n) per 256-thread workgroup (4 waves as 2 x 2, the SAME 64(m) x 128(n) wave tile, MFMA
+//     32x32x16 order and epilogues as conv_gemm256i_kernel), 75 KiB of LDS and <= 256 VGPRs: TWO workgroups per CU, one wave
+//     of each on every SIMD, so one workgroup's epilogue / prologue (memory) runs under the other's k-loop (matrix pipe);
+//   * K is walked in 32-column stages through a THREE-stage LDS ring (24 KiB each): two stages are in flight while the
+//     third is multiplied, one raw s_barrier per stage and a counted vmcnt (never 0 inside the loop);
+//   * LDS rows are 64 B: physical 16-B slot s of row r holds logical slot s ^ ((r >> 2) & 3), applied on the DMA source
+//     address and on the fragment reads (conflict-free for the four 16-lane groups of ds_read_b128);
+//   * no gather arithmetic: row m of the tile IS pixel m (1x1, stride 1); bias and the time-embedding rows of the tile reach
+//     LDS as DMA pieces of their own.
+// Per-accumulator K order is the same as in the other kernels (ascending k, one MFMA per 16 columns), so results are
+// bit-identical to conv_gemm256i_kernel on the launches both accept (tests/test_kernels_gpu.py).
+constexpr int SK_BK = 32;
+template <int WM, int WN> struct SkGeom {
+    static constexpr int TM = 64 * WM, TN = 128 * WN;
+    static constexpr int XB = TM * SK_BK * 2, WB = TN * SK_BK * 2, STAGE = XB + WB, NST = 3;
+    static constexpr int EPI = (1 + WM) * TN * 4;                  // bias + one time-embedding row per 64-row block
+    static constexpr int LDS = NST * STAGE + EPI;
+    static constexpr int XP = TM / 64, WP = TN / 64;               // 1-KiB DMA pieces (16 rows x 64 B) per wave and stage
+    static_assert(WM * WN == 4 && TN % 256 == 0, "4 waves; bias / row pieces are 256 floats");
+};
+
+// V = 0: compiler-scheduled k-step (four read -> lgkmcnt(0) -> 4-MFMA groups per stage); V = 1: the 12 fragment reads and 16
+// MFMAs of a stage as ONE asm statement with exact lgkmcnt counts (LDS returns in order): the reads of the second 16-column
+// slice fly behind the MFMAs of the first.  Same per-accumulator K order: bit-identical.
+template <int WM, int WN, int GNK, int V = 0>
+__global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(ConvArgs p) {
+    using G = SkGeom<WM, WN>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi32 = lane >> 5, l32 = lane & 31;
+    const unsigned n_tiles = p.n_pad / G::TN;
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    const unsigned mt = tile / n_tiles, nt = tile - mt * n_tiles;
+    const long long m0 = (long long)mt * G::TM;
+    const int n0 = nt * G::TN;
+
+    // DMA role of a lane inside a piece: row lane >> 2, physical slot lane & 3 <- logical slot (lane & 3) ^ ((row >> 2) & 3)
+    const int prow = lane >> 2;
+    const int slot_log = (lane & 3) ^ ((lane >> 4) & 3);
+    int xpix[G::XP];                                     // pixel of this lane's row in X piece wave + 4 j (-1: past M)
+#pragma unroll
+    for (int j = 0; j < G::XP; ++j) {
+        const long long m = m0 + (wave + 4 * j) * 16 + prow;
+        xpix[j] = m < p.M ? (int)m : -1;
+    }
+    const char* wlane = p.w + (((long long)(n0 + wave * 16 + prow)) * p.k_pad + slot_log * 8) * 2;   // W piece wave + 4 j: + j * wstep
+    const long long wstep = 64ll * p.k_pad * 2;
+    const int nk = p.k_pad / SK_BK;
+
+    auto issue = [&](int buf, int ks) {
+        char* sb = smem + buf * G::STAGE;
+        const int kc = ks * SK_BK;
+        const bool first = kc < p.c1;
+        const char* src = first ? p.a1 : p.a2;
+        const int cs = first ? p.c1 : p.c2;
+        const int coff = (first ? kc : kc - p.c1) + slot_log * 8;
+#pragma unroll
+        for (int j = 0; j < G::XP; ++j) {
+            const int px = xpix[j];
+            const int pxs = first ? px : a2_wrap(p, px);
+            const char* g = px >= 0 ? src + ((long long)pxs * cs + coff) * 2 : p.zero_page;
+            dma16(g, sb + (wave + 4 * j) * 1024);
+        }
+#pragma unroll
+        for (int j = 0; j < G::WP; ++j) dma16(wlane + j * wstep + (long long)kc * 2, sb + G::XB + (wave + 4 * j) * 1024);
+    };
+
+    // epilogue constants as DMA pieces of their own (older than every stage piece on the wave's vmcnt): bias[n0 .. n0 + TN),
+    // then per 64-row block of the tile the time-embedding row of that block's batch entry
+    char* sepi = smem + G::NST * G::STAGE;
+    if (wave < G::TN / 256 && p.bias) dma16((const char*)(p.bias + n0 + wave * 256 + lane * 4), sepi + wave * 1024);
+    if (p.rowbias) {
+#pragma unroll
+        for (int q = wave; q < WM * (G::TN / 256); q += 4) {
+            const int blk = q / (G::TN / 256), part = q - blk * (G::TN / 256);
+            long long mrow = m0 + blk * 64; if (mrow >= p.M) mrow = 0;
+            const float* r = p.rowbias + (long long)((int)(mrow / p.rows_per_batch)) * p.rowbias_stride + n0 + part * 256 + lane * 4;
+            dma16((const char*)r, sepi + (1 + blk) * G::TN * 4 + part * 1024);
+        }
+    }
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+
+    const int wn = wave % WN, wm = wave / WN;
+    float16_t acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int sw = (l32 >> 2) & 3;
+    const int offW = G::XB + (wn * 128 + l32) * 64, offX = (wm * 64 + l32) * 64;
+    const int so0 = ((0 + hi32) ^ sw) << 4, so1 = ((2 + hi32) ^ sw) << 4;
+
+    const unsigned ldsb = (unsigned)(size_t)(lptr_t)smem;
+    int cur = 0, nxt = 2;                                // buffer of stage ks / of stage ks + 2
+    for (int ks = 0; ks < nk; ++ks) {
+        // stage ks has landed once at most the pieces of stage ks + 1 are still outstanding
+        if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G::XP + G::WP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                    // RAW: every wave's pieces of stage ks; WAR: all reads of stage ks - 1 are done
+        asm volatile("" ::: "memory");
+        if (ks + 2 < nk) issue(nxt, ks + 2);
+        if constexpr (V == 1) {
+            const unsigned sbs = ldsb + cur * G::STAGE;
+            const unsigned aw0 = sbs + offW + so0, aw1 = sbs + offW + so1, ax0 = sbs + offX + so0, ax1 = sbs + offX + so1;
+            half8_t w00, w01, w02, w03, x00, x01, w10, w11, w12, w13, x10, x11;
+#define RD(D, A, OFF) "ds_read_b128 %[" #D "], %[" #A "] offset:" #OFF "\n"
+#define RDSET(S, A, AX) RD(w##S##0, A, 0) RD(x##S##0, AX, 0) RD(x##S##1, AX, 2048) RD(w##S##1, A, 2048) RD(w##S##2, A, 4096) RD(w##S##3, A, 6144)
+#define MF(C, A, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #A "], %[" #B "], %[" #C "]\n"
+#define WT(N) "s_waitcnt lgkmcnt(" #N ")\n"
+#define MFSET(S, N0, N1, N2, N3, N4)                                                           \
+    WT(N0) MF(c00, w##S##0, x##S##0) WT(N1) MF(c01, w##S##0, x##S##1)                          \
+    WT(N2) MF(c10, w##S##1, x##S##0) MF(c11, w##S##1, x##S##1)                                 \
+    WT(N3) MF(c20, w##S##2, x##S##0) MF(c21, w##S##2, x##S##1)                                 \
+    WT(N4) MF(c30, w##S##3, x##S##0) MF(c31, w##S##3, x##S##1)
+            asm volatile(
+                "s_waitcnt lgkmcnt(0)\n"          // nothing of the compiler's (SMEM) may be counted below
+                RDSET(0, aw0, ax0) RDSET(1, aw1, ax1)
+                MFSET(0, 10, 9, 8, 7, 6)
+                MFSET(1, 4, 3, 2, 1, 0)
+                : [c00] "+v"(acc[0][0]), [c01] "+v"(acc[0][1]), [c10] "+v"(acc[1][0]), [c11] "+v"(acc[1][1]),
+                  [c20] "+v"(acc[2][0]), [c21] "+v"(acc[2][1]), [c30] "+v"(acc[3][0]), [c31] "+v"(acc[3][1]),
+                  [w00] "=&v"(w00), [w01] "=&v"(w01), [w02] "=&v"(w02), [w03] "=&v"(w03), [x00] "=&v"(x00), [x01] "=&v"(x01),
+                  [w10] "=&v"(w10), [w11] "=&v"(w11), [w12] "=&v"(w12), [w13] "=&v"(w13), [x10] "=&v"(x10), [x11] "=&v"(x11)
+                : [aw0] "v"(aw0), [aw1] "v"(aw1), [ax0] "v"(ax0), [ax1] "v"(ax1)
+                : "memory");
+#undef RD
+#undef RDSET
+#undef MF
+#undef WT
+#undef MFSET
+        } else {
+        const char* st = smem + cur * G::STAGE;
+        half8_t fw[2][4], fx[2][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fw[0][i] = *(const half8_t*)(st + offW + i * 2048 + so0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fx[0][j] = *(const half8_t*)(st + offX + j * 2048 + so0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fw[1][i] = *(const half8_t*)(st + offW + i * 2048 + so1);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fx[1][j] = *(const half8_t*)(st + offX + j * 2048 + so1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fw[kk][i], fx[kk][j], acc[i][j], 0, 0, 0);
+        }
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt = nxt == 2 ? 0 : nxt + 1;
+    }
+    // V = 1: the MFMAs issued last may still be in flight and the compiler cannot see them (see conv_gemm256_kernel)
+    if constexpr (V == 1) asm volatile("s_nop 15\ns_nop 15" ::: "memory");
+    const unsigned ldsepi = (unsigned)(size_t)(lptr_t)sepi;
+    conv_epilogue<4, 2, GNK, true, 0>(p, acc, m0 + wm * 64, n0 + wn * 128, l32, hi32, ldsepi + wn * 512,
+                                      ldsepi + (1 + wm) * G::TN * 4 + wn * 512);
+}
+
 }  // namespace
 
 namespace {
-struct ConvEnv { int korder, tile_order, force_tile, dbg, persist, dmav; };
+struct ConvEnv { int korder, tile_order, force_tile, dbg, persist, dmav, sk, sk_maxk; };
 const ConvEnv& conv_env() {
     // Environment switches (development A/B only) are read once through a thread-safe magic static.
     static const ConvEnv env = [] {
         auto geti = [](const char* k, int d) { const char* e = getenv(k); return e ? atoi(e) : d; };
         return ConvEnv{geti("UAV_CONV_KORDER", 1), geti("UAV_CONV_TILE_ORDER", 1), geti("UAV_CONV_TILE", 0),
-                       geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0), geti("UAV_CONV_DMAV", 6)};      // 6: rotated k-step (round 4 default); 1: round 2-3 loop
+                       geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0), geti("UAV_CONV_DMAV", 6),       // 6: rotated k-step (round 4 default); 1: round 2-3 loop
+                       geti("UAV_CONV_SK", 1), geti("UAV_CONV_SK_MAXK", 1024)};                               // short-K kernel (round 5) for 1x1 launches with K <= SK_MAXK
     }();
     return env;
 }
@@ -1552,6 +1724,16 @@ bool conv_uses_big_tile(const uav_conv_params* q) {
     const int force_tile = conv_env().force_tile;
     return !small && (q->n_pad % LN == 0) && (force_tile >= 256 || (force_tile != 128 && grid256 >= 224));
 }
+// Short-K kernel: 1x1 / stride 1 launches of the big-tile class with K <= UAV_CONV_SK_MAXK and whole 256-column tiles.
+bool conv_uses_sk(const uav_conv_params* q) {
+    const ConvEnv& env = conv_env();
+    if (!env.sk || env.dbg || env.persist || !env.korder || (q->flags & (UAV_CONV_PERSISTENT | UAV_CONV_NO_SHORTK))) return false;
+    if (q->kt != 1 || q->kh != 1 || q->kw != 1 || q->stride != 1 || q->upsample || q->pad_t || q->pad_h || q->pad_w) return false;
+    if (q->ho != q->hi || q->wo != q->wi || q->out_map_w || q->a2_center_tap) return false;
+    if (q->ln_raw_out || q->ln_stat_in) return false;
+    if (q->n != q->n_pad || (q->n_pad % 256) || q->k_pad != q->c1 + q->c2 || q->k_pad > env.sk_maxk) return false;
+    return conv_uses_big_tile(q);
+}
 // Fused GroupNorm statistics are produced by the fast epilogues of the 256x256 kernel only: every wave tile (64 rows x
 // 128 channels) must lie inside M x N and qualify for a fast path, and a group must not straddle wave tiles.
 int conv_gn_cpg_log2(const uav_conv_params* q) {
@@ -1562,7 +1744,7 @@ int conv_gn_cpg_log2(const uav_conv_params* q) {
     for (int k = 2; k <= 7; ++k) if (cpg == (1 << k)) cl = k;
     if (cl < 0) return -1;
     const long long M = (long long)q->n_img * q->ho * q->wo;
-    if (!conv_uses_big_tile(q) || (M % 64) || (q->n % 128)) return -1;
+    if (!conv_uses_big_tile(q) || (M % 64) || (q->n % 128)) return -1;        // (the short-K kernel has the same 64 x 128 wave tiles)
     if (q->flags & (UAV_CONV_GEGLU | UAV_CONV_GELU | UAV_CONV_QUICK_GELU)) return -1;
     const bool of32 = q->flags & UAV_CONV_OUT_F32, rf32 = q->flags & UAV_CONV_RES_F32;
     if (of32) {
@@ -1700,7 +1882,31 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     const long long mtiles256 = (a.M + LM - 1) / LM;
     const long long grid256 = mtiles256 * (q->n_pad / LN);
     const bool big = conv_uses_big_tile(q);
-    if (big) {
+    if (big && conv_uses_sk(q)) {
+        using G = SkGeom<2, 2>;
+        constexpr int MAXDEV = 64;
+        static std::once_flag sk_once[MAXDEV];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return UAV_EINVAL;
+        std::call_once(sk_once[dev], [] {
+            const void* fns[] = {(const void*)conv_gemm_sk_kernel<2, 2, 0, 0>, (const void*)conv_gemm_sk_kernel<2, 2, 1, 0>,
+                                 (const void*)conv_gemm_sk_kernel<2, 2, 2, 0>, (const void*)conv_gemm_sk_kernel<2, 2, 3, 0>,
+                                 (const void*)conv_gemm_sk_kernel<2, 2, 0, 1>, (const void*)conv_gemm_sk_kernel<2, 2, 1, 1>,
+                                 (const void*)conv_gemm_sk_kernel<2, 2, 2, 1>, (const void*)conv_gemm_sk_kernel<2, 2, 3, 1>};
+            for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        });
+        const long long gsk = ((a.M + G::TM - 1) / G::TM) * (q->n_pad / G::TN);
+        if (gsk >= (1ll << 31)) return UAV_ESHAPE;
+        a.ntiles = (unsigned)gsk;
+        const int gnm = a.gn_ws ? gn_mode_of(a.gn_cpg_log2) : 0;
+#define SK_LAUNCH(GN, VV) hipLaunchKernelGGL((conv_gemm_sk_kernel<2, 2, GN, VV>), dim3((unsigned)gsk), dim3(256), G::LDS, s, a)
+        if (env.sk == 2) {                         // UAV_CONV_SK=2: compiler-scheduled k-step (A/B)
+            if (gnm == 0) SK_LAUNCH(0, 0); else if (gnm == 1) SK_LAUNCH(1, 0); else if (gnm == 2) SK_LAUNCH(2, 0); else SK_LAUNCH(3, 0);
+        } else {
+            if (gnm == 0) SK_LAUNCH(0, 1); else if (gnm == 1) SK_LAUNCH(1, 1); else if (gnm == 2) SK_LAUNCH(2, 1); else SK_LAUNCH(3, 1);
+        }
+#undef SK_LAUNCH
+    } else if (big) {
         constexpr int MAXDEV = 64;
         static std::once_flag dev_once[MAXDEV];
         static long long dev_ncu[MAXDEV];
