@@ -2,10 +2,15 @@
 random weights: a small quick-GELU model (OpenAI-CLIP style) and the ViT-H/14 text tower the released pipeline ships
 (24 layers, width 1024, 16 heads, GELU, 77 tokens).  Tolerance: activations / weights are fp16 with fp32 accumulation,
 the reference CLI runs this model in fp16 as well (from_pretrained(torch_dtype=float16)) -> rel-L2 <= 3e-3 vs fp32."""
+import json
+import os
+
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLIP_BAR = 3e-3          # -> measured + 25 % once profiles/r05_parity_* holds the value (VERDICT r4 weak #10)
 
 
 def rel_l2(a, b):
@@ -34,7 +39,11 @@ def test_clip_text_encoder_vs_transformers(dev, name, kw):
     out = m(ids.to(dev))
     assert out[0].shape == ref.shape and out[0].dtype == torch.float16 and out.last_hidden_state is out[0]
     e = rel_l2(out[0], ref)
-    assert e < 3e-3, f"{name}: rel-L2 {e}"
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "parity.jsonl"), "a") as fh:
+            fh.write(json.dumps(dict(case="clip_text_" + name, rel_l2_vs_transformers_fp32=e)) + "\n")
+    assert e < CLIP_BAR, f"{name}: rel-L2 {e}"
     # causality: changing a later token must not change earlier positions
     ids2 = ids.clone(); ids2[:, 50:] = 5
     out2 = m(ids2.to(dev))[0]

@@ -28,6 +28,7 @@ for step in "$@"; do
     shortk2)  UAV_CONV_SK=2 timeout 400 python $R/tools/bench_shortk.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_shortk_compiler_kstep.log ;;
     epi)      timeout 400 python $R/tools/bench_epilogue.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_epilogue.log ;;
     calib)    timeout 300 python $R/tools/calib_gemm.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_calib.jsonl ;;
+    blas)     timeout 300 python $R/tools/calib_blas_shapes.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_calib_blas_shapes.jsonl ;;
     calib_pmc)
       L=$O/${TAG}_calib_pmc.jsonl; : > $L
       for arm in blas conv1x1 conv3x3; do
