@@ -63,6 +63,10 @@ int  uav_device_check(int dev, char* name_out);
  * tile, two workgroups per CU, attention.py:523-564 / resnet.py:286-292) — same results bit for bit.  This flag keeps such a
  * launch in the general 256x256 kernel (A/B measurements and the bit-identity test). */
 #define UAV_CONV_NO_SHORTK 1024u
+/* Round 5: launches of the 256x256-tile class run in the four-wave kernel (conv_gemm256w_kernel: one wave per SIMD, 128 x 128 wave
+ * tiles, accumulators in the accumulator file) — same results bit for bit as the 8-wave kernel.  This flag keeps a launch in the
+ * 8-wave kernel (A/B measurements and the bit-identity tests). */
+#define UAV_CONV_NO_W4 2048u
 
 typedef struct {
     const void*  a1;            /* fp16 source 1, rows of c1 channels */

@@ -775,8 +775,8 @@ def test_shortk_kernel_bit_identical_to_general_kernel(ops, dev, case):
     n_img, hi = ops._factor_rows(M) if not (rb is not None or e.get("a2_half")) else (nb, M // nb)
     kw = dict(a2=x2, n_img=n_img, t_len=1, hi=hi, wi=1, residual=res, out_scale=e.get("scale", 1.0), out_f32=e.get("out_f32", False),
               rowbias=rb, rows_per_batch=M // nb if rb is not None else 0, gn_groups=e.get("gn"))
-    y_gen = ops.conv_gemm(x1, cw, no_shortk=True, **kw)
-    y_sk = ops.conv_gemm(x1, cw, **kw)
+    y_gen = ops.conv_gemm(x1, cw, no_shortk=True, no_w4=True, **kw)      # the 8-wave 256x256 kernel
+    y_sk = ops.conv_gemm(x1, cw, **kw)                                   # default dispatch: four-wave kernel (UAV_CONV_SK=1: short-K kernel)
     assert torch.equal(y_gen, y_sk), (name, (y_gen.float() - y_sk.float()).abs().max().item())
     if e.get("gn"):
         g0, g1 = getattr(y_gen, "_uav_gn", None), getattr(y_sk, "_uav_gn", None)
@@ -800,3 +800,67 @@ def test_shortk_kernel_bit_identical_to_general_kernel(ops, dev, case):
     ref = ref * e.get("scale", 1.0)
     err = rel_l2(y_sk[idx], ref)
     assert err < (1e-4 if e.get("out_f32") else 2e-3), (name, err)
+
+
+# ------------------------------------------------------------------------------------------------
+# Four-wave kernel (round 5, conv_gemm256w_kernel: one wave per SIMD, 128 x 128 wave tiles, buffer-load gather with the
+# hardware's out-of-range zero fill for padding) against the 8-wave kernel (UAV_CONV_NO_W4) — resnet.py:200-294, 94-196
+W4_CASES = [
+    # name, c1, c2, cout, (kt,kh,kw), stride, n_img, t_len, h, w, epilogue
+    ("3x3_256_res32_gn", 256, 0, 256, (1, 3, 3), 1, 4, 2, 120, 128, dict(res="f32", out_f32=True, gn=32)),
+    ("3x3_128_512_rowbias_gn", 128, 0, 512, (1, 3, 3), 1, 4, 2, 96, 80, dict(rowbias=True, gn=32)),
+    ("3x3_cat_ragged", 128, 64, 256, (1, 3, 3), 1, 6, 3, 97, 101, dict(res="f16")),
+    ("3x3_stride2", 128, 0, 512, (1, 3, 3), 2, 4, 2, 179, 181, dict(out_f32=True)),
+    ("t3_256", 256, 0, 256, (3, 1, 1), 1, 16, 8, 64, 64, dict(res="f16", gn=32)),
+    ("t5_128_ragged", 128, 0, 256, (5, 1, 1), 1, 12, 4, 70, 71, dict()),
+    ("3x3x3_64_chunk3", 64, 0, 256, (3, 3, 3), 1, 6, 3, 112, 96, dict(res="f32", out_f32=True)),
+    ("2x2_phase_like", 128, 0, 256, (1, 2, 2), 1, 4, 2, 128, 120, dict(pad=(0, 1, 1), out_hw=(128, 120))),
+    ("1x1_k4608", 4608, 0, 512, (1, 1, 1), 1, 1, 1, 30000, 1, dict()),
+    ("1x1_512_res32", 512, 0, 512, (1, 1, 1), 1, 1, 1, 51200, 1, dict(res="f32", out_f32=True, gn=32)),
+    ("1x1_bcast_a2", 256, 256, 512, (1, 1, 1), 1, 2, 1, 16000, 1, dict(a2_half=True, res="f16")),
+    ("3x3_bcast_a2", 128, 128, 256, (1, 3, 3), 1, 4, 2, 128, 128, dict(a2_half=True)),
+    ("geglu_512_4096", 512, 0, 4096, (1, 1, 1), 1, 1, 1, 25600, 1, dict(geglu=True)),
+]
+
+
+@pytest.mark.parametrize("case", W4_CASES, ids=[c[0] for c in W4_CASES])
+def test_w4_kernel_bit_identical_to_8wave_kernel(ops, dev, case):
+    """Same LDS image, MFMA order and epilogues -> the four-wave kernel must reproduce the 8-wave kernel BIT FOR BIT (outputs
+    and fused GroupNorm partials) on every tap set, stride, source split and tile tail; the 8-wave kernel itself is held to the
+    fp32 F.conv3d reference by the tests above."""
+    name, c1, c2, cout, k3, stride, n_img, t_len, h, w, e = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    cin = c1 + c2
+    geglu = e.get("geglu", False)
+    n_out = cout // 2 if geglu else cout
+    rows = n_img * h * w
+    x1 = torch.randn(rows, c1, generator=g).half().to(dev)
+    x2 = None
+    if c2:
+        x2 = torch.randn(rows // 2 if e.get("a2_half") else rows, c2, generator=g).half().to(dev)
+    wt = h16(cout, cin, *k3, dev=dev, scale=(cin * k3[0] * k3[1] * k3[2]) ** -0.5, gen=g)
+    cw = ops.pack_conv(wt, torch.randn(cout, generator=g).to(dev), geglu=geglu, device=dev)
+    pad = e.get("pad", (k3[0] // 2, k3[1] // 2, k3[2] // 2))
+    if e.get("out_hw"):
+        ho, wo = e["out_hw"]
+    else:
+        ho = (h + 2 * pad[1] - k3[1]) // stride + 1
+        wo = (w + 2 * pad[2] - k3[2]) // stride + 1
+    M = n_img * ho * wo
+    res = None
+    if e.get("res"):
+        res = torch.randn(M, n_out, generator=g).to(dev)
+        res = res if e["res"] == "f32" else res.half()
+    nb = n_img // t_len
+    rb = torch.randn(nb, cout, generator=g).to(dev).contiguous() if e.get("rowbias") else None
+    kw = dict(a2=x2, n_img=n_img, t_len=t_len, hi=h, wi=w, stride=stride, pad=pad, out_hw=e.get("out_hw"), residual=res,
+              out_f32=e.get("out_f32", False), rowbias=rb, rows_per_batch=M // nb if rb is not None else 0, gn_groups=e.get("gn"),
+              out_scale=1.0 / 1.3)
+    y8 = ops.conv_gemm(x1, cw, no_w4=True, no_shortk=True, **kw)
+    y4 = ops.conv_gemm(x1, cw, **kw)
+    assert y8.shape == (M, n_out)
+    diff = (y8.float() - y4.float()).abs()
+    assert torch.equal(y8, y4), (name, diff.max().item(), (diff > 0).float().mean().item(), (diff > 0).nonzero()[:6].tolist())
+    if e.get("gn"):
+        g0, g1 = getattr(y8, "_uav_gn", None), getattr(y4, "_uav_gn", None)
+        assert g0 is not None and g1 is not None and torch.equal(g0.ws, g1.ws)

@@ -2,7 +2,7 @@
 # One parameterised script for every GPU call of a round (VERDICT r4 hygiene #9: replaces tools/r4/r4_run*.sh).
 #   /usr/local/graft/bin/gpurun --timeout 900 -- 'bash tools/run.sh TAG step [step ...]'
 # TAG names the output files under gpurun_out/ (copy what is kept to profiles/rNN_*).  Steps (run in the order given):
-#   ktests          conv / linear kernel tests (tests/test_kernels_gpu.py -k "conv or linear or shortk")
+#   ktests          conv / linear kernel tests (tests/test_kernels_gpu.py -k "conv or linear or shortk or w4 or phase or shortcut or broadcast or groupnorm_stat")
 #   tests           the whole GPU suite + __graft_entry__.smoke()
 #   shortk          tools/bench_shortk.py, asm-scheduled k-step;   shortk2: the compiler-scheduled one (UAV_CONV_SK=2)
 #   epi             tools/bench_epilogue.py
@@ -21,12 +21,15 @@ log() { echo "== $(date +%H:%M:%S) $*" | tee -a $O/${TAG}_steps.log; }
 for step in "$@"; do
   log "$step"
   case $step in
-    ktests)   timeout 600 python -m pytest $R/tests/test_kernels_gpu.py -m gpu -x -q -n 2 -k "conv or linear or shortk" 2>&1 | tail -5 | tee $O/${TAG}_ktests.log ;;
+    ktests)   timeout 600 python -m pytest $R/tests/test_kernels_gpu.py -m gpu -x -q -n 2 -k "conv or linear or shortk or w4 or phase or shortcut or broadcast or groupnorm_stat" 2>&1 | tail -5 | tee $O/${TAG}_ktests.log ;;
     tests)    timeout 1500 python -m pytest $R/tests -m gpu -x -q 2>&1 | tail -15 | tee $O/${TAG}_tests.log
               (cd $R && timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee -a $O/${TAG}_tests.log) ;;
     shortk)   timeout 400 python $R/tools/bench_shortk.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_shortk.log ;;
     shortk2)  UAV_CONV_SK=2 timeout 400 python $R/tools/bench_shortk.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_shortk_compiler_kstep.log ;;
     epi)      timeout 400 python $R/tools/bench_epilogue.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_epilogue.log ;;
+    epi_w40)  UAV_CONV_W4=0 timeout 400 python $R/tools/bench_epilogue.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_epilogue_8wave.log ;;
+    calib_w40) UAV_CONV_W4=0 timeout 300 python $R/tools/calib_gemm.py conv1x1 conv3x3 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_calib_8wave.jsonl ;;
+    bench1_w40) (cd $R && UAV_CONV_W4=0 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2> /dev/null | tee $O/${TAG}_bench1_8wave.json) ;;
     calib)    timeout 300 python $R/tools/calib_gemm.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_calib.jsonl ;;
     blas)     timeout 300 python $R/tools/calib_blas_shapes.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_calib_blas_shapes.jsonl ;;
     calib_pmc)

@@ -55,6 +55,10 @@ struct ConvArgs {
     // rstd_m * (acc - mu_m * colsum_n) + bias'_n with the row statistics of its operand.
     char* lnp_raw; float* lnp_stat;                                    // producer outputs (nullptr: off)
     const float* lnc_stat; const float* lnc_colsum; int lnc_chunks, lnc_n; float lnc_eps;   // consumer inputs (lnc_stat nullptr: off)
+    // conv_gemm256w_kernel: byte sizes of the two sources (buffer-descriptor range = the hardware's zero fill for padding) and
+    // magic numbers of the three divisions that turn a GEMM row into (image, y, x, frame) — n / d = umulhi(n, mul) >> sh, n < 2^31
+    unsigned x1_bytes, x2_bytes;
+    unsigned dv_hw_mul, dv_hw_sh, dv_wo_mul, dv_wo_sh, dv_t_mul, dv_t_sh;
 };
 
 // Source-2 pixel of GEMM pixel px: the skip tensors of the CFG-shared UNet head exist once and serve both batch entries
@@ -1533,6 +1537,311 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
 
 
 // ---------------------------------------------------------------------------------------------
+// conv_gemm256w_kernel (round 5): the 256 x 256 x 64 tile walked by FOUR waves, one per SIMD, each owning a 128(n) x 128(m)
+// wave tile = 4 x 4 MFMA 32x32x16 tiles = 256 fp32 accumulators in the accumulator file (AGPRs), fragments, addresses and
+// the epilogue in the 256 architectural VGPRs.  Why (calibration of round 5, profiles/r05_calibration_*): on this chip
+// the vendor's plain fp16 GEMM of this geometry reaches 1.15-1.25 PFLOP/s on the operands the conv kernel sees where
+// conv_gemm256i_kernel (8 waves, two per SIMD, 64 x 128 wave tiles) reaches 0.92-1.02; its counters show the matrix pipe
+// 70 % busy at 1.64 GHz against 50-53 % at 1.8-1.9 GHz here — not the power limit: wave cycles parked at barriers /
+// waitcnts (33 % vs 8 %), 1.5x the LDS fragment bytes per MFMA, twice the barrier participants, and every DMA issue /
+// address instruction of one wave competing with the partner wave's MFMA issue.  This kernel keeps the LDS image, the
+// swapped MFMA (lane = pixel, 4 channels per register quad), the per-accumulator K order (-> BIT-IDENTICAL results) and
+// the epilogues of conv_gemm256i_kernel, and changes the schedule:
+//   * one instruction stream per SIMD: the 64 MFMAs of a k-step issue back to back, everything else — 32 ds_read_b128,
+//     16 LDS-DMA pieces, the gather's validity arithmetic, two barriers — sits in the issue slots between them (one asm
+//     statement per k-step, self-contained: nothing asynchronous is pending in a register when it ends);
+//   * 0.5 ds_read_b128 per MFMA (8 fragments feed 16 MFMAs) instead of 0.75; the whole 64-column stage lives in 128 VGPRs:
+//     slices 2-3 are read during slice 0, slices 0-1 of the NEXT stage during slice 3;
+//   * the gather is a buffer load: per lane and row a 32-bit byte offset computed ONCE per tile, the tap / channel-block
+//     step is a scalar added to the buffer base, and padding is the hardware's out-of-range rule — a precomputed per-row
+//     bit mask over the taps ORs the offset to 0xffffffff (2 VALU per piece and k-step instead of ~12, no zero page);
+//   * LDS-DMA stays in flight across both barriers (counted vmcnt, never 0 while more stages follow).
+constexpr int W4_NPRE = 10;                     // DMA pieces of a k-step issued before its second barrier (vmcnt count)
+
+struct W4Srd { unsigned w[4]; };
+UAV_DEVINL uint4_t w4_srd(const char* base, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    uint4_t r = {(unsigned)a, (unsigned)(a >> 32) & 0xffffu, bytes, 0x00020000u};
+    return r;
+}
+UAV_DEVINL unsigned udiv_magic(unsigned n, unsigned mul, unsigned sh) { return sh >= 32u ? n : (__umulhi(n, mul) >> sh); }
+
+template <int GNK>
+__global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hi32 = lane >> 5, l32 = lane & 31;
+
+    // tile id -> (m tile, n tile), frame-fastest for temporal taps (see conv_gemm256_kernel)
+    const unsigned n_tiles = p.n_pad / LN;
+    const int hw_o = p.ho * p.wo;
+    const unsigned tile = xcd_remap(blockIdx.x, gridDim.x);
+    unsigned mt = tile / n_tiles;
+    const unsigned nt = tile - mt * n_tiles;
+    if (p.kt > 1 && p.tile_order) {
+        const unsigned hw_ = (unsigned)hw_o;
+        if (hw_ % LM == 0) {
+            const unsigned S_ = hw_ / LM, per_clip_ = S_ * (unsigned)p.t_len;
+            const unsigned c_ = mt / per_clip_, r_ = mt - c_ * per_clip_;
+            const unsigned sp_ = r_ / (unsigned)p.t_len, t_ = r_ - sp_ * (unsigned)p.t_len;
+            mt = c_ * per_clip_ + t_ * S_ + sp_;
+        }
+    }
+    const long long m0 = (long long)mt * LM;
+    const int n0 = nt * LN;
+    const int cin = p.c1 + p.c2;
+
+    // ---- gather constants: byte offset of (row, slot) at tap (pad_t, pad_h, pad_w) and the mask of INVALID taps ------------
+    const int slot_log = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
+    const int rlane = wave * 8 + (lane >> 3);            // this lane's row inside every 32-row DMA piece
+    unsigned vo[8], vo2[8], im[8];
+    const int ylim = p.hi, xlim = p.wi;
+    const int khw = p.kh * p.kw;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const long long m_ = m0 + i * 32 + rlane;
+        const bool ok_ = m_ < p.M;
+        const unsigned mm_ = ok_ ? (unsigned)m_ : 0u;
+        const unsigned img_ = udiv_magic(mm_, p.dv_hw_mul, p.dv_hw_sh);
+        const unsigned rem_ = mm_ - img_ * (unsigned)hw_o;
+        const unsigned yo_ = udiv_magic(rem_, p.dv_wo_mul, p.dv_wo_sh);
+        const unsigned xo_ = rem_ - yo_ * (unsigned)p.wo;
+        const unsigned tt_ = img_ - udiv_magic(img_, p.dv_t_mul, p.dv_t_sh) * (unsigned)p.t_len;
+        const int yi_ = (int)yo_ * p.stride, xi_ = (int)xo_ * p.stride;
+        const unsigned px_ = (img_ * (unsigned)p.hi + (unsigned)yi_) * (unsigned)p.wi + (unsigned)xi_;
+        vo[i] = (px_ * (unsigned)p.c1 + (unsigned)slot_log * 8u) * 2u;
+        const unsigned px2_ = (p.a2_pix && px_ >= (unsigned)p.a2_pix) ? px_ - (unsigned)p.a2_pix : px_;
+        vo2[i] = (px2_ * (unsigned)p.c2 + (unsigned)slot_log * 8u) * 2u;
+        unsigned xbad = 0;
+        for (int dx = 0; dx < p.kw; ++dx) xbad |= ((unsigned)(xi_ - p.pad_w + dx) >= (unsigned)xlim ? 1u : 0u) << dx;
+        const unsigned full = (1u << p.kw) - 1u;
+        unsigned inv = 0;
+        for (int dt = 0; dt < p.kt; ++dt)
+            for (int dy = 0; dy < p.kh; ++dy) {
+                const bool bad = !ok_ | ((unsigned)((int)tt_ - p.pad_t + dt) >= (unsigned)p.t_len) | ((unsigned)(yi_ - p.pad_h + dy) >= (unsigned)ylim);
+                inv |= (bad ? full : xbad) << ((dt * p.kh + dy) * p.kw);
+            }
+        im[i] = inv;
+    }
+    const unsigned woff = (unsigned)(((long long)rlane * p.k_pad + slot_log * 8) * 2);
+    const unsigned wps32 = (unsigned)(32ll * p.k_pad * 2);
+    const char* wtile = p.w + (long long)n0 * p.k_pad * 2;
+
+    // temporal taps outside the clip for every row of the tile are skipped (see conv_gemm256i_kernel)
+    // (all of it scalar: 32-bit magic divisions — a 64-bit division would be expanded on the VALU and drag nk, and with it
+    // every wave-uniform operand of the k-step below, into vector registers)
+    int dt_lo = 0, dt_hi = p.kt;
+    if (p.kt > 1 && hw_o % LM == 0 && m0 < p.M) {
+        const unsigned img0 = udiv_magic((unsigned)m0, p.dv_hw_mul, p.dv_hw_sh);
+        const int t_ = (int)(img0 - udiv_magic(img0, p.dv_t_mul, p.dv_t_sh) * (unsigned)p.t_len);
+        dt_lo = p.pad_t - t_ > 0 ? p.pad_t - t_ : 0;
+        dt_hi = p.t_len + p.pad_t - t_ < p.kt ? p.t_len + p.pad_t - t_ : p.kt;
+    }
+    dt_lo = __builtin_amdgcn_readfirstlane(dt_lo); dt_hi = __builtin_amdgcn_readfirstlane(dt_hi);
+    const int tap_lo = dt_lo * khw;
+    const int ntaps = dt_hi * khw;
+    const int ctr_tap = (p.pad_t * p.kh + p.pad_h) * p.kw + p.pad_w;
+    const int nk = __builtin_amdgcn_readfirstlane(p.a2_ctr ? (p.c1 / BK) * (ntaps - tap_lo) + p.c2 / BK : (cin / BK) * (ntaps - tap_lo));
+    int kdt = dt_lo, kdy = 0, kdx = 0, ktap = tap_lo, kc = 0;    // wave-uniform: tap / channel block of the NEXT stage to address
+    bool on2 = false;                                             // the offsets in vo[] are those of source 2
+    uint4_t xsrd, wsrd;
+    unsigned tapn;
+
+    // scalar address step of the next stage: buffer bases (X: source + tap / channel-block displacement, W: + K offset)
+#define W4_NEXT()                                                                                            \
+    {                                                                                                        \
+        const bool first = kc < p.c1;                                                                        \
+        const char* xsrc = first ? p.a1 : p.a2;                                                              \
+        const int xcs = first ? p.c1 : p.c2;                                                                 \
+        const int xco = first ? kc : kc - p.c1;                                                              \
+        const long long xd = ((((long long)(kdt - p.pad_t) * p.hi + (kdy - p.pad_h)) * p.wi + (kdx - p.pad_w)) * xcs + xco) * 2; \
+        xsrd = w4_srd(xsrc + xd, first ? p.x1_bytes : p.x2_bytes);                                           \
+        wsrd = w4_srd(wtile + ((long long)ktap * cin + kc) * 2, 0x7fffffffu);                                \
+        tapn = (unsigned)ktap;                                                                               \
+        if (!first && !on2) {                                                                                \
+            on2 = true;                                                                                      \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) vo[i] = vo2[i];                                    \
+        }                                                                                                    \
+        if (p.a2_ctr && kc >= p.c1) {            /* source 2: one (centre) tap per channel block */          \
+            kc += BK;                                                                                        \
+        } else {                                 /* tap-innermost K order */                                 \
+            ++ktap;                                                                                          \
+            if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } }                           \
+            if (ktap == ntaps) {                                                                             \
+                ktap = tap_lo; kdt = dt_lo; kdy = 0; kdx = 0; kc += BK;                                      \
+                if (p.a2_ctr && kc >= p.c1) { ktap = ctr_tap; kdt = p.pad_t; kdy = p.pad_h; kdx = p.pad_w; } \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+
+    const int wn = wave & 1, wm = wave >> 1;
+    float16_t accA[4][2], accB[4][2];                    // rows [wm*128, +64) and [wm*128 + 64, +64)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accA[i][j][r] = 0.f; accB[i][j][r] = 0.f; }
+
+    const int sw = (l32 >> 1) & 7;
+    const unsigned ldsb = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned bW = ldsb + LA_BYTES + (wn * 128 + l32) * 128, bX = ldsb + (wm * 128 + l32) * 128;
+    unsigned aw0 = bW + ((((0 * 2 + hi32) ^ sw)) << 4), aw1 = bW + ((((1 * 2 + hi32) ^ sw)) << 4);
+    unsigned aw2 = bW + ((((2 * 2 + hi32) ^ sw)) << 4), aw3 = bW + ((((3 * 2 + hi32) ^ sw)) << 4);
+    unsigned ax0 = bX + ((((0 * 2 + hi32) ^ sw)) << 4), ax1 = bX + ((((1 * 2 + hi32) ^ sw)) << 4);
+    unsigned ax2 = bX + ((((2 * 2 + hi32) ^ sw)) << 4), ax3 = bX + ((((3 * 2 + hi32) ^ sw)) << 4);
+    const unsigned ldsw = ldsb + wave * 1024;            // this wave's 1-KiB slice inside every 4-KiB group of rows
+
+    // epilogue constants as DMA pieces of their own (older than every stage piece on vmcnt): bias[n0 .. n0 + 256), then per
+    // 64-row block of the tile the time-embedding row of that block's batch entry
+    char* sepi = smem + 2 * LSTAGE;
+    if (wave == 0 && p.bias) dma16((const char*)(p.bias + n0 + lane * 4), sepi);
+    if (p.rowbias) {
+        long long mrow = m0 + wave * 64; if (mrow >= p.M) mrow = 0;
+        const int col = n0 + lane * 4;
+        const float* r = p.rowbias + (long long)((int)(mrow / p.rows_per_batch)) * p.rowbias_stride + (col + 4 <= p.n ? col : 0);
+        dma16((const char*)r, sepi + 1024 + wave * 1024);
+    }
+
+#define RD(D, A, OFF) "ds_read_b128 %[" #D "], %[" #A "] offset:" #OFF "\n"
+#define MF(C, A, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #A "], %[" #B "], %[" #C "]\n"
+    // X piece I (rows I*32 ..): validity -> effective offset, M0 = LDS destination, buffer load to LDS
+#define PX(I, OFF)                                                                                           \
+    "s_cbranch_vccz .Lnx%=_" #I "\n"                                                                         \
+    "v_bfe_i32 %[t" #I "], %[im" #I "], %[tapn], 1\n"                                                        \
+    "s_add_u32 m0, %[ldsn], " #OFF "\n"                                                                      \
+    "v_or_b32 %[t" #I "], %[t" #I "], %[vo" #I "]\n"                                                         \
+    "buffer_load_dwordx4 %[t" #I "], %[xsrd], 0 offen lds\n"                                                 \
+    ".Lnx%=_" #I ":\n"
+#define PW0(OFF)                                                                                             \
+    "s_cbranch_vccz .Lnw%=_0\n" "s_add_u32 m0, %[ldsn], " #OFF "\n" "s_nop 0\n"                              \
+    "buffer_load_dwordx4 %[woff], %[wsrd], 0 offen lds\n" ".Lnw%=_0:\n"
+#define PW(I, OFF)                                                                                           \
+    "s_cbranch_vccz .Lnw%=_" #I "\n" "s_add_u32 m0, %[ldsn], " #OFF "\n" "s_nop 0\n"                         \
+    "buffer_load_dwordx4 %[woff], %[wsrd], %[ws" #I "] offen lds\n" ".Lnw%=_" #I ":\n"
+#define W4_DMA_IN                                                                                            \
+    [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [vo4] "v"(vo[4]), [vo5] "v"(vo[5]),            \
+    [vo6] "v"(vo[6]), [vo7] "v"(vo[7]), [im0] "v"(im[0]), [im1] "v"(im[1]), [im2] "v"(im[2]), [im3] "v"(im[3]),            \
+    [im4] "v"(im[4]), [im5] "v"(im[5]), [im6] "v"(im[6]), [im7] "v"(im[7]), [woff] "v"(woff), [xsrd] "s"(xsrd),            \
+    [wsrd] "s"(wsrd), [ws1] "s"(ws1), [ws2] "s"(ws2), [ws3] "s"(ws3), [ws4] "s"(ws4), [ws5] "s"(ws5), [ws6] "s"(ws6),      \
+    [ws7] "s"(ws7), [ldsn] "s"(ldsn), [dodma] "s"(dodma), [tapn] "s"(tapn)
+#define W4_TMP_OUT                                                                                           \
+    [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6),        \
+    [t7] "=&v"(t7), [m0s] "=&s"(m0s)
+    const unsigned ws1 = wps32, ws2 = 2 * wps32, ws3 = 3 * wps32, ws4 = 4 * wps32, ws5 = 5 * wps32, ws6 = 6 * wps32, ws7 = 7 * wps32;
+
+    // ---- prologue: stage 0 -> buffer 0, stage 1 -> buffer 1 -----------------------------------------
+    for (int st = 0; st < 2 && st < nk; ++st) {
+        W4_NEXT()
+        const unsigned ldsn = ldsw + st * LSTAGE;
+        const int dodma = 3;
+        unsigned t0, t1, t2, t3, t4, t5, t6, t7, m0s;
+        asm volatile("s_mov_b32 %[m0s], m0\n" "s_cmp_gt_i32 %[dodma], 2\n" "s_cselect_b64 vcc, -1, 0\n"
+                     PX(0, 0) PX(1, 4096) PX(2, 8192) PX(3, 12288) PX(4, 16384) PX(5, 20480) PX(6, 24576) PX(7, 28672)
+                     PW0(32768) PW(1, 36864) PW(2, 40960) PW(3, 45056) PW(4, 49152) PW(5, 53248) PW(6, 57344) PW(7, 61440)
+                     "s_mov_b32 m0, %[m0s]\n"
+                     : W4_TMP_OUT : W4_DMA_IN : "memory", "scc", "vcc");
+    }
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                        // stage 0 of every wave has landed, the epilogue constants are in LDS
+    asm volatile("" ::: "memory");
+
+    half8_t w00, w01, w02, w03, x00, x01, x02, x03, w10, w11, w12, w13, x10, x11, x12, x13;
+    half8_t w20, w21, w22, w23, x20, x21, x22, x23, w30, w31, w32, w33, x30, x31, x32, x33;
+#define RDW(S, A) RD(w##S##0, A, 0) RD(w##S##1, A, 4096) RD(w##S##2, A, 8192) RD(w##S##3, A, 12288)
+#define RDX(S, A) RD(x##S##0, A, 0) RD(x##S##1, A, 4096) RD(x##S##2, A, 8192) RD(x##S##3, A, 12288)
+    asm volatile(RDW(0, aw0) RDX(0, ax0) RDW(1, aw1) RDX(1, ax1) "s_waitcnt lgkmcnt(0)\n"
+                 : [w00] "=&v"(w00), [w01] "=&v"(w01), [w02] "=&v"(w02), [w03] "=&v"(w03), [x00] "=&v"(x00), [x01] "=&v"(x01),
+                   [x02] "=&v"(x02), [x03] "=&v"(x03), [w10] "=&v"(w10), [w11] "=&v"(w11), [w12] "=&v"(w12), [w13] "=&v"(w13),
+                   [x10] "=&v"(x10), [x11] "=&v"(x11), [x12] "=&v"(x12), [x13] "=&v"(x13)
+                 : [aw0] "v"(aw0), [aw1] "v"(aw1), [ax0] "v"(ax0), [ax1] "v"(ax1) : "memory");
+
+    // one MFMA of slice S: accumulator (NI, MI); MI 0-1 live in accA, 2-3 in accB
+#define M4(S, NI, E0, E1, E2, E3)                                                                            \
+    MF(a##NI##0, w##S##NI, x##S##0) E0 MF(a##NI##1, w##S##NI, x##S##1) E1                                    \
+    MF(b##NI##0, w##S##NI, x##S##2) E2 MF(b##NI##1, w##S##NI, x##S##3) E3
+#define NO ""
+#define TG(R) "v_add_u32 %[" #R "], %[sdel], %[" #R "]\n"
+    int sdel = LSTAGE;                                   // + 64 KiB / - 64 KiB: the fragment addresses flip between the two stages
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        // the asm decides "is there a stage ks + 2" itself from the integer nk - ks: a 0 / 1 flag computed here is selected
+        // onto the VALU (zero-extended compare -> v_cndmask) and hipcc then hands the asm that VGPR for an "s" operand
+        const int dodma = nk - ks;                       // DMA iff > 2
+        if (ks + 2 < nk) W4_NEXT()
+        const unsigned ldsn = ldsw + cur * LSTAGE;       // stage ks + 2 goes into THIS k-step's buffer (released by barrier A)
+        unsigned t0, t1, t2, t3, t4, t5, t6, t7, m0s;
+        asm volatile(
+            "s_mov_b32 %[m0s], m0\n" "s_cmp_gt_i32 %[dodma], 2\n" "s_cselect_b64 vcc, -1, 0\n"
+            "s_waitcnt lgkmcnt(0)\n"                     // nothing of the compiler's (SMEM) may be pending below
+            // slice 0 (16 MFMAs) + the 16 fragment reads of slices 2 and 3
+            M4(0, 0, RD(w20, aw2, 0), RD(w21, aw2, 4096), RD(w22, aw2, 8192), RD(w23, aw2, 12288))
+            M4(0, 1, RD(x20, ax2, 0), RD(x21, ax2, 4096), RD(x22, ax2, 8192), RD(x23, ax2, 12288))
+            M4(0, 2, RD(w30, aw3, 0), RD(w31, aw3, 4096), RD(w32, aw3, 8192), RD(w33, aw3, 12288))
+            M4(0, 3, RD(x30, ax3, 0), RD(x31, ax3, 4096), RD(x32, ax3, 8192), RD(x33, ax3, 12288))
+            // slice 1: fragment addresses flip to the other stage; all reads of this stage done -> barrier A frees its buffer
+            M4(1, 0, TG(aw0) TG(ax0), TG(aw1) TG(ax1), TG(aw2) TG(ax2), TG(aw3) TG(ax3))
+            "s_waitcnt lgkmcnt(0)\n" "s_barrier\n"
+            M4(1, 1, PX(0, 0), NO, PX(1, 4096), NO)
+            M4(1, 2, NO, PX(2, 8192), NO, NO)
+            M4(1, 3, PX(3, 12288), NO, PX(4, 16384), NO)
+            // slice 2
+            M4(2, 0, NO, PX(5, 20480), NO, NO)
+            M4(2, 1, PX(6, 24576), NO, PX(7, 28672), NO)
+            M4(2, 2, NO, PW0(32768), NO, NO)
+            M4(2, 3, PW(1, 36864), NO, NO, NO)
+            // 10 pieces issued: the 16 of stage ks + 1 (issued one k-step ago) have landed once <= 10 are outstanding
+            "s_cbranch_vccz .Lw0%=\n" "s_waitcnt vmcnt(10)\n" "s_branch .Lw1%=\n" ".Lw0%=:\n" "s_waitcnt vmcnt(0)\n" ".Lw1%=:\n"
+            "s_barrier\n"
+            // slice 3 + the 16 fragment reads of slices 0 and 1 of stage ks + 1, the remaining 6 W pieces in between
+            M4(3, 0, RD(w00, aw0, 0), RD(w01, aw0, 4096), RD(w02, aw0, 8192) PW(2, 40960), RD(w03, aw0, 12288))
+            M4(3, 1, RD(x00, ax0, 0), RD(x01, ax0, 4096) PW(3, 45056), RD(x02, ax0, 8192), RD(x03, ax0, 12288) PW(4, 49152))
+            M4(3, 2, RD(w10, aw1, 0), RD(w11, aw1, 4096), RD(w12, aw1, 8192) PW(5, 53248), RD(w13, aw1, 12288))
+            M4(3, 3, RD(x10, ax1, 0), RD(x11, ax1, 4096) PW(6, 57344), RD(x12, ax1, 8192), RD(x13, ax1, 12288) PW(7, 61440))
+            "s_waitcnt lgkmcnt(0)\n"
+            "s_mov_b32 m0, %[m0s]\n"
+            : [a00] "+a"(accA[0][0]), [a01] "+a"(accA[0][1]), [a10] "+a"(accA[1][0]), [a11] "+a"(accA[1][1]),
+              [a20] "+a"(accA[2][0]), [a21] "+a"(accA[2][1]), [a30] "+a"(accA[3][0]), [a31] "+a"(accA[3][1]),
+              [b00] "+a"(accB[0][0]), [b01] "+a"(accB[0][1]), [b10] "+a"(accB[1][0]), [b11] "+a"(accB[1][1]),
+              [b20] "+a"(accB[2][0]), [b21] "+a"(accB[2][1]), [b30] "+a"(accB[3][0]), [b31] "+a"(accB[3][1]),
+              [w00] "+v"(w00), [w01] "+v"(w01), [w02] "+v"(w02), [w03] "+v"(w03), [x00] "+v"(x00), [x01] "+v"(x01),
+              [x02] "+v"(x02), [x03] "+v"(x03), [w10] "+v"(w10), [w11] "+v"(w11), [w12] "+v"(w12), [w13] "+v"(w13),
+              [x10] "+v"(x10), [x11] "+v"(x11), [x12] "+v"(x12), [x13] "+v"(x13),
+              [w20] "=&v"(w20), [w21] "=&v"(w21), [w22] "=&v"(w22), [w23] "=&v"(w23), [x20] "=&v"(x20), [x21] "=&v"(x21),
+              [x22] "=&v"(x22), [x23] "=&v"(x23), [w30] "=&v"(w30), [w31] "=&v"(w31), [w32] "=&v"(w32), [w33] "=&v"(w33),
+              [x30] "=&v"(x30), [x31] "=&v"(x31), [x32] "=&v"(x32), [x33] "=&v"(x33),
+              [aw0] "+v"(aw0), [aw1] "+v"(aw1), [aw2] "+v"(aw2), [aw3] "+v"(aw3), [ax0] "+v"(ax0), [ax1] "+v"(ax1),
+              [ax2] "+v"(ax2), [ax3] "+v"(ax3), W4_TMP_OUT
+            : W4_DMA_IN, [sdel] "s"(sdel)
+            : "memory", "scc", "vcc");
+        sdel = -sdel;
+        cur ^= 1;
+    }
+#undef RD
+#undef MF
+#undef PX
+#undef PW0
+#undef PW
+#undef W4_DMA_IN
+#undef W4_TMP_OUT
+#undef RDW
+#undef RDX
+#undef M4
+#undef NO
+#undef TG
+#undef W4_NEXT
+    // the MFMAs issued last may still be in flight and the compiler cannot see them
+    asm volatile("s_nop 15\ns_nop 15" ::: "memory");
+    const unsigned ldsepi = ldsb + 2 * LSTAGE;
+    conv_epilogue<4, 2, GNK, true, 0>(p, accA, m0 + wm * 128, n0 + wn * 128, l32, hi32, ldsepi + wn * 512,
+                                      ldsepi + 1024 + (2 * wm) * 1024 + wn * 512);
+    conv_epilogue<4, 2, GNK, true, 0>(p, accB, m0 + wm * 128 + 64, n0 + wn * 128, l32, hi32, ldsepi + wn * 512,
+                                      ldsepi + 1024 + (2 * wm + 1) * 1024 + wn * 512);
+}
+
+// ---------------------------------------------------------------------------------------------
 // Short-K kernel (round 5): 1x1 convs / nn.Linear with K = C_in <= a few k-steps (the q / out / proj_in / proj_out
 // projections of attention.py:523-564, the 1x1 shortcuts of resnet.py:286-292).  In the 256x256x64 tile these launches
 // spend as long in their prologue (two cold DMA stages) and epilogue (fp32 residual in, fp32 rows out: HBM-bound) as in the
@@ -1704,15 +2013,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(ConvArgs p) {
 
 }  // namespace
 
+#ifdef UAV_DEV_W4_ONLY          // development: compile conv_gemm256w_kernel alone (seconds instead of minutes)
+extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
+    ConvArgs a = {};
+    hipLaunchKernelGGL(conv_gemm256w_kernel<0>, dim3(1), dim3(256), 2 * LSTAGE + LEPI_BYTES, (hipStream_t)stream, a);
+    return q ? 0 : 1;
+}
+#else
 namespace {
-struct ConvEnv { int korder, tile_order, force_tile, dbg, persist, dmav, sk, sk_maxk; };
+struct ConvEnv { int korder, tile_order, force_tile, dbg, persist, dmav, sk, sk_maxk, w4; };
 const ConvEnv& conv_env() {
     // Environment switches (development A/B only) are read once through a thread-safe magic static.
     static const ConvEnv env = [] {
         auto geti = [](const char* k, int d) { const char* e = getenv(k); return e ? atoi(e) : d; };
         return ConvEnv{geti("UAV_CONV_KORDER", 1), geti("UAV_CONV_TILE_ORDER", 1), geti("UAV_CONV_TILE", 0),
                        geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0), geti("UAV_CONV_DMAV", 6),       // 6: rotated k-step (round 4 default); 1: round 2-3 loop
-                       geti("UAV_CONV_SK", 1), geti("UAV_CONV_SK_MAXK", 1024)};                               // short-K kernel (round 5) for 1x1 launches with K <= SK_MAXK
+                       geti("UAV_CONV_SK", 0), geti("UAV_CONV_SK_MAXK", 1024),                                // short-K kernel (round 5 candidate, measured neutral: off) for 1x1 launches with K <= SK_MAXK
+                       geti("UAV_CONV_W4", 1)};                                                               // four-wave 128x128-wave-tile kernel (round 5) instead of conv_gemm256i_kernel
     }();
     return env;
 }
@@ -1723,6 +2040,25 @@ bool conv_uses_big_tile(const uav_conv_params* q) {
     const long long grid256 = ((M + LM - 1) / LM) * (q->n_pad / LN);
     const int force_tile = conv_env().force_tile;
     return !small && (q->n_pad % LN == 0) && (force_tile >= 256 || (force_tile != 128 && grid256 >= 224));
+}
+// n / d for n < 2^31 as umulhi(n, mul) >> sh (d >= 2: s = ceil(log2 d), mul = floor(2^(31+s) / d) + 1, sh = s - 1; d == 1: sh = 32 = "no division")
+void conv_magic(unsigned d, unsigned* mul, unsigned* sh) {
+    if (d <= 1) { *mul = 0; *sh = 32; return; }
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    *mul = (unsigned)(((1ull << (31 + s)) / d) + 1ull);
+    *sh = s - 1;
+}
+// Four-wave kernel (conv_gemm256w_kernel): every launch of the big-tile class whose taps fit a 32-bit validity mask and whose
+// sources fit a 32-bit buffer range; LayerNorm-fold instances, the nearest-2x gather and the A/B switches stay with the 8-wave kernels.
+bool conv_uses_w4(const uav_conv_params* q) {
+    const ConvEnv& env = conv_env();
+    if (!env.w4 || env.dbg || env.persist || !env.korder || env.dmav != 6 || (q->flags & (UAV_CONV_PERSISTENT | UAV_CONV_NO_W4))) return false;
+    if (q->upsample || q->ln_raw_out || q->ln_stat_in || q->kt * q->kh * q->kw > 32) return false;
+    const unsigned long long px = (unsigned long long)q->n_img * q->hi * q->wi;
+    const unsigned long long a2px = q->a2_images ? px / 2 : px;
+    if (px * q->c1 * 2 >= 0xfffffff0ull || a2px * q->c2 * 2 >= 0xfffffff0ull) return false;
+    return conv_uses_big_tile(q);
 }
 // Short-K kernel: 1x1 / stride 1 launches of the big-tile class with K <= UAV_CONV_SK_MAXK and whole 256-column tiles.
 bool conv_uses_sk(const uav_conv_params* q) {
@@ -1840,6 +2176,7 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
             return UAV_ESHAPE;
         a.a2_ctr = 1;
     }
+    a.x1_bytes = a.x2_bytes = 0; a.dv_hw_mul = a.dv_wo_mul = a.dv_t_mul = 0; a.dv_hw_sh = a.dv_wo_sh = a.dv_t_sh = 32;
     a.lnp_raw = nullptr; a.lnp_stat = nullptr; a.lnc_stat = nullptr; a.lnc_colsum = nullptr; a.lnc_chunks = 0; a.lnc_n = 0; a.lnc_eps = 0.f;
     if (q->ln_raw_out || q->ln_stat_in) {
         if (!conv_ln_ok(q)) return UAV_ESHAPE;             // ask uav_conv_gemm_ln_ok() first
@@ -1906,6 +2243,29 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
             if (gnm == 0) SK_LAUNCH(0, 1); else if (gnm == 1) SK_LAUNCH(1, 1); else if (gnm == 2) SK_LAUNCH(2, 1); else SK_LAUNCH(3, 1);
         }
 #undef SK_LAUNCH
+    } else if (big && conv_uses_w4(q)) {
+        constexpr int MAXDEV = 64;
+        static std::once_flag w4_once[MAXDEV];
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return UAV_EINVAL;
+        std::call_once(w4_once[dev], [] {
+            const void* fns[] = {(const void*)conv_gemm256w_kernel<0>, (const void*)conv_gemm256w_kernel<1>,
+                                 (const void*)conv_gemm256w_kernel<2>, (const void*)conv_gemm256w_kernel<3>};
+            for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE + LEPI_BYTES);
+        });
+        const unsigned long long px = (unsigned long long)q->n_img * q->hi * q->wi;
+        a.x1_bytes = (unsigned)(px * q->c1 * 2);
+        a.x2_bytes = (unsigned)((q->a2_images ? px / 2 : px) * q->c2 * 2);
+        conv_magic((unsigned)(q->ho * q->wo), &a.dv_hw_mul, &a.dv_hw_sh);
+        conv_magic((unsigned)q->wo, &a.dv_wo_mul, &a.dv_wo_sh);
+        conv_magic((unsigned)q->t_len, &a.dv_t_mul, &a.dv_t_sh);
+        a.ntiles = (unsigned)grid256;
+        const int gnm = a.gn_ws ? gn_mode_of(a.gn_cpg_log2) : 0;
+        const size_t lds = 2 * LSTAGE + LEPI_BYTES;
+        if (gnm == 0) hipLaunchKernelGGL(conv_gemm256w_kernel<0>, dim3((unsigned)grid256), dim3(256), lds, s, a);
+        else if (gnm == 1) hipLaunchKernelGGL(conv_gemm256w_kernel<1>, dim3((unsigned)grid256), dim3(256), lds, s, a);
+        else if (gnm == 2) hipLaunchKernelGGL(conv_gemm256w_kernel<2>, dim3((unsigned)grid256), dim3(256), lds, s, a);
+        else hipLaunchKernelGGL(conv_gemm256w_kernel<3>, dim3((unsigned)grid256), dim3(256), lds, s, a);
     } else if (big) {
         constexpr int MAXDEV = 64;
         static std::once_flag dev_once[MAXDEV];
@@ -1959,3 +2319,4 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         hipLaunchKernelGGL(conv_gemm_kernel<0>, dim3((unsigned)grid), dim3(256), 2 * STAGE_BYTES, s, a);
     return uav_launch_status();
 }
+#endif  // UAV_DEV_W4_ONLY

@@ -45,6 +45,7 @@ CONV_PERSISTENT = 64
 CONV_RES_F32 = 128
 CONV_GELU, CONV_QUICK_GELU = 256, 512
 CONV_NO_SHORTK = 1024
+CONV_NO_W4 = 2048
 CONV_RELU, CONV_SIGMOID, CONV_TANH = 4, 8, 16
 
 # name -> (restype, argtypes); the complete export list of include/uav_hip.h

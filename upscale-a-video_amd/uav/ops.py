@@ -246,7 +246,7 @@ def upsample_phase_weights(weight):
 def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None,
               rowbias=None, rows_per_batch=0, residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None,
               persistent=False, act=None, gn_groups=None, out_map=None, a2_center=False, ln_produce=False, ln_consume=None,
-              gn_shared=None, no_shortk=False):
+              gn_shared=None, no_shortk=False, no_w4=False):
     """out[M][n_out] = scale*(conv(a1|a2, W) + bias + rowbias[m//rows_per_batch] + residual).
 
     no_shortk: keep a 1x1 launch out of the short-K kernel (UAV_CONV_NO_SHORTK: A/B measurements, bit-identity test).
@@ -302,6 +302,8 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
         flags |= {"gelu": _lib.CONV_GELU, "quick_gelu": _lib.CONV_QUICK_GELU}[act]
     if no_shortk:
         flags |= _lib.CONV_NO_SHORTK
+    if no_w4:
+        flags |= _lib.CONV_NO_W4
     p = _lib.ConvParams()
     p.a1 = _p(a1); p.a2 = _p(a2); p.c1 = c1; p.c2 = c2
     p.w = _p(wt.w); p.bias = _p(wt.bias)
@@ -406,12 +408,12 @@ def _factor_rows(m):
 
 
 def linear(x, wt: ConvW, *, residual=None, out_scale=1.0, rowbias=None, rows_per_batch=0, out_f32=False, act=None,
-           gn_groups=None, ln_produce=False, ln_consume=None, no_shortk=False):
+           gn_groups=None, ln_produce=False, ln_consume=None, no_shortk=False, no_w4=False):
     """nn.Linear over token rows x[M][K] (a 1x1 'conv': every row is one pixel)."""
     n_img, hi = _factor_rows(x.shape[0])
     return conv_gemm(x, wt, n_img=n_img, t_len=1, hi=hi, wi=1, residual=residual, out_scale=out_scale,
                      rowbias=rowbias, rows_per_batch=rows_per_batch, out_f32=out_f32, act=act, gn_groups=gn_groups,
-                     ln_produce=ln_produce, ln_consume=ln_consume, no_shortk=no_shortk)
+                     ln_produce=ln_produce, ln_consume=ln_consume, no_shortk=no_shortk, no_w4=no_w4)
 
 
 def ln_fold_ok(m, k, wt: ConvW):
