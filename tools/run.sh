@@ -26,10 +26,15 @@ for step in "$@"; do
               (cd $R && timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee -a $O/${TAG}_tests.log) ;;
     shortk)   timeout 400 python $R/tools/bench_shortk.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_shortk.log ;;
     shortk2)  UAV_CONV_SK=2 timeout 400 python $R/tools/bench_shortk.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_shortk_compiler_kstep.log ;;
+    trace_stag) UAV_CONV_W4_STAGGER=${UAV_STAG:-30000} UAV_CONV_W4_TRACE=1 timeout 300 python $R/tools/trace_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_trace_stagger.log ;;
+    w4ab_stag) UAV_CONV_W4_STAGGER=${UAV_STAG:-30000} timeout 500 python $R/tools/bench_w4.py lin 1x1 t3 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_vs_8wave_stagger.log ;;
+    trace)    UAV_CONV_W4_TRACE=1 timeout 300 python $R/tools/trace_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_trace.log ;;
+    w4ab)     timeout 500 python $R/tools/bench_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_vs_8wave.log ;;
     epi)      timeout 400 python $R/tools/bench_epilogue.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_epilogue.log ;;
     epi_w40)  UAV_CONV_W4=0 timeout 400 python $R/tools/bench_epilogue.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_epilogue_8wave.log ;;
     calib_w40) UAV_CONV_W4=0 timeout 300 python $R/tools/calib_gemm.py conv1x1 conv3x3 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_calib_8wave.jsonl ;;
-    bench1_w40) (cd $R && UAV_CONV_W4=0 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2> /dev/null | tee $O/${TAG}_bench1_8wave.json) ;;
+    bench1_mink) (cd $R && UAV_CONV_W4_MINK=${UAV_MINK:-1024} timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_w4_mink.json) ;;
+    bench1_w40) (cd $R && UAV_CONV_W4=0 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_8wave.json) ;;
     calib)    timeout 300 python $R/tools/calib_gemm.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_calib.jsonl ;;
     blas)     timeout 300 python $R/tools/calib_blas_shapes.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_calib_blas_shapes.jsonl ;;
     calib_pmc)
@@ -57,7 +62,7 @@ PY
       cat $L ;;
     bench)    (cd $R && timeout 900 python bench.py 2> $O/${TAG}_bench.err | tee $O/${TAG}_bench.json) ;;
     bench_sk0) (cd $R && UAV_CONV_SK=0 timeout 900 python bench.py --no-cpu-baseline 2> /dev/null | tee $O/${TAG}_bench_sk0.json) ;;
-    bench1)   (cd $R && timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2> $O/${TAG}_bench1.err | tee $O/${TAG}_bench1.json) ;;
+    bench1)   (cd $R && timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> $O/${TAG}_bench1.err | tee $O/${TAG}_bench1.json) ;;
     bench1_sk0) (cd $R && UAV_CONV_SK=0 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2> /dev/null | tee $O/${TAG}_bench1_sk0.json) ;;
     shape)    (cd $R && UAV_BENCH_DETAIL=1 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> $O/${TAG}_per_shape.txt > $O/${TAG}_bench_detail.json; grep -v amdgpu.ids $O/${TAG}_per_shape.txt | head -70) ;;
     prof)     rm -rf /tmp/prof; (cd $R && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof -o b -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> /dev/null)

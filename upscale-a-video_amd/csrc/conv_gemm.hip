@@ -26,6 +26,8 @@
 #include "uav_common.h"
 #include <stdlib.h>
 #include <mutex>
+#include <vector>
+#include <stdio.h>
 
 namespace {
 
@@ -59,6 +61,8 @@ struct ConvArgs {
     // magic numbers of the three divisions that turn a GEMM row into (image, y, x, frame) — n / d = umulhi(n, mul) >> sh, n < 2^31
     unsigned x1_bytes, x2_bytes;
     unsigned dv_hw_mul, dv_hw_sh, dv_wo_mul, dv_wo_sh, dv_t_mul, dv_t_sh;
+    unsigned long long* trace;                                          // development (UAV_CONV_W4_TRACE): 8 words per workgroup
+    unsigned stagger;                                                   // experiment (UAV_CONV_W4_STAGGER): start delay of every other first-round workgroup, ticks
 };
 
 // Source-2 pixel of GEMM pixel px: the skip tensors of the CFG-shared UNet head exist once and serve both batch entries
@@ -1566,12 +1570,21 @@ UAV_DEVINL uint4_t w4_srd(const char* base, unsigned bytes) {
 }
 UAV_DEVINL unsigned udiv_magic(unsigned n, unsigned mul, unsigned sh) { return sh >= 32u ? n : (__umulhi(n, mul) >> sh); }
 
-template <int GNK>
+// TR = 1: development instance (UAV_CONV_W4_TRACE=1) that stamps s_memtime at the phase boundaries of every workgroup.
+template <int GNK, int TR = 0>
 __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi32 = lane >> 5, l32 = lane & 31;
+    unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
+    if (p.stagger && blockIdx.x < 256u && ((blockIdx.x >> 3) & 1u)) {
+        // experiment: de-phase the CUs — all workgroups of the first round start together and stay in step (same tile cost), so the
+        // whole chip is in its HBM-bound epilogue, or in none, at the same time
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(16);
+    }
+    if (TR) ts[0] = __builtin_amdgcn_s_memtime();
 
     // tile id -> (m tile, n tile), frame-fastest for temporal taps (see conv_gemm256_kernel)
     const unsigned n_tiles = p.n_pad / LN;
@@ -1595,9 +1608,15 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
     // ---- gather constants: byte offset of (row, slot) at tap (pad_t, pad_h, pad_w) and the mask of INVALID taps ------------
     const int slot_log = (lane & 7) ^ ((wave * 4 + (lane >> 4)) & 7);
     const int rlane = wave * 8 + (lane >> 3);            // this lane's row inside every 32-row DMA piece
+    // im[i]: which tap displacements fall outside the input for this lane's row of piece i — bits [0:7] frame steps dt, [8:15]
+    // rows dy, [16:23] columns dx (all set for a row past M); a stage's tap selects one bit of each field (tab_sel below).  The
+    // invalid steps of an axis are a prefix and a suffix of 0 .. k-1: two clamps and shifts, no loop over the taps.
     unsigned vo[8], vo2[8], im[8];
-    const int ylim = p.hi, xlim = p.wi;
-    const int khw = p.kh * p.kw;
+    auto axis_bad = [](int c0, int lim) -> unsigned {     // steps d in 0 .. 7 with c0 + d outside [0, lim)
+        const int lo = c0 < 0 ? (-c0 < 8 ? -c0 : 8) : 0;
+        const int h0 = lim - c0 < 0 ? 0 : (lim - c0 < 8 ? lim - c0 : 8);
+        return ((1u << lo) - 1u) | (0xffu & ~((1u << h0) - 1u));
+    };
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const long long m_ = m0 + i * 32 + rlane;
@@ -1613,17 +1632,10 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
         vo[i] = (px_ * (unsigned)p.c1 + (unsigned)slot_log * 8u) * 2u;
         const unsigned px2_ = (p.a2_pix && px_ >= (unsigned)p.a2_pix) ? px_ - (unsigned)p.a2_pix : px_;
         vo2[i] = (px2_ * (unsigned)p.c2 + (unsigned)slot_log * 8u) * 2u;
-        unsigned xbad = 0;
-        for (int dx = 0; dx < p.kw; ++dx) xbad |= ((unsigned)(xi_ - p.pad_w + dx) >= (unsigned)xlim ? 1u : 0u) << dx;
-        const unsigned full = (1u << p.kw) - 1u;
-        unsigned inv = 0;
-        for (int dt = 0; dt < p.kt; ++dt)
-            for (int dy = 0; dy < p.kh; ++dy) {
-                const bool bad = !ok_ | ((unsigned)((int)tt_ - p.pad_t + dt) >= (unsigned)p.t_len) | ((unsigned)(yi_ - p.pad_h + dy) >= (unsigned)ylim);
-                inv |= (bad ? full : xbad) << ((dt * p.kh + dy) * p.kw);
-            }
-        im[i] = inv;
+        const unsigned pk = axis_bad((int)tt_ - p.pad_t, p.t_len) | (axis_bad(yi_ - p.pad_h, p.hi) << 8) | (axis_bad(xi_ - p.pad_w, p.wi) << 16);
+        im[i] = ok_ ? pk : 0x00ffffffu;
     }
+    const int khw = p.kh * p.kw;
     const unsigned woff = (unsigned)(((long long)rlane * p.k_pad + slot_log * 8) * 2);
     const unsigned wps32 = (unsigned)(32ll * p.k_pad * 2);
     const char* wtile = p.w + (long long)n0 * p.k_pad * 2;
@@ -1643,46 +1655,65 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
     const int ntaps = dt_hi * khw;
     const int ctr_tap = (p.pad_t * p.kh + p.pad_h) * p.kw + p.pad_w;
     const int nk = __builtin_amdgcn_readfirstlane(p.a2_ctr ? (p.c1 / BK) * (ntaps - tap_lo) + p.c2 / BK : (cin / BK) * (ntaps - tap_lo));
-    int kdt = dt_lo, kdy = 0, kdx = 0, ktap = tap_lo, kc = 0;    // wave-uniform: tap / channel block of the NEXT stage to address
-    bool on2 = false;                                             // the offsets in vo[] are those of source 2
+
+    // ---- scalar address walk of the stages (tap-innermost K order), ~25 SALU per stage, no division, no 64-bit multiply:
+    //   X base of a stage = source + channel-block bytes (xb) + byte displacement of its tap (table in the lanes of tab_lo / tab_hi,
+    //   lane = tap index, read with v_readlane); W base = wcur, stepped by one tap (cin * 2 bytes) or, behind the last tap of a
+    //   channel block, back to the first tap of the next block.  Source 2 (channel blocks >= c1; centre tap only with a2_ctr) is a
+    //   second phase with its own constants, entered through a wave-uniform branch once per tile.
+    const int cin2 = cin * 2;
+    int tap0 = tap_lo, tapend = ntaps;                            // taps of a channel block in the current phase
+    long long wstep_wrap = 128ll - (long long)(ntaps - tap_lo - 1) * cin2;
+    int blkleft = p.c1 / BK;
+    int tau = tap_lo;
+    unsigned xbytes = p.x1_bytes;
+    long long xb = (long long)p.a1;
+    long long wcur = (long long)wtile + (long long)tap_lo * cin2;
+    // tables over the taps, one tap per lane (read with v_readlane): byte displacement of the tap in the current source and the
+    // three validity bits it selects
+    int tab_lo, tab_hi, tab_sel;
+    long long tab_pd;
+    {
+        const int tp = lane < 32 ? lane : 0;
+        const int dt_ = (int)(((float)tp + 0.5f) * (1.0f / (float)khw)), r_ = tp - dt_ * khw;      // exact: tp < 32
+        const int dy_ = (int)(((float)r_ + 0.5f) * (1.0f / (float)p.kw)), dx_ = r_ - dy_ * p.kw;
+        tab_pd = ((long long)(dt_ - p.pad_t) * p.hi + (dy_ - p.pad_h)) * p.wi + (dx_ - p.pad_w);
+        const long long d1 = tab_pd * p.c1 * 2;
+        tab_lo = (int)(unsigned)d1; tab_hi = (int)(d1 >> 32);
+        tab_sel = (1 << (dt_ & 7)) | (1 << (8 + (dy_ & 7))) | (1 << (16 + (dx_ & 7)));
+    }
     uint4_t xsrd, wsrd;
     unsigned tapn;
-
-    // scalar address step of the next stage: buffer bases (X: source + tap / channel-block displacement, W: + K offset)
 #define W4_NEXT()                                                                                            \
     {                                                                                                        \
-        const bool first = kc < p.c1;                                                                        \
-        const char* xsrc = first ? p.a1 : p.a2;                                                              \
-        const int xcs = first ? p.c1 : p.c2;                                                                 \
-        const int xco = first ? kc : kc - p.c1;                                                              \
-        const long long xd = ((((long long)(kdt - p.pad_t) * p.hi + (kdy - p.pad_h)) * p.wi + (kdx - p.pad_w)) * xcs + xco) * 2; \
-        xsrd = w4_srd(xsrc + xd, first ? p.x1_bytes : p.x2_bytes);                                           \
-        wsrd = w4_srd(wtile + ((long long)ktap * cin + kc) * 2, 0x7fffffffu);                                \
-        tapn = (unsigned)ktap;                                                                               \
-        if (!first && !on2) {                                                                                \
-            on2 = true;                                                                                      \
-            _Pragma("unroll") for (int i = 0; i < 8; ++i) vo[i] = vo2[i];                                    \
-        }                                                                                                    \
-        if (p.a2_ctr && kc >= p.c1) {            /* source 2: one (centre) tap per channel block */          \
-            kc += BK;                                                                                        \
-        } else {                                 /* tap-innermost K order */                                 \
-            ++ktap;                                                                                          \
-            if (++kdx == p.kw) { kdx = 0; if (++kdy == p.kh) { kdy = 0; ++kdt; } }                           \
-            if (ktap == ntaps) {                                                                             \
-                ktap = tap_lo; kdt = dt_lo; kdy = 0; kdx = 0; kc += BK;                                      \
-                if (p.a2_ctr && kc >= p.c1) { ktap = ctr_tap; kdt = p.pad_t; kdy = p.pad_h; kdx = p.pad_w; } \
+        if (blkleft == 0) {                                  /* source 1 is exhausted: phase 2 (once per tile) */ \
+            blkleft = 0x40000000;                                                                            \
+            if (p.c2 > 0) {                                                                                  \
+                xb = (long long)p.a2; xbytes = p.x2_bytes;                                                   \
+                if (p.a2_ctr) {                                                                              \
+                    wcur += (long long)(ctr_tap - tap_lo) * cin2;                                            \
+                    tap0 = ctr_tap; tapend = ctr_tap + 1; tau = ctr_tap; wstep_wrap = 128;                   \
+                }                                                                                            \
+                const long long d2 = tab_pd * p.c2 * 2;                                                      \
+                tab_lo = (int)(unsigned)d2; tab_hi = (int)(d2 >> 32);                                        \
+                _Pragma("unroll") for (int i = 0; i < 8; ++i) vo[i] = vo2[i];                                \
             }                                                                                                \
         }                                                                                                    \
+        const unsigned dl = (unsigned)__builtin_amdgcn_readlane(tab_lo, tau);                                \
+        const int dh = __builtin_amdgcn_readlane(tab_hi, tau);                                               \
+        const long long xa = xb + (long long)(((unsigned long long)(unsigned)dh << 32) | dl);               \
+        xsrd = uint4_t{(unsigned)xa, (unsigned)((unsigned long long)xa >> 32) & 0xffffu, xbytes, 0x00020000u}; \
+        wsrd = uint4_t{(unsigned)wcur, (unsigned)((unsigned long long)wcur >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u}; \
+        tapn = (unsigned)__builtin_amdgcn_readlane(tab_sel, tau);                                            \
+        const int t1_ = tau + 1;                                                                             \
+        const int wm_ = (tapend - t1_ - 1) >> 31;            /* -1 behind the last tap of the block, else 0 */ \
+        tau = (t1_ & ~wm_) | (tap0 & wm_);                                                                   \
+        xb += (long long)(128 & wm_);                                                                        \
+        wcur += wm_ ? wstep_wrap : (long long)cin2;                                                          \
+        blkleft += wm_;                                                                                      \
     }
 
     const int wn = wave & 1, wm = wave >> 1;
-    float16_t accA[4][2], accB[4][2];                    // rows [wm*128, +64) and [wm*128 + 64, +64)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { accA[i][j][r] = 0.f; accB[i][j][r] = 0.f; }
 
     const int sw = (l32 >> 1) & 7;
     const unsigned ldsb = (unsigned)(size_t)(lptr_t)smem;
@@ -1706,12 +1737,14 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
 
 #define RD(D, A, OFF) "ds_read_b128 %[" #D "], %[" #A "] offset:" #OFF "\n"
 #define MF(C, A, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #A "], %[" #B "], %[" #C "]\n"
-    // X piece I (rows I*32 ..): validity -> effective offset, M0 = LDS destination, buffer load to LDS
+    // X piece I (rows I*32 ..): the stage's tap bits against the row's invalid-step bits -> effective offset (all ones: out of
+    // range, the load returns zeros), M0 = LDS destination, buffer load to LDS
 #define PX(I, OFF)                                                                                           \
     "s_cbranch_vccz .Lnx%=_" #I "\n"                                                                         \
-    "v_bfe_i32 %[t" #I "], %[im" #I "], %[tapn], 1\n"                                                        \
+    "v_and_b32 %[t" #I "], %[tapn], %[im" #I "]\n"                                                           \
     "s_add_u32 m0, %[ldsn], " #OFF "\n"                                                                      \
-    "v_or_b32 %[t" #I "], %[t" #I "], %[vo" #I "]\n"                                                         \
+    "v_cmp_ne_u32_e64 %[sp], 0, %[t" #I "]\n"                                                                \
+    "v_cndmask_b32_e64 %[t" #I "], %[vo" #I "], -1, %[sp]\n"                                                 \
     "buffer_load_dwordx4 %[t" #I "], %[xsrd], 0 offen lds\n"                                                 \
     ".Lnx%=_" #I ":\n"
 #define PW0(OFF)                                                                                             \
@@ -1728,21 +1761,32 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
     [ws7] "s"(ws7), [ldsn] "s"(ldsn), [dodma] "s"(dodma), [tapn] "s"(tapn)
 #define W4_TMP_OUT                                                                                           \
     [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6),        \
-    [t7] "=&v"(t7), [m0s] "=&s"(m0s)
+    [t7] "=&v"(t7), [m0s] "=&s"(m0s), [sp] "=&s"(spair)
     const unsigned ws1 = wps32, ws2 = 2 * wps32, ws3 = 3 * wps32, ws4 = 4 * wps32, ws5 = 5 * wps32, ws6 = 6 * wps32, ws7 = 7 * wps32;
 
+    if (TR) ts[1] = __builtin_amdgcn_s_memtime();
     // ---- prologue: stage 0 -> buffer 0, stage 1 -> buffer 1 -----------------------------------------
     for (int st = 0; st < 2 && st < nk; ++st) {
         W4_NEXT()
         const unsigned ldsn = ldsw + st * LSTAGE;
         const int dodma = 3;
         unsigned t0, t1, t2, t3, t4, t5, t6, t7, m0s;
+        unsigned long long spair;
         asm volatile("s_mov_b32 %[m0s], m0\n" "s_cmp_gt_i32 %[dodma], 2\n" "s_cselect_b64 vcc, -1, 0\n"
                      PX(0, 0) PX(1, 4096) PX(2, 8192) PX(3, 12288) PX(4, 16384) PX(5, 20480) PX(6, 24576) PX(7, 28672)
                      PW0(32768) PW(1, 36864) PW(2, 40960) PW(3, 45056) PW(4, 49152) PW(5, 53248) PW(6, 57344) PW(7, 61440)
                      "s_mov_b32 m0, %[m0s]\n"
                      : W4_TMP_OUT : W4_DMA_IN : "memory", "scc", "vcc");
     }
+    // the 256 accumulators are cleared while the first stages are in flight
+    float16_t accA[4][2], accB[4][2];                    // rows [wm*128, +64) and [wm*128 + 64, +64)
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { accA[i][j][r] = 0.f; accB[i][j][r] = 0.f; }
+    asm volatile("" : "+a"(accA[0][0]), "+a"(accA[3][1]), "+a"(accB[0][0]), "+a"(accB[3][1]));     // (keeps the clears here)
     if (nk > 1) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                        // stage 0 of every wave has landed, the epilogue constants are in LDS
@@ -1764,6 +1808,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
     MF(b##NI##0, w##S##NI, x##S##2) E2 MF(b##NI##1, w##S##NI, x##S##3) E3
 #define NO ""
 #define TG(R) "v_add_u32 %[" #R "], %[sdel], %[" #R "]\n"
+    if (TR) ts[2] = __builtin_amdgcn_s_memtime();
     int sdel = LSTAGE;                                   // + 64 KiB / - 64 KiB: the fragment addresses flip between the two stages
     int cur = 0;
     for (int ks = 0; ks < nk; ++ks) {
@@ -1773,6 +1818,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
         if (ks + 2 < nk) W4_NEXT()
         const unsigned ldsn = ldsw + cur * LSTAGE;       // stage ks + 2 goes into THIS k-step's buffer (released by barrier A)
         unsigned t0, t1, t2, t3, t4, t5, t6, t7, m0s;
+        unsigned long long spair;
         asm volatile(
             "s_mov_b32 %[m0s], m0\n" "s_cmp_gt_i32 %[dodma], 2\n" "s_cselect_b64 vcc, -1, 0\n"
             "s_waitcnt lgkmcnt(0)\n"                     // nothing of the compiler's (SMEM) may be pending below
@@ -1834,11 +1880,24 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
 #undef W4_NEXT
     // the MFMAs issued last may still be in flight and the compiler cannot see them
     asm volatile("s_nop 15\ns_nop 15" ::: "memory");
+    if (TR) ts[3] = __builtin_amdgcn_s_memtime();
     const unsigned ldsepi = ldsb + 2 * LSTAGE;
     conv_epilogue<4, 2, GNK, true, 0>(p, accA, m0 + wm * 128, n0 + wn * 128, l32, hi32, ldsepi + wn * 512,
                                       ldsepi + 1024 + (2 * wm) * 1024 + wn * 512);
+    if (TR) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[4] = __builtin_amdgcn_s_memtime(); }
     conv_epilogue<4, 2, GNK, true, 0>(p, accB, m0 + wm * 128 + 64, n0 + wn * 128, l32, hi32, ldsepi + wn * 512,
                                       ldsepi + 1024 + (2 * wm + 1) * 1024 + wn * 512);
+    if (TR) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[5] = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            unsigned long long* t = p.trace + (size_t)blockIdx.x * 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t[i] = ts[i];
+            t[6] = (unsigned long long)nk;
+            t[7] = (unsigned long long)__builtin_amdgcn_s_getreg(0xf814);      // HW_REG_XCC_ID etc. (unused)
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2021,7 +2080,7 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
 }
 #else
 namespace {
-struct ConvEnv { int korder, tile_order, force_tile, dbg, persist, dmav, sk, sk_maxk, w4; };
+struct ConvEnv { int korder, tile_order, force_tile, dbg, persist, dmav, sk, sk_maxk, w4, w4_mink; };
 const ConvEnv& conv_env() {
     // Environment switches (development A/B only) are read once through a thread-safe magic static.
     static const ConvEnv env = [] {
@@ -2029,7 +2088,7 @@ const ConvEnv& conv_env() {
         return ConvEnv{geti("UAV_CONV_KORDER", 1), geti("UAV_CONV_TILE_ORDER", 1), geti("UAV_CONV_TILE", 0),
                        geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0), geti("UAV_CONV_DMAV", 6),       // 6: rotated k-step (round 4 default); 1: round 2-3 loop
                        geti("UAV_CONV_SK", 0), geti("UAV_CONV_SK_MAXK", 1024),                                // short-K kernel (round 5 candidate, measured neutral: off) for 1x1 launches with K <= SK_MAXK
-                       geti("UAV_CONV_W4", 1)};                                                               // four-wave 128x128-wave-tile kernel (round 5) instead of conv_gemm256i_kernel
+                       geti("UAV_CONV_W4", 1), geti("UAV_CONV_W4_MINK", 1024)};                             // W4 for K = taps x C_in >= MINK (same-box clip A/B, run 10: 1.000 -> 1.057 everywhere -> 1.070 from K = 1024)                                                               // four-wave 128x128-wave-tile kernel (round 5) instead of conv_gemm256i_kernel
     }();
     return env;
 }
@@ -2054,7 +2113,8 @@ void conv_magic(unsigned d, unsigned* mul, unsigned* sh) {
 bool conv_uses_w4(const uav_conv_params* q) {
     const ConvEnv& env = conv_env();
     if (!env.w4 || env.dbg || env.persist || !env.korder || env.dmav != 6 || (q->flags & (UAV_CONV_PERSISTENT | UAV_CONV_NO_W4))) return false;
-    if (q->upsample || q->ln_raw_out || q->ln_stat_in || q->kt * q->kh * q->kw > 32) return false;
+    if (q->upsample || q->ln_raw_out || q->ln_stat_in || q->kt * q->kh * q->kw > 32 || q->kt > 8 || q->kh > 8 || q->kw > 8) return false;
+    if ((long long)q->kt * q->kh * q->kw * (q->c1 + q->c2) < env.w4_mink) return false;      // A/B: short K stays with the 8-wave kernel
     const unsigned long long px = (unsigned long long)q->n_img * q->hi * q->wi;
     const unsigned long long a2px = q->a2_images ? px / 2 : px;
     if (px * q->c1 * 2 >= 0xfffffff0ull || a2px * q->c2 * 2 >= 0xfffffff0ull) return false;
@@ -2176,6 +2236,7 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
             return UAV_ESHAPE;
         a.a2_ctr = 1;
     }
+    a.trace = nullptr; a.stagger = 0;
     a.x1_bytes = a.x2_bytes = 0; a.dv_hw_mul = a.dv_wo_mul = a.dv_t_mul = 0; a.dv_hw_sh = a.dv_wo_sh = a.dv_t_sh = 32;
     a.lnp_raw = nullptr; a.lnp_stat = nullptr; a.lnc_stat = nullptr; a.lnc_colsum = nullptr; a.lnc_chunks = 0; a.lnc_n = 0; a.lnc_eps = 0.f;
     if (q->ln_raw_out || q->ln_stat_in) {
@@ -2262,6 +2323,32 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         a.ntiles = (unsigned)grid256;
         const int gnm = a.gn_ws ? gn_mode_of(a.gn_cpg_log2) : 0;
         const size_t lds = 2 * LSTAGE + LEPI_BYTES;
+        a.trace = nullptr;
+        static const int w4_stagger = [] { const char* e = getenv("UAV_CONV_W4_STAGGER"); return e ? atoi(e) : 0; }();
+        a.stagger = (unsigned)w4_stagger;
+        static const bool w4_trace = getenv("UAV_CONV_W4_TRACE") != nullptr;
+        if (w4_trace && gnm == 0) {        // development: phase time stamps of every workgroup, printed to stderr (synchronises!)
+            static std::once_flag tr_once;
+            std::call_once(tr_once, [] { (void)hipFuncSetAttribute((const void*)conv_gemm256w_kernel<0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE + LEPI_BYTES); });
+            unsigned long long* tb = nullptr;
+            if (hipMalloc((void**)&tb, (size_t)grid256 * 64) != hipSuccess) return UAV_EINVAL;
+            a.trace = tb;
+            hipLaunchKernelGGL((conv_gemm256w_kernel<0, 1>), dim3((unsigned)grid256), dim3(256), lds, s, a);
+            std::vector<unsigned long long> h((size_t)grid256 * 8);
+            (void)hipStreamSynchronize(s);
+            (void)hipMemcpy(h.data(), tb, h.size() * 8, hipMemcpyDeviceToHost);
+            (void)hipFree(tb);
+            double sum[5] = {0, 0, 0, 0, 0}; unsigned long long tmin = ~0ull, tmax = 0;
+            for (long long i = 0; i < grid256; ++i) {
+                for (int k = 0; k < 5; ++k) sum[k] += (double)(h[i * 8 + k + 1] - h[i * 8 + k]);
+                if (h[i * 8] < tmin) tmin = h[i * 8];
+                if (h[i * 8 + 5] > tmax) tmax = h[i * 8 + 5];
+            }
+            fprintf(stderr, "[w4 trace] tiles %lld nk %llu ticks: setup %.0f prologue %.0f loop %.0f (%.1f / k-step) epiA %.0f epiB %.0f | whole launch %llu ticks\n",
+                    grid256, h[6], sum[0] / grid256, sum[1] / grid256, sum[2] / grid256, sum[2] / grid256 / (double)h[6], sum[3] / grid256,
+                    sum[4] / grid256, tmax - tmin);
+            return uav_launch_status();
+        }
         if (gnm == 0) hipLaunchKernelGGL(conv_gemm256w_kernel<0>, dim3((unsigned)grid256), dim3(256), lds, s, a);
         else if (gnm == 1) hipLaunchKernelGGL(conv_gemm256w_kernel<1>, dim3((unsigned)grid256), dim3(256), lds, s, a);
         else if (gnm == 2) hipLaunchKernelGGL(conv_gemm256w_kernel<2>, dim3((unsigned)grid256), dim3(256), lds, s, a);
