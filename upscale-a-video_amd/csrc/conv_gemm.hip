@@ -1560,7 +1560,6 @@ __global__ __launch_bounds__(512, 2) void conv_gemm256i_kernel(ConvArgs p) {
 //     step is a scalar added to the buffer base, and padding is the hardware's out-of-range rule — a precomputed per-row
 //     bit mask over the taps ORs the offset to 0xffffffff (2 VALU per piece and k-step instead of ~12, no zero page);
 //   * LDS-DMA stays in flight across both barriers (counted vmcnt, never 0 while more stages follow).
-constexpr int W4_NPRE = 10;                     // DMA pieces of a k-step issued before its second barrier (vmcnt count)
 
 struct W4Srd { unsigned w[4]; };
 UAV_DEVINL uint4_t w4_srd(const char* base, unsigned bytes) {
@@ -1656,62 +1655,73 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
     const int ctr_tap = (p.pad_t * p.kh + p.pad_h) * p.kw + p.pad_w;
     const int nk = __builtin_amdgcn_readfirstlane(p.a2_ctr ? (p.c1 / BK) * (ntaps - tap_lo) + p.c2 / BK : (cin / BK) * (ntaps - tap_lo));
 
-    // ---- scalar address walk of the stages (tap-innermost K order), ~25 SALU per stage, no division, no 64-bit multiply:
-    //   X base of a stage = source + channel-block bytes (xb) + byte displacement of its tap (table in the lanes of tab_lo / tab_hi,
-    //   lane = tap index, read with v_readlane); W base = wcur, stepped by one tap (cin * 2 bytes) or, behind the last tap of a
-    //   channel block, back to the first tap of the next block.  Source 2 (channel blocks >= c1; centre tap only with a2_ctr) is a
-    //   second phase with its own constants, entered through a wave-uniform branch once per tile.
+    // ---- scalar address walk of the stages (tap-innermost K order): 32-bit, inside the asm, hidden between the MFMAs -------
+    //   Both buffer descriptors are constant per source: X = (source base - xbias, source bytes + 2 xbias), W = (this tile's
+    //   rows, "no limit").  A stage is addressed by two scalars: X displacement xso = xkc + tab[tap] — added to the per-lane
+    //   offsets on the VALU (measured, run 12: gfx950 range-checks voffset + SOFFSET, so a displacement in the SGPR offset zero-
+    //   fills valid pixels near the end of the tensor) — channel-block bytes + xbias +
+    //   the tap's byte displacement (>= -xbias; pixel displacements in the lanes of `tab_pd`, lane = tap, read with v_readlane,
+    //   times the source's bytes per pixel) — and W soffset
+    //   = wofs (+ piece rows), stepped by one tap (cin * 2 bytes) or, behind the last tap of a channel block, back to the first
+    //   tap of the next block (wwrap).  Source 2 (channel blocks >= c1; centre tap only with a2_ctr) is a second phase with its
+    //   own constants, entered through a wave-uniform branch once per tile.
     const int cin2 = cin * 2;
     int tap0 = tap_lo, tapend = ntaps;                            // taps of a channel block in the current phase
-    long long wstep_wrap = 128ll - (long long)(ntaps - tap_lo - 1) * cin2;
-    int blkleft = p.c1 / BK;
+    int wwrap = 128 - (ntaps - tap_lo - 1) * cin2;
+    int blk = p.c1 / BK;                                          // channel blocks left in this phase
     int tau = tap_lo;
-    unsigned xbytes = p.x1_bytes;
-    long long xb = (long long)p.a1;
-    long long wcur = (long long)wtile + (long long)tap_lo * cin2;
-    // tables over the taps, one tap per lane (read with v_readlane): byte displacement of the tap in the current source and the
-    // three validity bits it selects
-    int tab_lo, tab_hi, tab_sel;
-    long long tab_pd;
+    int wofs = tap_lo * cin2;
+    // tables over the taps, one tap per lane: pixel displacement (x cs2 = bytes in the current source) and the three validity
+    // bits a tap selects
+    int tab_sel, tab_pd;
     {
         const int tp = lane < 32 ? lane : 0;
         const int dt_ = (int)(((float)tp + 0.5f) * (1.0f / (float)khw)), r_ = tp - dt_ * khw;      // exact: tp < 32
         const int dy_ = (int)(((float)r_ + 0.5f) * (1.0f / (float)p.kw)), dx_ = r_ - dy_ * p.kw;
-        tab_pd = ((long long)(dt_ - p.pad_t) * p.hi + (dy_ - p.pad_h)) * p.wi + (dx_ - p.pad_w);
-        const long long d1 = tab_pd * p.c1 * 2;
-        tab_lo = (int)(unsigned)d1; tab_hi = (int)(d1 >> 32);
+        tab_pd = ((dt_ - p.pad_t) * p.hi + (dy_ - p.pad_h)) * p.wi + (dx_ - p.pad_w);
         tab_sel = (1 << (dt_ & 7)) | (1 << (8 + (dy_ & 7))) | (1 << (16 + (dx_ & 7)));
     }
-    uint4_t xsrd, wsrd;
-    unsigned tapn;
-#define W4_NEXT()                                                                                            \
+    const int pdmin = ((p.pad_t * p.hi + p.pad_h) * p.wi + p.pad_w);      // -(most negative pixel displacement)
+    int xkc = pdmin * p.c1 * 2;                                   // channel-block bytes + xbias of the next stage to address
+    int cs2 = p.c1 * 2;                                           // bytes per pixel of the current source
+    uint4_t xsrd = w4_srd(p.a1 - (long long)pdmin * p.c1 * 2, p.x1_bytes + (unsigned)(2 * pdmin * p.c1 * 2));
+    const uint4_t wsrd = w4_srd(wtile, 0x7fffffffu);
+    // phase 2 (called when blk reaches 0, before the asm addresses the next stage)
+#define W4_PHASE2()                                                                                          \
     {                                                                                                        \
-        if (blkleft == 0) {                                  /* source 1 is exhausted: phase 2 (once per tile) */ \
-            blkleft = 0x40000000;                                                                            \
-            if (p.c2 > 0) {                                                                                  \
-                xb = (long long)p.a2; xbytes = p.x2_bytes;                                                   \
-                if (p.a2_ctr) {                                                                              \
-                    wcur += (long long)(ctr_tap - tap_lo) * cin2;                                            \
-                    tap0 = ctr_tap; tapend = ctr_tap + 1; tau = ctr_tap; wstep_wrap = 128;                   \
-                }                                                                                            \
-                const long long d2 = tab_pd * p.c2 * 2;                                                      \
-                tab_lo = (int)(unsigned)d2; tab_hi = (int)(d2 >> 32);                                        \
-                _Pragma("unroll") for (int i = 0; i < 8; ++i) vo[i] = vo2[i];                                \
+        blk = 0x40000000;                                                                                    \
+        if (p.c2 > 0) {                                                                                      \
+            xsrd = w4_srd(p.a2 - (long long)pdmin * p.c2 * 2, p.x2_bytes + (unsigned)(2 * pdmin * p.c2 * 2)); \
+            xkc = pdmin * p.c2 * 2;                                                                          \
+            cs2 = p.c2 * 2;                                                                                  \
+            if (p.a2_ctr) {                                                                                  \
+                wofs += (ctr_tap - tap_lo) * cin2;                                                           \
+                tap0 = ctr_tap; tapend = ctr_tap + 1; tau = ctr_tap; wwrap = 128;                            \
             }                                                                                                \
+            _Pragma("unroll") for (int i = 0; i < 8; ++i) vo[i] = vo2[i];                                    \
         }                                                                                                    \
-        const unsigned dl = (unsigned)__builtin_amdgcn_readlane(tab_lo, tau);                                \
-        const int dh = __builtin_amdgcn_readlane(tab_hi, tau);                                               \
-        const long long xa = xb + (long long)(((unsigned long long)(unsigned)dh << 32) | dl);               \
-        xsrd = uint4_t{(unsigned)xa, (unsigned)((unsigned long long)xa >> 32) & 0xffffu, xbytes, 0x00020000u}; \
-        wsrd = uint4_t{(unsigned)wcur, (unsigned)((unsigned long long)wcur >> 32) & 0xffffu, 0x7fffffffu, 0x00020000u}; \
-        tapn = (unsigned)__builtin_amdgcn_readlane(tab_sel, tau);                                            \
-        const int t1_ = tau + 1;                                                                             \
-        const int wm_ = (tapend - t1_ - 1) >> 31;            /* -1 behind the last tap of the block, else 0 */ \
-        tau = (t1_ & ~wm_) | (tap0 & wm_);                                                                   \
-        xb += (long long)(128 & wm_);                                                                        \
-        wcur += wm_ ? wstep_wrap : (long long)cin2;                                                          \
-        blkleft += wm_;                                                                                      \
     }
+    // the walk itself (asm): this stage's scalars -> stap (validity bits), xso (X soffset), wso (W soffset); then advance
+#define W4_WALK                                                                                              \
+    "v_readlane_b32 %[stap], %[tabsel], %[tau]\n"                                                            \
+    "v_readlane_b32 %[xso], %[tab], %[tau]\n"                                                                \
+    "s_mov_b32 %[wso], %[wofs]\n"                                                                            \
+    "s_add_i32 %[tau], %[tau], 1\n"                                                                          \
+    "s_mul_i32 %[xso], %[xso], %[cs2]\n"                                                                     \
+    "s_add_u32 %[xso], %[xso], %[xkc]\n"                                                                     \
+    "s_cmp_eq_u32 %[tau], %[tapend]\n"                                                                       \
+    "s_cselect_b32 %[tau], %[tap0], %[tau]\n"                                                                \
+    "s_cselect_b32 %[sa], 128, 0\n"                                                                          \
+    "s_cselect_b32 %[sb], %[wwrap], %[cin2]\n"                                                               \
+    "s_cselect_b32 %[sc], -1, 0\n"                                                                           \
+    "s_add_u32 %[xkc], %[xkc], %[sa]\n"                                                                      \
+    "s_add_u32 %[wofs], %[wofs], %[sb]\n"                                                                    \
+    "s_add_i32 %[blk], %[blk], %[sc]\n"
+#define W4_WALK_OUT                                                                                          \
+    [tau] "+s"(tau), [xkc] "+s"(xkc), [wofs] "+s"(wofs), [blk] "+s"(blk), [stap] "=&s"(stap), [xso] "=&s"(xso),            \
+    [wso] "=&s"(wso), [sa] "=&s"(sa), [sb] "=&s"(sb), [sc] "=&s"(sc)
+#define W4_WALK_IN                                                                                           \
+    [tab] "v"(tab_pd), [tabsel] "v"(tab_sel), [tapend] "s"(tapend), [tap0] "s"(tap0), [wwrap] "s"(wwrap), [cin2] "s"(cin2), [cs2] "s"(cs2)
 
     const int wn = wave & 1, wm = wave >> 1;
 
@@ -1741,40 +1751,37 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
     // range, the load returns zeros), M0 = LDS destination, buffer load to LDS
 #define PX(I, OFF)                                                                                           \
     "s_cbranch_vccz .Lnx%=_" #I "\n"                                                                         \
-    "v_and_b32 %[t" #I "], %[tapn], %[im" #I "]\n"                                                           \
+    "v_and_b32 %[t" #I "], %[stap], %[im" #I "]\n"                                                           \
     "s_add_u32 m0, %[ldsn], " #OFF "\n"                                                                      \
     "v_cmp_ne_u32_e64 %[sp], 0, %[t" #I "]\n"                                                                \
-    "v_cndmask_b32_e64 %[t" #I "], %[vo" #I "], -1, %[sp]\n"                                                 \
+    "v_add_u32 %[t" #I "], %[xso], %[vo" #I "]\n"                                                            \
+    "v_cndmask_b32_e64 %[t" #I "], %[t" #I "], -1, %[sp]\n"                                                  \
     "buffer_load_dwordx4 %[t" #I "], %[xsrd], 0 offen lds\n"                                                 \
     ".Lnx%=_" #I ":\n"
-#define PW0(OFF)                                                                                             \
-    "s_cbranch_vccz .Lnw%=_0\n" "s_add_u32 m0, %[ldsn], " #OFF "\n" "s_nop 0\n"                              \
-    "buffer_load_dwordx4 %[woff], %[wsrd], 0 offen lds\n" ".Lnw%=_0:\n"
+    // W piece I (rows I*32 ..): every lane valid; the piece's row offset accumulates in wso
 #define PW(I, OFF)                                                                                           \
     "s_cbranch_vccz .Lnw%=_" #I "\n" "s_add_u32 m0, %[ldsn], " #OFF "\n" "s_nop 0\n"                         \
-    "buffer_load_dwordx4 %[woff], %[wsrd], %[ws" #I "] offen lds\n" ".Lnw%=_" #I ":\n"
+    "buffer_load_dwordx4 %[woff], %[wsrd], %[wso] offen lds\n" "s_add_u32 %[wso], %[wso], %[wps]\n" ".Lnw%=_" #I ":\n"
 #define W4_DMA_IN                                                                                            \
     [vo0] "v"(vo[0]), [vo1] "v"(vo[1]), [vo2] "v"(vo[2]), [vo3] "v"(vo[3]), [vo4] "v"(vo[4]), [vo5] "v"(vo[5]),            \
     [vo6] "v"(vo[6]), [vo7] "v"(vo[7]), [im0] "v"(im[0]), [im1] "v"(im[1]), [im2] "v"(im[2]), [im3] "v"(im[3]),            \
     [im4] "v"(im[4]), [im5] "v"(im[5]), [im6] "v"(im[6]), [im7] "v"(im[7]), [woff] "v"(woff), [xsrd] "s"(xsrd),            \
-    [wsrd] "s"(wsrd), [ws1] "s"(ws1), [ws2] "s"(ws2), [ws3] "s"(ws3), [ws4] "s"(ws4), [ws5] "s"(ws5), [ws6] "s"(ws6),      \
-    [ws7] "s"(ws7), [ldsn] "s"(ldsn), [dodma] "s"(dodma), [tapn] "s"(tapn)
+    [wsrd] "s"(wsrd), [wps] "s"(wps32), [ldsn] "s"(ldsn), [dodma] "s"(dodma), W4_WALK_IN
 #define W4_TMP_OUT                                                                                           \
     [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [t6] "=&v"(t6),        \
-    [t7] "=&v"(t7), [m0s] "=&s"(m0s), [sp] "=&s"(spair)
-    const unsigned ws1 = wps32, ws2 = 2 * wps32, ws3 = 3 * wps32, ws4 = 4 * wps32, ws5 = 5 * wps32, ws6 = 6 * wps32, ws7 = 7 * wps32;
+    [t7] "=&v"(t7), [m0s] "=&s"(m0s), [sp] "=&s"(spair), W4_WALK_OUT
 
     if (TR) ts[1] = __builtin_amdgcn_s_memtime();
     // ---- prologue: stage 0 -> buffer 0, stage 1 -> buffer 1 -----------------------------------------
     for (int st = 0; st < 2 && st < nk; ++st) {
-        W4_NEXT()
+        if (blk == 0) W4_PHASE2()
         const unsigned ldsn = ldsw + st * LSTAGE;
         const int dodma = 3;
-        unsigned t0, t1, t2, t3, t4, t5, t6, t7, m0s;
+        unsigned t0, t1, t2, t3, t4, t5, t6, t7, m0s, stap, xso, wso, sa, sb, sc;
         unsigned long long spair;
-        asm volatile("s_mov_b32 %[m0s], m0\n" "s_cmp_gt_i32 %[dodma], 2\n" "s_cselect_b64 vcc, -1, 0\n"
+        asm volatile("s_mov_b32 %[m0s], m0\n" "s_cmp_gt_i32 %[dodma], 2\n" "s_cselect_b64 vcc, -1, 0\n" W4_WALK
                      PX(0, 0) PX(1, 4096) PX(2, 8192) PX(3, 12288) PX(4, 16384) PX(5, 20480) PX(6, 24576) PX(7, 28672)
-                     PW0(32768) PW(1, 36864) PW(2, 40960) PW(3, 45056) PW(4, 49152) PW(5, 53248) PW(6, 57344) PW(7, 61440)
+                     PW(0, 32768) PW(1, 36864) PW(2, 40960) PW(3, 45056) PW(4, 49152) PW(5, 53248) PW(6, 57344) PW(7, 61440)
                      "s_mov_b32 m0, %[m0s]\n"
                      : W4_TMP_OUT : W4_DMA_IN : "memory", "scc", "vcc");
     }
@@ -1815,9 +1822,9 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
         // the asm decides "is there a stage ks + 2" itself from the integer nk - ks: a 0 / 1 flag computed here is selected
         // onto the VALU (zero-extended compare -> v_cndmask) and hipcc then hands the asm that VGPR for an "s" operand
         const int dodma = nk - ks;                       // DMA iff > 2
-        if (ks + 2 < nk) W4_NEXT()
+        if (blk == 0) W4_PHASE2()
         const unsigned ldsn = ldsw + cur * LSTAGE;       // stage ks + 2 goes into THIS k-step's buffer (released by barrier A)
-        unsigned t0, t1, t2, t3, t4, t5, t6, t7, m0s;
+        unsigned t0, t1, t2, t3, t4, t5, t6, t7, m0s, stap, xso, wso, sa, sb, sc;
         unsigned long long spair;
         asm volatile(
             "s_mov_b32 %[m0s], m0\n" "s_cmp_gt_i32 %[dodma], 2\n" "s_cselect_b64 vcc, -1, 0\n"
@@ -1827,25 +1834,27 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
             M4(0, 1, RD(x20, ax2, 0), RD(x21, ax2, 4096), RD(x22, ax2, 8192), RD(x23, ax2, 12288))
             M4(0, 2, RD(w30, aw3, 0), RD(w31, aw3, 4096), RD(w32, aw3, 8192), RD(w33, aw3, 12288))
             M4(0, 3, RD(x30, ax3, 0), RD(x31, ax3, 4096), RD(x32, ax3, 8192), RD(x33, ax3, 12288))
-            // slice 1: fragment addresses flip to the other stage; all reads of this stage done -> barrier A frees its buffer
+            // slice 1: the scalar walk to stage ks + 2, the fragment addresses flip to the other stage; all reads of this stage
+            // done -> barrier A frees its buffer
+            "s_cbranch_vccz .Lnwk%=\n" W4_WALK ".Lnwk%=:\n"
             M4(1, 0, TG(aw0) TG(ax0), TG(aw1) TG(ax1), TG(aw2) TG(ax2), TG(aw3) TG(ax3))
             "s_waitcnt lgkmcnt(0)\n" "s_barrier\n"
             M4(1, 1, PX(0, 0), NO, PX(1, 4096), NO)
-            M4(1, 2, NO, PX(2, 8192), NO, NO)
-            M4(1, 3, PX(3, 12288), NO, PX(4, 16384), NO)
+            M4(1, 2, NO, PX(2, 8192), NO, PX(3, 12288))
+            M4(1, 3, NO, PX(4, 16384), NO, PX(5, 20480))
             // slice 2
-            M4(2, 0, NO, PX(5, 20480), NO, NO)
-            M4(2, 1, PX(6, 24576), NO, PX(7, 28672), NO)
-            M4(2, 2, NO, PW0(32768), NO, NO)
-            M4(2, 3, PW(1, 36864), NO, NO, NO)
-            // 10 pieces issued: the 16 of stage ks + 1 (issued one k-step ago) have landed once <= 10 are outstanding
-            "s_cbranch_vccz .Lw0%=\n" "s_waitcnt vmcnt(10)\n" "s_branch .Lw1%=\n" ".Lw0%=:\n" "s_waitcnt vmcnt(0)\n" ".Lw1%=:\n"
+            M4(2, 0, NO, PX(6, 24576), NO, PX(7, 28672))
+            M4(2, 1, NO, NO, NO, NO)
+            // 8 pieces issued: the 16 of stage ks + 1 (issued one k-step ago) have landed once <= 8 are outstanding
+            "s_cbranch_vccz .Lw0%=\n" "s_waitcnt vmcnt(8)\n" "s_branch .Lw1%=\n" ".Lw0%=:\n" "s_waitcnt vmcnt(0)\n" ".Lw1%=:\n"
             "s_barrier\n"
-            // slice 3 + the 16 fragment reads of slices 0 and 1 of stage ks + 1, the remaining 6 W pieces in between
-            M4(3, 0, RD(w00, aw0, 0), RD(w01, aw0, 4096), RD(w02, aw0, 8192) PW(2, 40960), RD(w03, aw0, 12288))
-            M4(3, 1, RD(x00, ax0, 0), RD(x01, ax0, 4096) PW(3, 45056), RD(x02, ax0, 8192), RD(x03, ax0, 12288) PW(4, 49152))
-            M4(3, 2, RD(w10, aw1, 0), RD(w11, aw1, 4096), RD(w12, aw1, 8192) PW(5, 53248), RD(w13, aw1, 12288))
-            M4(3, 3, RD(x10, ax1, 0), RD(x11, ax1, 4096) PW(6, 57344), RD(x12, ax1, 8192), RD(x13, ax1, 12288) PW(7, 61440))
+            // rest of slice 2 + slice 3: the 16 fragment reads of slices 0 and 1 of stage ks + 1 and the 8 W pieces
+            M4(2, 2, RD(w00, aw0, 0), RD(w01, aw0, 4096) PW(0, 32768), RD(w02, aw0, 8192), RD(w03, aw0, 12288) PW(1, 36864))
+            M4(2, 3, RD(x00, ax0, 0), RD(x01, ax0, 4096) PW(2, 40960), RD(x02, ax0, 8192), RD(x03, ax0, 12288) PW(3, 45056))
+            M4(3, 0, RD(w10, aw1, 0), RD(w11, aw1, 4096) PW(4, 49152), RD(w12, aw1, 8192), RD(w13, aw1, 12288) PW(5, 53248))
+            M4(3, 1, RD(x10, ax1, 0), RD(x11, ax1, 4096) PW(6, 57344), RD(x12, ax1, 8192), RD(x13, ax1, 12288) PW(7, 61440))
+            M4(3, 2, NO, NO, NO, NO)
+            M4(3, 3, NO, NO, NO, NO)
             "s_waitcnt lgkmcnt(0)\n"
             "s_mov_b32 m0, %[m0s]\n"
             : [a00] "+a"(accA[0][0]), [a01] "+a"(accA[0][1]), [a10] "+a"(accA[1][0]), [a11] "+a"(accA[1][1]),
@@ -1868,8 +1877,11 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
 #undef RD
 #undef MF
 #undef PX
-#undef PW0
 #undef PW
+#undef W4_WALK
+#undef W4_WALK_OUT
+#undef W4_WALK_IN
+#undef W4_PHASE2
 #undef W4_DMA_IN
 #undef W4_TMP_OUT
 #undef RDW
@@ -1877,7 +1889,6 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
 #undef M4
 #undef NO
 #undef TG
-#undef W4_NEXT
     // the MFMAs issued last may still be in flight and the compiler cannot see them
     asm volatile("s_nop 15\ns_nop 15" ::: "memory");
     if (TR) ts[3] = __builtin_amdgcn_s_memtime();
@@ -2117,7 +2128,8 @@ bool conv_uses_w4(const uav_conv_params* q) {
     if ((long long)q->kt * q->kh * q->kw * (q->c1 + q->c2) < env.w4_mink) return false;      // A/B: short K stays with the 8-wave kernel
     const unsigned long long px = (unsigned long long)q->n_img * q->hi * q->wi;
     const unsigned long long a2px = q->a2_images ? px / 2 : px;
-    if (px * q->c1 * 2 >= 0xfffffff0ull || a2px * q->c2 * 2 >= 0xfffffff0ull) return false;
+    const unsigned long long halo = 2ull * (((unsigned long long)q->pad_t * q->hi + q->pad_h) * q->wi + q->pad_w) + 16;   // pixels of displacement range
+    if ((px + halo) * q->c1 * 2 >= 0xfffffff0ull || (a2px + halo) * q->c2 * 2 >= 0xfffffff0ull) return false;
     return conv_uses_big_tile(q);
 }
 // Short-K kernel: 1x1 / stride 1 launches of the big-tile class with K <= UAV_CONV_SK_MAXK and whole 256-column tiles.
