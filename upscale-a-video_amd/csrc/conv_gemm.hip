@@ -1702,21 +1702,24 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
         }                                                                                                    \
     }
     // the walk itself (asm): this stage's scalars -> stap (validity bits), xso (X soffset), wso (W soffset); then advance
-#define W4_WALK                                                                                              \
+#define W4_WALK1                                                                                             \
     "v_readlane_b32 %[stap], %[tabsel], %[tau]\n"                                                            \
     "v_readlane_b32 %[xso], %[tab], %[tau]\n"                                                                \
     "s_mov_b32 %[wso], %[wofs]\n"                                                                            \
     "s_add_i32 %[tau], %[tau], 1\n"                                                                          \
     "s_mul_i32 %[xso], %[xso], %[cs2]\n"                                                                     \
-    "s_add_u32 %[xso], %[xso], %[xkc]\n"                                                                     \
+    "s_add_u32 %[xso], %[xso], %[xkc]\n"
+#define W4_WALK2                                                                                             \
     "s_cmp_eq_u32 %[tau], %[tapend]\n"                                                                       \
     "s_cselect_b32 %[tau], %[tap0], %[tau]\n"                                                                \
     "s_cselect_b32 %[sa], 128, 0\n"                                                                          \
     "s_cselect_b32 %[sb], %[wwrap], %[cin2]\n"                                                               \
-    "s_cselect_b32 %[sc], -1, 0\n"                                                                           \
+    "s_cselect_b32 %[sc], -1, 0\n"
+#define W4_WALK3                                                                                             \
     "s_add_u32 %[xkc], %[xkc], %[sa]\n"                                                                      \
     "s_add_u32 %[wofs], %[wofs], %[sb]\n"                                                                    \
     "s_add_i32 %[blk], %[blk], %[sc]\n"
+#define W4_WALK W4_WALK1 W4_WALK2 W4_WALK3
 #define W4_WALK_OUT                                                                                          \
     [tau] "+s"(tau), [xkc] "+s"(xkc), [wofs] "+s"(wofs), [blk] "+s"(blk), [stap] "=&s"(stap), [xso] "=&s"(xso),            \
     [wso] "=&s"(wso), [sa] "=&s"(sa), [sb] "=&s"(sb), [sc] "=&s"(sc)
@@ -1749,15 +1752,18 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
 #define MF(C, A, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #A "], %[" #B "], %[" #C "]\n"
     // X piece I (rows I*32 ..): the stage's tap bits against the row's invalid-step bits -> effective offset (all ones: out of
     // range, the load returns zeros), M0 = LDS destination, buffer load to LDS
-#define PX(I, OFF)                                                                                           \
-    "s_cbranch_vccz .Lnx%=_" #I "\n"                                                                         \
+#define PXA(I)                                                                                               \
     "v_and_b32 %[t" #I "], %[stap], %[im" #I "]\n"                                                           \
-    "s_add_u32 m0, %[ldsn], " #OFF "\n"                                                                      \
     "v_cmp_ne_u32_e64 %[sp], 0, %[t" #I "]\n"                                                                \
     "v_add_u32 %[t" #I "], %[xso], %[vo" #I "]\n"                                                            \
-    "v_cndmask_b32_e64 %[t" #I "], %[t" #I "], -1, %[sp]\n"                                                  \
+    "v_cndmask_b32_e64 %[t" #I "], %[t" #I "], -1, %[sp]\n"
+#define PXB(I, OFF)                                                                                          \
+    "s_cbranch_vccz .Lnx%=_" #I "\n"                                                                         \
+    "s_add_u32 m0, %[ldsn], " #OFF "\n"                                                                      \
+    "s_nop 0\n"                                                                                              \
     "buffer_load_dwordx4 %[t" #I "], %[xsrd], 0 offen lds\n"                                                 \
     ".Lnx%=_" #I ":\n"
+#define PX(I, OFF) PXA(I) PXB(I, OFF)
     // W piece I (rows I*32 ..): every lane valid; the piece's row offset accumulates in wso
 #define PW(I, OFF)                                                                                           \
     "s_cbranch_vccz .Lnw%=_" #I "\n" "s_add_u32 m0, %[ldsn], " #OFF "\n" "s_nop 0\n"                         \
@@ -1821,7 +1827,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
     for (int ks = 0; ks < nk; ++ks) {
         // the asm decides "is there a stage ks + 2" itself from the integer nk - ks: a 0 / 1 flag computed here is selected
         // onto the VALU (zero-extended compare -> v_cndmask) and hipcc then hands the asm that VGPR for an "s" operand
-        const int dodma = nk - ks;                       // DMA iff > 2
+        const int dodma = p.stagger == 0xdeadu ? 0 : nk - ks;       // DMA iff > 2 (development: UAV_CONV_W4_STAGGER=57005 times the loop without its DMA)
         if (blk == 0) W4_PHASE2()
         const unsigned ldsn = ldsw + cur * LSTAGE;       // stage ks + 2 goes into THIS k-step's buffer (released by barrier A)
         unsigned t0, t1, t2, t3, t4, t5, t6, t7, m0s, stap, xso, wso, sa, sb, sc;
@@ -1829,30 +1835,30 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
         asm volatile(
             "s_mov_b32 %[m0s], m0\n" "s_cmp_gt_i32 %[dodma], 2\n" "s_cselect_b64 vcc, -1, 0\n"
             "s_waitcnt lgkmcnt(0)\n"                     // nothing of the compiler's (SMEM) may be pending below
-            // slice 0 (16 MFMAs) + the 16 fragment reads of slices 2 and 3
+            // slice 0 (16 MFMAs) + the 16 fragment reads of slices 2 and 3; the scalar walk to stage ks + 2 in three pieces
             M4(0, 0, RD(w20, aw2, 0), RD(w21, aw2, 4096), RD(w22, aw2, 8192), RD(w23, aw2, 12288))
             M4(0, 1, RD(x20, ax2, 0), RD(x21, ax2, 4096), RD(x22, ax2, 8192), RD(x23, ax2, 12288))
-            M4(0, 2, RD(w30, aw3, 0), RD(w31, aw3, 4096), RD(w32, aw3, 8192), RD(w33, aw3, 12288))
-            M4(0, 3, RD(x30, ax3, 0), RD(x31, ax3, 4096), RD(x32, ax3, 8192), RD(x33, ax3, 12288))
-            // slice 1: the scalar walk to stage ks + 2, the fragment addresses flip to the other stage; all reads of this stage
-            // done -> barrier A frees its buffer
-            "s_cbranch_vccz .Lnwk%=\n" W4_WALK ".Lnwk%=:\n"
-            M4(1, 0, TG(aw0) TG(ax0), TG(aw1) TG(ax1), TG(aw2) TG(ax2), TG(aw3) TG(ax3))
+            M4(0, 2, RD(w30, aw3, 0) "s_cbranch_vccz .Lk1%=\n" W4_WALK1 ".Lk1%=:\n", RD(w31, aw3, 4096),
+                     RD(w32, aw3, 8192) "s_cbranch_vccz .Lk2%=\n" W4_WALK2 ".Lk2%=:\n", RD(w33, aw3, 12288))
+            M4(0, 3, RD(x30, ax3, 0) "s_cbranch_vccz .Lk3%=\n" W4_WALK3 ".Lk3%=:\n", RD(x31, ax3, 4096), RD(x32, ax3, 8192), RD(x33, ax3, 12288))
+            // slice 1: the fragment addresses flip to the other stage, the effective X offsets of pieces 0-3; all reads of this
+            // stage done -> barrier A frees its buffer
+            M4(1, 0, TG(aw0) TG(ax0) PXA(0), TG(aw1) TG(ax1) PXA(1), TG(aw2) TG(ax2) PXA(2), TG(aw3) TG(ax3) PXA(3))
             "s_waitcnt lgkmcnt(0)\n" "s_barrier\n"
-            M4(1, 1, PX(0, 0), NO, PX(1, 4096), NO)
-            M4(1, 2, NO, PX(2, 8192), NO, PX(3, 12288))
-            M4(1, 3, NO, PX(4, 16384), NO, PX(5, 20480))
+            M4(1, 1, PXB(0, 0), PXA(4), PXB(1, 4096), PXA(5))
+            M4(1, 2, PXB(2, 8192), PXA(6), PXB(3, 12288), PXA(7))
+            M4(1, 3, PXB(4, 16384), NO, PXB(5, 20480), NO)
             // slice 2
-            M4(2, 0, NO, PX(6, 24576), NO, PX(7, 28672))
+            M4(2, 0, PXB(6, 24576), NO, PXB(7, 28672), NO)
             M4(2, 1, NO, NO, NO, NO)
             // 8 pieces issued: the 16 of stage ks + 1 (issued one k-step ago) have landed once <= 8 are outstanding
             "s_cbranch_vccz .Lw0%=\n" "s_waitcnt vmcnt(8)\n" "s_branch .Lw1%=\n" ".Lw0%=:\n" "s_waitcnt vmcnt(0)\n" ".Lw1%=:\n"
             "s_barrier\n"
             // rest of slice 2 + slice 3: the 16 fragment reads of slices 0 and 1 of stage ks + 1 and the 8 W pieces
-            M4(2, 2, RD(w00, aw0, 0), RD(w01, aw0, 4096) PW(0, 32768), RD(w02, aw0, 8192), RD(w03, aw0, 12288) PW(1, 36864))
-            M4(2, 3, RD(x00, ax0, 0), RD(x01, ax0, 4096) PW(2, 40960), RD(x02, ax0, 8192), RD(x03, ax0, 12288) PW(3, 45056))
-            M4(3, 0, RD(w10, aw1, 0), RD(w11, aw1, 4096) PW(4, 49152), RD(w12, aw1, 8192), RD(w13, aw1, 12288) PW(5, 53248))
-            M4(3, 1, RD(x10, ax1, 0), RD(x11, ax1, 4096) PW(6, 57344), RD(x12, ax1, 8192), RD(x13, ax1, 12288) PW(7, 61440))
+            M4(2, 2, RD(w00, aw0, 0) PW(0, 32768), RD(w01, aw0, 4096), RD(w02, aw0, 8192) PW(1, 36864), RD(w03, aw0, 12288))
+            M4(2, 3, RD(x00, ax0, 0) PW(2, 40960), RD(x01, ax0, 4096), RD(x02, ax0, 8192) PW(3, 45056), RD(x03, ax0, 12288))
+            M4(3, 0, RD(w10, aw1, 0) PW(4, 49152), RD(w11, aw1, 4096), RD(w12, aw1, 8192) PW(5, 53248), RD(w13, aw1, 12288))
+            M4(3, 1, RD(x10, ax1, 0) PW(6, 57344), RD(x11, ax1, 4096), RD(x12, ax1, 8192) PW(7, 61440), RD(x13, ax1, 12288))
             M4(3, 2, NO, NO, NO, NO)
             M4(3, 3, NO, NO, NO, NO)
             "s_waitcnt lgkmcnt(0)\n"
@@ -1877,6 +1883,11 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
 #undef RD
 #undef MF
 #undef PX
+#undef PXA
+#undef PXB
+#undef W4_WALK1
+#undef W4_WALK2
+#undef W4_WALK3
 #undef PW
 #undef W4_WALK
 #undef W4_WALK_OUT
