@@ -62,7 +62,6 @@ struct ConvArgs {
     unsigned x1_bytes, x2_bytes;
     unsigned dv_hw_mul, dv_hw_sh, dv_wo_mul, dv_wo_sh, dv_t_mul, dv_t_sh;
     unsigned long long* trace;                                          // development (UAV_CONV_W4_TRACE): 8 words per workgroup
-    unsigned stagger;                                                   // experiment (UAV_CONV_W4_STAGGER): start delay of every other first-round workgroup, ticks
 };
 
 // Source-2 pixel of GEMM pixel px: the skip tensors of the CFG-shared UNet head exist once and serve both batch entries
@@ -1577,12 +1576,6 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int hi32 = lane >> 5, l32 = lane & 31;
     unsigned long long ts[6] = {0, 0, 0, 0, 0, 0};
-    if (p.stagger && blockIdx.x < 256u && ((blockIdx.x >> 3) & 1u)) {
-        // experiment: de-phase the CUs — all workgroups of the first round start together and stay in step (same tile cost), so the
-        // whole chip is in its HBM-bound epilogue, or in none, at the same time
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)p.stagger) __builtin_amdgcn_s_sleep(16);
-    }
     if (TR) ts[0] = __builtin_amdgcn_s_memtime();
 
     // tile id -> (m tile, n tile), frame-fastest for temporal taps (see conv_gemm256_kernel)
@@ -1827,7 +1820,7 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
     for (int ks = 0; ks < nk; ++ks) {
         // the asm decides "is there a stage ks + 2" itself from the integer nk - ks: a 0 / 1 flag computed here is selected
         // onto the VALU (zero-extended compare -> v_cndmask) and hipcc then hands the asm that VGPR for an "s" operand
-        const int dodma = p.stagger == 0xdeadu ? 0 : nk - ks;       // DMA iff > 2 (development: UAV_CONV_W4_STAGGER=57005 times the loop without its DMA)
+        const int dodma = nk - ks;                       // DMA iff > 2
         if (blk == 0) W4_PHASE2()
         const unsigned ldsn = ldsw + cur * LSTAGE;       // stage ks + 2 goes into THIS k-step's buffer (released by barrier A)
         unsigned t0, t1, t2, t3, t4, t5, t6, t7, m0s, stap, xso, wso, sa, sb, sc;
@@ -2259,7 +2252,7 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
             return UAV_ESHAPE;
         a.a2_ctr = 1;
     }
-    a.trace = nullptr; a.stagger = 0;
+    a.trace = nullptr;
     a.x1_bytes = a.x2_bytes = 0; a.dv_hw_mul = a.dv_wo_mul = a.dv_t_mul = 0; a.dv_hw_sh = a.dv_wo_sh = a.dv_t_sh = 32;
     a.lnp_raw = nullptr; a.lnp_stat = nullptr; a.lnc_stat = nullptr; a.lnc_colsum = nullptr; a.lnc_chunks = 0; a.lnc_n = 0; a.lnc_eps = 0.f;
     if (q->ln_raw_out || q->ln_stat_in) {
@@ -2347,8 +2340,6 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         const int gnm = a.gn_ws ? gn_mode_of(a.gn_cpg_log2) : 0;
         const size_t lds = 2 * LSTAGE + LEPI_BYTES;
         a.trace = nullptr;
-        static const int w4_stagger = [] { const char* e = getenv("UAV_CONV_W4_STAGGER"); return e ? atoi(e) : 0; }();
-        a.stagger = (unsigned)w4_stagger;
         static const bool w4_trace = getenv("UAV_CONV_W4_TRACE") != nullptr;
         if (w4_trace && gnm == 0) {        // development: phase time stamps of every workgroup, printed to stderr (synchronises!)
             static std::once_flag tr_once;
