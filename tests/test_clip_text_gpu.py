@@ -1,7 +1,7 @@
 """MI355X-native CLIP text encoder (uav/clip_text.py) against transformers' `CLIPTextModel` (fp32, CPU) with seeded
 random weights: a small quick-GELU model (OpenAI-CLIP style) and the ViT-H/14 text tower the released pipeline ships
 (24 layers, width 1024, 16 heads, GELU, 77 tokens).  Tolerance: activations / weights are fp16 with fp32 accumulation,
-the reference CLI runs this model in fp16 as well (from_pretrained(torch_dtype=float16)) -> rel-L2 <= 3e-3 vs fp32."""
+the reference CLI runs this model in fp16 as well (from_pretrained(torch_dtype=float16)); bars: measured + 25 % (CLIP_BARS)."""
 import json
 import os
 
@@ -10,7 +10,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLIP_BAR = 3e-3          # -> measured + 25 % once profiles/r05_parity_* holds the value
+# measured (round 5, run 18): 6.3e-4 (small quick-GELU model), 1.32e-3 (ViT-H text tower, 24 layers); bars = measured + 25 %
+CLIP_BARS = {"small_quick_gelu": 8.0e-4, "vit_h_text_tower": 1.65e-3}
 
 
 def rel_l2(a, b):
@@ -43,7 +44,7 @@ def test_clip_text_encoder_vs_transformers(dev, name, kw):
     if os.path.isdir(d):
         with open(os.path.join(d, "parity.jsonl"), "a") as fh:
             fh.write(json.dumps(dict(case="clip_text_" + name, rel_l2_vs_transformers_fp32=e)) + "\n")
-    assert e < CLIP_BAR, f"{name}: rel-L2 {e}"
+    assert e < CLIP_BARS[name], f"{name}: rel-L2 {e}"
     # causality: changing a later token must not change earlier positions
     ids2 = ids.clone(); ids2[:, 50:] = 5
     out2 = m(ids2.to(dev))[0]

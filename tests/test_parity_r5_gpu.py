@@ -89,6 +89,8 @@ def test_tiled_video_vae_full_width_vs_reference_cli_loop(dev):
     assert s_all < TILED_BARS[0] * 1.5, (s_all, s_unsat)
 
 
-# bars = measured + 10 % (profiles/r05_parity_*.jsonl); until the first GPU measurement they are the quarter-width bars
-T14_BARS = (3.5e-3, 4.5e-3, 5.5e-3)
-TILED_BARS = (4.5e-3, 5.5e-3)
+# bars = measured + 10 % (round 5, run 18, profiles/r05_parity_full_suite_run18.jsonl):
+#   T = 14, 30 steps:  latents 7.7e-4, .images 9.2e-4 over all pixels / 1.20e-3 over the 87 % the reference does not clamp
+#   tiled vae_video, 5 steps: .images 2.32e-3 / 3.08e-3 (the 5-step schedule weighs each UNet error ~6x, like configs[0]); seam strip 2.17e-3
+T14_BARS = (8.5e-4, 1.02e-3, 1.32e-3)
+TILED_BARS = (2.55e-3, 3.4e-3)
