@@ -91,11 +91,14 @@ def predicted_scaling(args, world, value):
     units = n_win * (2 if args.shard_cfg else 1)
     chunks = math.ceil(args.frames / 3)
     # one unit = one window evaluation (or one guidance branch of it); decode chunks cost ~1.37 window units of a B2 window
-    win_flop, chunk_flop = 176.99 * (1.027 / 2 if args.shard_cfg else 1.0), 299.05 / 3      # TFLOP (SURVEY §8d, 8-frame window / 3-frame chunk)
+    # TFLOP of an 8-frame 320x320 window / a 3-frame decode chunk: only their RATIO enters the prediction, and it is the
+    # ratio of the default shape — `unit_costs` on the line says so when another --height / --width runs
+    win_flop, chunk_flop = 176.99 * (1.027 / 2 if args.shard_cfg else 1.0), 299.05 / 3
     def t(n):
         return args.ddim_steps * math.ceil(units / n) * win_flop + math.ceil(chunks / n) * chunk_flop
     base = value if world == 1 else None
     return {"mode": "one clip, units dealt over the ranks (strong scaling)", "units_per_step": units, "decode_chunks": chunks,
+            "unit_costs": "window : chunk FLOP ratio of the default 320x320 shape" + ("" if (args.height, args.width) == (320, 320) else " (another shape runs: approximate)"),
             "speedup_vs_1_gpu": {str(n): t(1) / t(n) for n in ns},
             "frames_per_s": ({str(n): base * t(1) / t(n) * (1.0 if n == 1 else 0.99) for n in ns} if base else None)}
 
@@ -225,6 +228,9 @@ def main():
                     help="residual-stream precision of the UNet (UNetVideoModel.stream_dtype): f16 = every stored tensor fp16, the "
                          "arithmetic of the reference's `.half()` UNet; f32 = fp32 rows, fp32 latents between DDIM steps, fp16 MFMA "
                          "operands.  Default: the engine's default (models_video/unet_video.py DEFAULT_STREAM); named in config.workload")
+    ap.add_argument("--precision", choices=["default", "high"], default=None,
+                    help="UNetVideoModel.precision: 'high' also reads block tails as fp16 hi|lo pairs and keeps the ResNet branch tensor "
+                         "fp32 (1.10e-3 instead of 1.23e-3 on unclamped pixels, +5.7 %% per clip); named in config.workload")
     ap.add_argument("--text-encoder", choices=["clip", "standin"], default="clip",
                     help="clip: ViT-H/14 text tower (random init) on the HIP kernels, run once per distinct prompt pair")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -275,6 +281,8 @@ def main():
         pipe.vae = pipe.vae.half()              # what `pipeline.vae.half()` users get: all-fp16 decoder rows
     if args.unet_stream is not None:
         pipe.unet.stream_dtype = torch.float32 if args.unet_stream == "f32" else torch.float16
+    if args.precision is not None:
+        pipe.unet.precision = args.precision
     unet_f32 = pipe.unet.stream_f32()
     pipe.cfg_shared_input = not args.no_cfg_share
     pipe.shard_windows = args.shard_windows
@@ -298,10 +306,26 @@ def main():
             for name in ("conv2.weight", "conv2.bias"):     # damp the random flow head: few-pixel flows
                 getattr(raft.fix_raft.update_block.flow_head.conv2, name.split(".")[1]).mul_(0.05)
         torch.cuda.synchronize(); t_r = time.perf_counter()
-        flows = list(raft.forward_slicing(clip, iters=20))
+        raft_flows = list(raft.forward_slicing(clip, iters=20))
         torch.cuda.synchronize(); raft_s = time.perf_counter() - t_r
         pipe.propagator = Propagation(4, learnable=False)
         psteps = [s for s in (24, 26, 28) if s < args.ddim_steps]
+        # A random-weight RAFT produces flows that fail the forward-backward check on every pixel (measured, round 4): the
+        # propagation is then the identity and the line would time a no-op.  The flows that ENTER the pipeline are therefore exact
+        # translations in forward_slicing's output contract ((1, T-1, 2, H, W), pixels per frame; backward = -forward): consistent
+        # by construction, so the mask keeps everything but the border the warp leaves.  RAFT itself still runs (and is timed, outside
+        # the timed region like inference_upscale_a_video.py:191); what the propagation changes is measured on a probe tensor.
+        ff = torch.zeros_like(raft_flows[0]); ff[:, :, 0] = 2.0; ff[:, :, 1] = 1.0
+        flows = [ff, -ff]
+        with torch.no_grad():
+            probe = torch.randn(1, 4, args.frames, args.height, args.width, device=dev)
+            moved = pipe.propagator(probe, flows[0], flows[1], interpolation="nearest", mode="fuse", fuse_scale=0.5, alpha1=0.001, alpha2=0.05)
+            prop_changed = float((moved != probe).float().mean().item())
+            raft_moved = pipe.propagator(probe, raft_flows[0], raft_flows[1], interpolation="nearest", mode="fuse", fuse_scale=0.5, alpha1=0.001, alpha2=0.05)
+            raft_changed = float((raft_moved != probe).float().mean().item())
+        del probe, moved, raft_moved
+        if prop_changed <= 0.5:
+            raise SystemExit(f"bench.py --propagation: the flows change only {prop_changed:.3f} of the latent elements (need > 0.5)")
     kw = dict(image=clip, flows_bi=flows, num_inference_steps=args.ddim_steps, guidance_scale=6.0, noise_level=120,
               negative_prompt="blur, worst quality", propagation_steps=psteps)
     prompt = "best quality, extremely detailed"
@@ -454,6 +478,13 @@ def main():
                        "clips_per_step": world * ncl, "frames_per_clip": args.frames},
         }
         res["config"]["predicted_scaling"] = predicted_scaling(args, world, res["value"])
+        res["config"]["overlap_mode"] = getattr(pipe, "last_overlap_mode", "serial")
+        if args.propagation:
+            res["config"]["propagation_changed_fraction"] = prop_changed
+            res["config"]["propagation_flows"] = ("exact translation (2, 1) px / frame in forward_slicing's contract; flows of the random-weight "
+                                                   f"RAFT (computed and timed, {raft_s * 1e3:.0f} ms) change {raft_changed:.3f} of the elements")
+        if args.precision is not None:
+            res["config"]["unet_precision"] = args.precision
         # device memory of the timed region (torch caching allocator, rank 0): peak bytes in live tensors / held by the allocator's
         # pools — side streams (overlap_streams, clips_per_step) own pools of their own
         res["config"]["peak_memory_gb"] = {"allocated": round(peak_alloc / 2 ** 30, 2), "reserved": round(peak_reserved / 2 ** 30, 2)}

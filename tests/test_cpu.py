@@ -979,3 +979,48 @@ def test_publish_acquire_are_noops_without_a_gpu():
     from uav import engine as E
     obj = object()
     assert E.publish(obj) is obj and E.acquire(obj) is obj and not E._PENDING
+
+
+def test_asm_scheduled_conv_kernels_have_no_scratch():
+    """the rotated k-step of conv_gemm256i_kernel<6,*> and the four-wave conv_gemm256w_kernel keep DMA targets and
+    operand fragments live across inline-asm statements; a compiler spill between them would read stale data silently.  The
+    build audit (uav/build.py audit_conv_scratch, run on every build) reads the code-object metadata of the library: no private
+    segment, no spilled VGPR in either kernel family; the accumulators of the four-wave kernel are the full 256-entry AGPR file."""
+    from uav import build
+    build.build(verbose=False)
+    build.audit_conv_scratch()
+    meta = build.kernel_metadata()
+    w4 = {k: v for k, v in meta.items() if "conv_gemm256w_kernel" in k}
+    assert len(w4) >= 4
+    for name, md in w4.items():
+        assert md["agpr_count"] == "256" and md["max_flat_workgroup_size"] == "256", (name, md)
+
+
+def test_magic_division_of_the_four_wave_conv_setup():
+    """conv_gemm.hip conv_magic: n / d == umulhi(n, mul) >> sh for every n < 2^31 (the output-pixel index range the four-wave
+    kernel's setup divides by Ho*Wo, Wo and T).  Python restatement of the host function, checked on the divisors the models use,
+    on random divisors, and on the values around every multiple boundary where a wrong multiplier fails first."""
+    import random
+
+    def magic(d):
+        if d <= 1:
+            return 0, 32
+        s = 0
+        while (1 << s) < d:
+            s += 1
+        return ((1 << (31 + s)) // d + 1) & 0xFFFFFFFFFFFF, s - 1
+
+    def div(n, mul, sh):
+        return n if sh == 32 else ((n * mul) >> 32) >> sh
+
+    rng = random.Random(7)
+    ds = [2, 3, 5, 7, 8, 14, 40, 80, 160, 320, 640, 1280, 40 * 40, 80 * 80, 160 * 160, 320 * 320, 1280 * 1280, 2560 * 2560, 65535, 65535 * 65535 // 3]
+    ds += [rng.randrange(2, 1 << 31) for _ in range(200)] + [(1 << k) + e for k in range(1, 31) for e in (-1, 0, 1) if (1 << k) + e >= 2]
+    for d in ds:
+        mul, sh = magic(d)
+        assert mul < (1 << 32), d
+        ns = [0, 1, d - 1, d, d + 1, (1 << 31) - 1, ((1 << 31) - 1) // d * d, ((1 << 31) - 1) // d * d - 1]
+        ns += [rng.randrange(0, 1 << 31) for _ in range(50)] + [q * d + e for q in (rng.randrange(0, (1 << 31) // d + 1) for _ in range(20)) for e in (-1, 0)]
+        for n in ns:
+            if 0 <= n < (1 << 31):
+                assert div(n, mul, sh) == n // d, (n, d)

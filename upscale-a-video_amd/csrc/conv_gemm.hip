@@ -2100,6 +2100,10 @@ const ConvEnv& conv_env() {
     // Environment switches (development A/B only) are read once through a thread-safe magic static.
     static const ConvEnv env = [] {
         auto geti = [](const char* k, int d) { const char* e = getenv(k); return e ? atoi(e) : d; };
+        {   // only the loops that still have instances: an unknown value used to fall through to the round-1 kernel silently
+            const int v = geti("UAV_CONV_DMAV", 6);
+            if (v != 1 && v != 6) { fprintf(stderr, "[uav] UAV_CONV_DMAV=%d has no kernel instance (1: round 2-3 loop, 6: rotated k-step); using 6\n", v); setenv("UAV_CONV_DMAV", "6", 1); }
+        }
         return ConvEnv{geti("UAV_CONV_KORDER", 1), geti("UAV_CONV_TILE_ORDER", 1), geti("UAV_CONV_TILE", 0),
                        geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0), geti("UAV_CONV_DMAV", 6),       // 6: rotated k-step (round 4 default); 1: round 2-3 loop
                        geti("UAV_CONV_SK", 0), geti("UAV_CONV_SK_MAXK", 1024),                                // short-K kernel (round 5 candidate, measured neutral: off) for 1x1 launches with K <= SK_MAXK

@@ -94,6 +94,7 @@ class VideoUpscalePipeline(ConfigMixin):
         self.overlap_streams = int(os.environ.get("UAV_OVERLAP_STREAMS", "2"))
         self.overlap_split_cfg = os.environ.get("UAV_OVERLAP_SPLIT_CFG", "0") == "1"
         self.overlap_min_free_fraction = 0.35        # serial fallback below this share of free device memory
+        self.last_overlap_mode = "serial"            # what the last call's window / chunk loop ran as (bench.py reports it)
         self.latents_trace = None          # test hook: set to a list to collect the latents after every DDIM step
         self.cache_prompt_embeds = True
         self._prompt_cache = {}
@@ -222,11 +223,16 @@ class VideoUpscalePipeline(ConfigMixin):
             return None
         try:
             free, total = torch.cuda.mem_get_info(device)
+            # blocks the caching allocator holds but does not use (incl. the side-stream pools of an earlier call) are free for
+            # this purpose: counting them as used made the mode depend on call order
+            free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)
         except (RuntimeError, AssertionError):       # no HIP runtime (host-logic tests with stand-in streams): nothing to gate on
             free, total = 1, 1
         if free < self.overlap_min_free_fraction * total:
+            self.last_overlap_mode = "serial (memory gate: %.0f %% of the device free)" % (100.0 * free / max(total, 1))
             return None
         if n_windows > 1 or (self.overlap_split_cfg and do_cfg):
+            self.last_overlap_mode = "%d streams" % self.overlap_streams
             return streams.stream_set(device, self.overlap_streams)
         return None
 

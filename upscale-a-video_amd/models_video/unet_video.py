@@ -182,6 +182,13 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
         # (f32 | f16), see DESIGN.md §4 for the measured parity / cost of both.
         self.stream_dtype = None
         self.__dict__["_env_stream"] = os.environ.get("UAV_UNET_STREAM", DEFAULT_STREAM)      # read once, at construction
+        # precision = "high" (attribute, `UAV_UNET_PRECISION=high`, bench.py --precision high): the two remaining fp16 roundings of
+        # the fp32 stream that are cheap to lift — block tails read by their 1x1 consumer as an fp16 hi | lo pair (engine.TAIL_HILO)
+        # and the ResNet branch tensor between conv1 and norm2 kept in fp32 (engine.BRANCH_F32).  Measured at the headline shape
+        # (round 4, profiles/r04_parity_precision_knobs_at_headline_shape_run3.jsonl): latents 8.2e-4 -> 7.1e-4, `.images` 9.5e-4 ->
+        # 8.5e-4 over all pixels / 1.23e-3 -> 1.10e-3 over the pixels the reference does not clamp, for +5.7 % per clip.
+        # "default": both off.  The switches live in uav.engine and are set for the duration of forward().
+        self.precision = os.environ.get("UAV_UNET_PRECISION", "default")
 
     # ------------------------------------------------------------------------------------------
     def _embedding(self, timestep, class_labels, bsz, dev):
@@ -239,6 +246,16 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
             raise NotImplementedError("attention_mask is never passed by the pipeline")
         if sample.shape[1] + low_res.shape[1] != self.config.in_channels:
             raise ValueError(f"expected {self.config.in_channels} input channels, got {sample.shape[1]}+{low_res.shape[1]}")
+        if self.precision not in ("default", "high"):
+            raise ValueError(f"UNetVideoModel.precision must be 'default' or 'high', got {self.precision!r}")
+        if self.precision == "high" and not (E.TAIL_HILO and E.BRANCH_F32):
+            saved = (E.TAIL_HILO, E.BRANCH_F32)
+            E.TAIL_HILO, E.BRANCH_F32 = True, True
+            try:
+                return self.forward(sample, timestep, low_res, encoder_hidden_states, class_labels, attention_mask, return_dict,
+                                    cfg_shared_input)
+            finally:
+                E.TAIL_HILO, E.BRANCH_F32 = saved
         dev = sample.device
         s32 = self.stream_f32()
         if self.config.center_input_sample:

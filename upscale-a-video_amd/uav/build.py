@@ -88,6 +88,7 @@ def _build_locked(objdir, verbose):
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     audit_accumulator_file()
+    audit_conv_scratch()
     with open(STAMP, "w") as fh:
         fh.write(_digest())
     if verbose:
@@ -132,6 +133,76 @@ def audit_accumulator_file():
     if bad:
         raise RuntimeError("audit: hipcc uses the accumulator file inside attn512w_kernel, which names a[0:255] from inline asm:\n  "
                            + "\n  ".join(bad[:8]))
+
+
+def kernel_metadata(lib=None):
+    """{kernel symbol: {metadata field: value}} of every gfx950 code object bundled in the library, read from the AMDGPU
+    metadata note (llvm-readelf --notes) of each offload bundle entry."""
+    import re
+    import struct
+    import tempfile
+    readelf = os.path.join(os.path.dirname(os.path.dirname(HIPCC)), "lib", "llvm", "bin", "llvm-readelf")
+    with open(lib or LIB, "rb") as fh:
+        blob = fh.read()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    out = {}
+    pos = 0
+    while True:
+        i = blob.find(magic, pos)
+        if i < 0:
+            break
+        pos = i + 1
+        (entries,) = struct.unpack_from("<Q", blob, i + len(magic))
+        if entries > 16:
+            continue
+        o = i + len(magic) + 8
+        for _ in range(entries):
+            off, size, tlen = struct.unpack_from("<QQQ", blob, o)
+            o += 24
+            triple = blob[o:o + tlen].decode(errors="replace")
+            o += tlen
+            if "gfx950" not in triple or size == 0:
+                continue
+            with tempfile.NamedTemporaryFile(suffix=".elf") as tf:
+                tf.write(blob[i + off:i + off + size]); tf.flush()
+                r = subprocess.run([readelf, "--notes", tf.name], capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"llvm-readelf failed on a bundled code object:\n{r.stderr}")
+            cur = None
+            for ln in r.stdout.splitlines():
+                m = re.match(r"\s+(- )?\.(\w+):\s+(\S+)", ln)
+                if not m:
+                    continue
+                if m.group(1) and ln.startswith("  - "):      # a new entry of amdhsa.kernels (args entries are indented deeper)
+                    cur = {}
+                if cur is None:
+                    continue
+                cur[m.group(2)] = m.group(3)
+                if m.group(2) == "name":
+                    out[m.group(3)] = cur
+    return out
+
+
+def audit_conv_scratch():
+    """The rotated k-step of conv_gemm256i_kernel<6,*,0> and the one-statement k-step of conv_gemm256w_kernel carry LDS-DMA
+    targets, staged constants and fragment registers across inline-asm statements with hand-counted vmcnt/lgkmcnt waits
+    (csrc/conv_gemm.hip).  A compiler spill of one of those registers to scratch between the statements would read stale
+    data without any diagnostic, so the build fails if either kernel family has a private segment or a spilled VGPR
+    (SGPR spills go to VGPR lanes and are harmless)."""
+    meta = kernel_metadata()
+    seen = 0
+    bad = []
+    for name, md in meta.items():
+        if "conv_gemm256w_kernel" in name or "conv_gemm256i_kernelILi6E" in name:
+            if name.endswith("ELi1EEEvNS_8ConvArgsE") and "conv_gemm256i_kernel" in name:
+                continue                                      # the traced 8-wave instance (s_memtime stores) is a tool, not a product path
+            seen += 1
+            if int(md.get("private_segment_fixed_size", "1")) != 0 or int(md.get("vgpr_spill_count", "1")) != 0:
+                bad.append(f"{name}: scratch {md.get('private_segment_fixed_size')} B, {md.get('vgpr_spill_count')} spilled VGPRs")
+    if seen < 8:
+        raise RuntimeError(f"audit: only {seen} conv_gemm256i<6,*>/conv_gemm256w instances found in {LIB}")
+    if bad:
+        raise RuntimeError("audit: the asm-scheduled conv kernels must not spill:\n  " + "\n  ".join(bad))
 
 
 if __name__ == "__main__":

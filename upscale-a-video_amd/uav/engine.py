@@ -98,9 +98,12 @@ def publish(obj=None):
         return obj
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream())
-    if len(_PENDING) > 256:                          # builds that nobody asked for again: retire the completed ones
-        for k in [k for k, (_, e) in list(_PENDING.items()) if e.query()]:
-            _PENDING.pop(k, None)
+    # retire the builds whose event has completed on EVERY publish (the dict holds a strong reference to the object — an evicted
+    # text-K/V tuple or class-label index would otherwise stay pinned in device memory until it happened to be acquired again; the
+    # dict is a handful of entries in the steady state).  Host threads of the two-clip mode share the dict: every
+    # operation here is a single dict call under the GIL, and a doubly-popped key is harmless (pop(k, None)).
+    for k in [k for k, (_, e) in list(_PENDING.items()) if e.query()]:
+        _PENDING.pop(k, None)
     _PENDING[id(obj)] = (obj, ev)
     return obj
 
