@@ -12,6 +12,9 @@
 #   prof            rocprofv3 --kernel-trace --stats over bench.py --steps 2
 #   traffic         tools/pmc_traffic.sh (conv HBM bytes per launch, own --pmc passes)
 #   digest          tools/conv_digest.py
+#   bench1_head     bench1 on tools/ab/libuav_hip_head.so (a build of the library from HEAD's sources, same-box A/B of uncommitted kernel work)
+#   trace0 / trace_small   phase stamps of the four-wave kernel on the K = 512 linears (full grid / 64..3200-tile grids)
+#   bench1_lnfold / parity_lnfold   the LayerNorm-fold switch (UAV_LN_FOLD=1): clip time and the headline parity test
 # Environment: any UAV_* variable is passed through to every step.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; shift
@@ -27,6 +30,11 @@ for step in "$@"; do
     shortk)   timeout 400 python $R/tools/bench_shortk.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_shortk.log ;;
     shortk2)  UAV_CONV_SK=2 timeout 400 python $R/tools/bench_shortk.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_shortk_compiler_kstep.log ;;
     trace)    UAV_CONV_W4_TRACE=1 timeout 300 python $R/tools/trace_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_trace.log ;;
+    trace_small) UAV_TRACE_SMALL=1 UAV_CONV_TILE=256 UAV_CONV_W4_MINK=0 UAV_CONV_W4_TRACE=1 timeout 300 python $R/tools/trace_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_trace_small_grids.log ;;
+    bench1_lnfold) (cd $R && UAV_LN_FOLD=1 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_lnfold.json) ;;
+    parity_lnfold) (cd $R && rm -f gpurun_out/parity.jsonl; UAV_LN_FOLD=1 timeout 900 python -m pytest tests/test_parity_r4_gpu.py -m gpu -q -k "headline" 2>&1 | tail -15 | tee $O/${TAG}_parity_lnfold.log; mv gpurun_out/parity.jsonl $O/${TAG}_parity_lnfold.jsonl 2> /dev/null) ;;
+    bench1_head) (cd $R && UAV_HIP_LIB=$R/tools/ab/libuav_hip_head.so timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_head_lib.json) ;;
+    trace0)   UAV_CONV_W4_MINK=0 UAV_CONV_W4_TRACE=1 timeout 300 python $R/tools/trace_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_trace.log ;;
     w4ab)     timeout 500 python $R/tools/bench_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_vs_8wave.log ;;
     epi)      timeout 400 python $R/tools/bench_epilogue.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_epilogue.log ;;
     epi_w40)  UAV_CONV_W4=0 timeout 400 python $R/tools/bench_epilogue.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_epilogue_8wave.log ;;
@@ -64,7 +72,9 @@ PY
     bench1_sk0) (cd $R && UAV_CONV_SK=0 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2> /dev/null | tee $O/${TAG}_bench1_sk0.json) ;;
     shape)    (cd $R && UAV_BENCH_DETAIL=1 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> $O/${TAG}_per_shape.txt > $O/${TAG}_bench_detail.json; grep -v amdgpu.ids $O/${TAG}_per_shape.txt | head -70) ;;
     prof)     rm -rf /tmp/prof; (cd $R && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof -o b -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> /dev/null)
-              f=$(find /tmp/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_rocprofv3_kernel_stats.csv && head -25 "$f" ;;
+              # ROCm 7.2 rocprofv3 writes a rocpd database, not a csv: its `top_kernels` view IS the --stats kernel summary
+              db=$(find /tmp/prof -name "*.db" | head -1)
+              [ -n "$db" ] && python $R/tools/rocpd_top_kernels.py "$db" $O/${TAG}_rocprofv3_kernel_stats.csv "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (MI355X; rocpd view top_kernels; 1 warm-up + 2 timed clips + the two-clip throughput leg + 1 instrumented clip)" && head -14 $O/${TAG}_rocprofv3_kernel_stats.csv | cut -c1-200 ;;
     traffic)  (cd $R && bash tools/pmc_traffic.sh 2>&1 | tail -5); cp $O/pmc_conv_traffic.json $O/${TAG}_pmc_conv_traffic.json 2> /dev/null ;;
     digest)   timeout 200 python $R/tools/conv_digest.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_digest.log ;;
     *)        echo "unknown step $step" ;;

@@ -29,6 +29,17 @@ def run(name, n_img, t_len, h, w, cin, cout, k3, res=None, out_f32=False, geglu=
     torch.cuda.synchronize()
 
 
+if os.environ.get("UAV_TRACE_SMALL"):
+    # Is the epilogue of the K = 512 linears bound by the CU (vector-memory transactions: a lane owns a ROW, so every 16-B piece of a
+    # wave's load / store is its own cache line) or by the chip (all 256 CUs in their epilogues at once)?  The same tile on 64 / 128 /
+    # 256 / 3200 workgroups (UAV_CONV_TILE=256 forces the big tile on the small grids): per-tile epilogue ticks that do not fall on
+    # the small grids are CU-bound.
+    for m in (8192, 16384, 32768, 409600):
+        run(f"lin 512->512 M={m} ->f16", 1, 1, m, 1, 512, 512, (1, 1, 1))
+        run(f"lin 512->512 M={m} res32->f32", 1, 1, m, 1, 512, 512, (1, 1, 1), res="f32", out_f32=True)
+        run(f"lin 512->512 M={m} ->f32", 1, 1, m, 1, 512, 512, (1, 1, 1), out_f32=True)
+    sys.exit(0)
+
 run("lin 512->512 M=409600 ->f16", 1, 1, 409600, 1, 512, 512, (1, 1, 1))
 run("lin 512->512 M=409600 res32->f32", 1, 1, 409600, 1, 512, 512, (1, 1, 1), res="f32", out_f32=True)
 run("lin 512->4096 geglu M=409600", 1, 1, 409600, 1, 512, 4096, (1, 1, 1), geglu=True)

@@ -455,6 +455,175 @@ UAV_DEVINL void conv_epilogue_f32_fast(const ConvArgs& p, float16_t (&acc)[NI][M
     if constexpr (GN) conv_gn_store<NI, MI, GNM>(p, gst, gsq, mw0, nw0, l32, hi32);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row-coalesced fp32 epilogue of the four-wave kernel (round 5, second session).  In the accumulator layout a lane owns an
+// output ROW: the 64 lanes of one global_load / store_dwordx4 of conv_epilogue_f32_fast touch 32 rows x 32 B — 32 cache lines, a
+// quarter of each — and the residual is fetched ONE 32-column block ahead of its use.  The phase trace of the K = 512 linears
+// (profiles/r05_w4_phase_trace_small_grids_run22.log) shows what that costs: an epilogue with an fp32 residual and an fp32
+// result takes 35 k cycles per 256 x 256 tile even when three quarters of the chip are idle (54 k with the whole chip in it),
+// 2.3x the tile's main loop: four serialized HBM round trips per 64-row half (4.4 k cycles each on an idle chip, 6.8 k on a
+// busy one) plus 2.8 k cycles of store issue per block that do not depend on the chip's load at all — the CU's vector-memory
+// path takes ~3 cycles per lane-line, whatever the line's fill.
+// Here the wave first DUMPS its 64 x 128 half tile into its own 32-KiB quarter of the (now idle) stage buffers — rows of 512 B,
+// the 16-B quad q of row r at physical quad q ^ (r & 7): conflict-free for the b128 writes of 8 consecutive rows (lane = row)
+// and for the b128 reads of 8 lanes along a row — and the accumulators are DEAD from there on: the epilogue proper runs on a
+// nearly empty register file.  It reads the tile back TRANSPOSED — lane L holds row 8k + (L >> 3), columns 4 (L & 7) .. +3 of
+// each 32-column block, k = 0..7 — so a wave-wide load / store is 8 rows x 128 contiguous bytes = 8 whole cache lines instead of
+// 32 quarter lines, and ALL residual loads of the half tile (32 loads, 128 VGPRs) go out before the first of them is needed: one
+// round trip instead of four.  Bias, time-embedding row and residual are added per element in the same order as before
+// (((acc + bias) + rowbias) + residual) * out_scale: the stored values are BIT-IDENTICAL to conv_epilogue_f32_fast.  GroupNorm
+// partials are sums of the same fp32 values in another order (rows first, then the quads of a group: xor butterfly over the
+// lanes) — deterministic, equal up to fp32 summation order.
+// No workgroup barrier inside: LDS operations of one wave execute in order and the buffer is the wave's own; the KERNEL puts one
+// barrier in front of the first dump (other waves may still be reading the stage buffers).
+constexpr int CO_ROW = 512;                   // bytes per dumped row (128 fp32)
+constexpr int CO_BYTES = 64 * CO_ROW;         // per wave: 32 KiB
+typedef __attribute__((address_space(3))) float4_t* lds_f4wptr_t;
+
+// ORD: loop nest of the 32 writes — quad-outermost (0) or block-outermost (1).  The same 32 instructions either way; which one hipcc
+// allocates without a spill differs per kernel instance (the k-loop of this kernel sits at exactly 256 VGPRs and its accumulator
+// file is full: measured, the statistics instance of 16-channel groups needs 1, the others 0 — the build audit checks all of them;
+// issuing the residual loads in front of the dump, which would hide their round trip under it, spills in three of the four).
+template <int ORD>
+UAV_DEVINL void conv_co_dump(float16_t (&acc)[4][2], unsigned lbuf, int l32, int hi32) {
+    const unsigned row = lbuf + l32 * CO_ROW;
+    const int sw = l32 & 7;
+    auto put = [&](int ni, int mi, int g, unsigned a) {
+        float4_t v = {acc[ni][mi][4 * g], acc[ni][mi][4 * g + 1], acc[ni][mi][4 * g + 2], acc[ni][mi][4 * g + 3]};
+        // the data operand in VGPRs: left to itself hipcc feeds ds_write_b128 from the accumulator file directly and then
+        // spills the accumulators' own register class (there is not one free AGPR in this kernel)
+        asm volatile("" : "+v"(v));
+        *(lds_f4wptr_t)(size_t)(a + mi * 32 * CO_ROW + ni * 128) = v;
+    };
+    if constexpr (ORD == 0) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const unsigned a = row + (((2 * g + hi32) ^ sw) << 4);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) put(ni, mi, g, a);
+        }
+    } else {
+        unsigned aq[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) aq[g] = row + (((2 * g + hi32) ^ sw) << 4);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) put(ni, mi, g, aq[g]);
+    }
+    asm volatile("" ::: "memory");
+}
+
+// Wave-uniform: does the wave tile at (mw0, nw0) take an fp32-result fast path?  Mirrors the tests of conv_epilogue exactly
+// (statistics instances: the host only launches them when every wave tile qualifies, conv_gn_cpg_log2).  0: no; 1: plain;
+// 2: fp32 residual; 3: time-embedding row (one batch entry per wave tile, no residual).
+template <int GNK>
+UAV_DEVINL int conv_co_kind(const ConvArgs& p, long long mw0, int nw0) {
+    if (!(p.flags & UAV_CONV_OUT_F32)) return 0;
+    if constexpr (GNK != 0) {
+        if (mw0 >= p.M || nw0 >= p.n) return 0;              // (conv_epilogue returns at once for such a tile)
+        return p.rowbias ? 3 : p.residual ? 2 : 1;
+    } else {
+        const bool rf32 = p.flags & UAV_CONV_RES_F32;
+        if ((p.flags & (UAV_CONV_GELU | UAV_CONV_QUICK_GELU | UAV_CONV_GEGLU)) || !p.bias || mw0 + 64 > p.M || nw0 + 128 > p.n ||
+            (p.out_stride & 3) || (p.residual && (!rf32 || (p.res_stride & 3))))
+            return 0;
+        if (!p.rowbias) return p.residual ? 2 : 1;
+        const int b0 = (int)(mw0 / p.rows_per_batch), b1 = (int)((mw0 + 63) / p.rows_per_batch);
+        return (b0 == b1 && !p.residual) ? 3 : 0;
+    }
+}
+
+template <bool RES, int GNM, bool RB>
+UAV_DEVINL void conv_epilogue_f32_lds(const ConvArgs& p, long long mw0, int nw0, unsigned lb, unsigned lr, unsigned lbuf) {
+    constexpr int NI = 4, NK = 8;
+    constexpr bool GN = GNM != 0;
+    const float osc = p.out_scale;
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const int tr = lane >> 3, tq = lane & 7;                 // row 8k + tr, columns 4 tq .. 4 tq + 3 of every 32-column block
+    const unsigned rbase = lbuf + tr * CO_ROW + ((tq ^ tr) << 4);     // + k * 8 rows + ni * 128 B  ((8k + tr) & 7 == tr)
+    float4_t R[RES ? NI : 1][NK];
+    if (RES) {
+        const float* rrow0 = (const float*)p.residual + (mw0 + tr) * p.res_stride + nw0 + 4 * tq;
+        const long long rstep = 8ll * p.res_stride;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int k = 0; k < NK; ++k) R[RES ? ni : 0][k] = *(const float4_t*)(rrow0 + k * rstep + ni * 32);
+    }
+    int orow[NK];                                            // output row of this lane's k-th row (strided for a sub-pixel phase)
+#pragma unroll
+    for (int k = 0; k < NK; ++k) orow[k] = (int)out_row(p, mw0 + 8 * k + tr);
+    float* const obase = (float*)p.out + nw0 + 4 * tq;
+    float s1[GN ? NI : 1], s2[GN ? NI : 1];
+    if (GN) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) { s1[ni] = 0.f; s2[ni] = 0.f; }
+    }
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+        const float4_t bq = lds_f4(lb + (ni * 32 + 4 * tq) * 4);
+        float4_t rq = {0.f, 0.f, 0.f, 0.f};
+        if (RB) rq = lds_f4(lr + (ni * 32 + 4 * tq) * 4);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const float4_t t = lds_f4(rbase + k * 8 * CO_ROW + ni * 128);
+            float4_t o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = t[j] + bq[j];
+                if (RB) v += rq[j];
+                if (RES) v += R[RES ? ni : 0][k][j];
+                o[j] = v * osc;
+            }
+            *(float4_t*)(obase + (long long)orow[k] * p.out_stride + ni * 32) = o;
+            if (GN) {
+                s1[GN ? ni : 0] += (o[0] + o[1]) + (o[2] + o[3]);
+                s2[GN ? ni : 0] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
+            }
+        }
+    }
+    asm volatile("" ::: "memory");                           // (the next dump of this wave overwrites the buffer: keep the reads above it)
+    if constexpr (GN) {
+        // rows: lanes that share tq (xor 8, 16, 32); then the quads of a group of 2^cl channels (xor 1, 2, 4); groups wider than a
+        // 32-column block are sums of blocks.  Afterwards every lane holds the totals of its class.
+        const int cl = p.gn_cpg_log2;                        // GNM 1: 2 | 3, GNM 2: 4, GNM 3: 5 | 6 | 7 (wave-uniform)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            float a = s1[ni], b = s2[ni];
+            a += __shfl_xor(a, 8, 64); b += __shfl_xor(b, 8, 64);
+            a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);
+            a += __shfl_xor(a, 32, 64); b += __shfl_xor(b, 32, 64);
+            if (GNM >= 2 || cl >= 3) { a += __shfl_xor(a, 1, 64); b += __shfl_xor(b, 1, 64); }
+            if (GNM >= 2) { a += __shfl_xor(a, 2, 64); b += __shfl_xor(b, 2, 64); }
+            if (GNM == 3) { a += __shfl_xor(a, 4, 64); b += __shfl_xor(b, 4, 64); }
+            s1[ni] = a; s2[ni] = b;
+        }
+        float vs, vq; int grp; bool writer;
+        if (GNM == 3 && cl == 7) {
+            vs = (s1[0] + s1[1]) + (s1[2] + s1[3]); vq = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+            grp = nw0 >> 7; writer = lane == 0;
+        } else if (GNM == 3 && cl == 6) {
+            vs = tr == 0 ? s1[0] + s1[1] : s1[2] + s1[3]; vq = tr == 0 ? s2[0] + s2[1] : s2[2] + s2[3];
+            grp = (nw0 >> 6) + tr; writer = tr < 2 && tq == 0;
+        } else {                                             // lane (tr = block, tq) writes the group its quad opens
+            vs = tr == 0 ? s1[0] : tr == 1 ? s1[1] : tr == 2 ? s1[2] : s1[3];
+            vq = tr == 0 ? s2[0] : tr == 1 ? s2[1] : tr == 2 ? s2[2] : s2[3];
+            const int qpg = 1 << (cl - 2);                   // quads per group: 1, 2, 4, 8
+            grp = (nw0 + tr * 32 + 4 * tq) >> cl; writer = tr < NI && (tq & (qpg - 1)) == 0;
+        }
+        if (writer && grp < p.gn_groups) {
+            float* ws_s = p.gn_ws + (long long)grp * p.gn_chunks + gn_chunk_index(p, mw0, 64);
+            ws_s[0] = vs;
+            ws_s[(long long)p.gn_groups * p.gn_chunks] = vq;
+        }
+    }
+}
+
 // GEGLU fast path (same preconditions; no residual / rowbias by contract): value/gate tile pairs (2b, 2b+1).
 template <int NI, int MI, bool BIAS, bool ST = false, bool LNC = false>
 UAV_DEVINL void conv_epilogue_geglu_fast(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32,
@@ -514,7 +683,9 @@ UAV_DEVINL void conv_epilogue_geglu_fast(const ConvArgs& p, float16_t (&acc)[NI]
 // LNF: the LayerNorm-fold instances of the kernel (1: producer, 2: consumer) — like the statistics instances they are kernels
 // of their own so that their registers do not weigh on the plain kernel's allocation; the host launches them only when every
 // wave tile qualifies (conv_ln_ok).
-template <int NI, int MI, int GNK = 0, bool ST = false, int LNF = 0>
+// NF32: the caller (four-wave kernel) has already taken every wave tile that qualifies for an fp32-result fast path
+// (conv_w4_epilogue / conv_co_kind, the same tests): those paths are not instantiated here.
+template <int NI, int MI, int GNK = 0, bool ST = false, int LNF = 0, bool NF32 = false>
 UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long long mw0, int nw0, int l32, int hi32,
                               unsigned lb = 0, unsigned lr = 0) {
     if constexpr (LNF == 1) {
@@ -532,7 +703,9 @@ UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long 
     if constexpr (GNK != 0) {
         if (mw0 >= p.M || nw0 >= p.n) return;                   // wave tile outside the output: nothing to store or count
         const float* rbrow = p.rowbias ? p.rowbias + (long long)((int)(mw0 / p.rows_per_batch)) * p.rowbias_stride : nullptr;
-        if (p.flags & UAV_CONV_OUT_F32) {
+        if constexpr (NF32) {
+            if (p.flags & UAV_CONV_OUT_F32) return;     // not reached: conv_co_kind != 0 for every such tile of a statistics instance
+        } else if (p.flags & UAV_CONV_OUT_F32) {
             if (rbrow) conv_epilogue_f32_fast<NI, MI, false, GNK, true, ST>(p, acc, mw0, nw0, l32, hi32, rbrow, lb, lr);   // conv1: no residual
             else if (p.residual) conv_epilogue_f32_fast<NI, MI, true, GNK, false, ST>(p, acc, mw0, nw0, l32, hi32, nullptr, lb, lr);
             else conv_epilogue_f32_fast<NI, MI, false, GNK, false, ST>(p, acc, mw0, nw0, l32, hi32, nullptr, lb, lr);
@@ -560,7 +733,7 @@ UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long 
     const bool of32 = p.flags & UAV_CONV_OUT_F32;
     const bool rf32 = p.flags & UAV_CONV_RES_F32;
     const unsigned actf = p.flags & (UAV_CONV_GELU | UAV_CONV_QUICK_GELU);      // activation: generic path only (tiny GEMMs)
-    if (of32 && !actf && !geglu && p.bias && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n && !(p.out_stride & 3) &&
+    if (!NF32 && of32 && !actf && !geglu && p.bias && mw0 + MI * 32 <= p.M && nw0 + NI * 32 <= p.n && !(p.out_stride & 3) &&
         (!p.residual || (rf32 && !(p.res_stride & 3)))) {
         if (!p.rowbias) {
             if (p.residual) conv_epilogue_f32_fast<NI, MI, true, 0, false, ST>(p, acc, mw0, nw0, l32, hi32, nullptr, lb, lr);
@@ -746,6 +919,18 @@ UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long 
             }
         }
     }
+}
+
+// One 64 x 128 half tile of the four-wave kernel: through LDS when it takes an fp32-result fast path, else the shared epilogue.
+template <int GNK>
+UAV_DEVINL void conv_w4_epilogue(const ConvArgs& p, float16_t (&acc)[4][2], long long mw0, int nw0, int l32, int hi32,
+                                 unsigned lb, unsigned lr, unsigned lbuf) {
+    const int kind = conv_co_kind<GNK>(p, mw0, nw0);
+    if (kind == 0) { conv_epilogue<4, 2, GNK, true, 0, true>(p, acc, mw0, nw0, l32, hi32, lb, lr); return; }
+    conv_co_dump<GNK == 2 ? 1 : 0>(acc, lbuf, l32, hi32);
+    if (kind == 2) conv_epilogue_f32_lds<true, GNK, false>(p, mw0, nw0, lb, lr, lbuf);
+    else if (kind == 3) conv_epilogue_f32_lds<false, GNK, true>(p, mw0, nw0, lb, lr, lbuf);
+    else conv_epilogue_f32_lds<false, GNK, false>(p, mw0, nw0, lb, lr, lbuf);
 }
 
 template <int SMALL>
@@ -1897,11 +2082,14 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
     asm volatile("s_nop 15\ns_nop 15" ::: "memory");
     if (TR) ts[3] = __builtin_amdgcn_s_memtime();
     const unsigned ldsepi = ldsb + 2 * LSTAGE;
-    conv_epilogue<4, 2, GNK, true, 0>(p, accA, m0 + wm * 128, n0 + wn * 128, l32, hi32, ldsepi + wn * 512,
-                                      ldsepi + 1024 + (2 * wm) * 1024 + wn * 512);
+    // row-coalesced fp32 epilogues dump the half tile into this wave's quarter of the stage buffers: every wave's fragment reads must be done
+    __builtin_amdgcn_s_barrier();
+    const unsigned lbuf = ldsb + wave * CO_BYTES;
+    conv_w4_epilogue<GNK>(p, accA, m0 + wm * 128, n0 + wn * 128, l32, hi32, ldsepi + wn * 512,
+                          ldsepi + 1024 + (2 * wm) * 1024 + wn * 512, lbuf);
     if (TR) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[4] = __builtin_amdgcn_s_memtime(); }
-    conv_epilogue<4, 2, GNK, true, 0>(p, accB, m0 + wm * 128 + 64, n0 + wn * 128, l32, hi32, ldsepi + wn * 512,
-                                      ldsepi + 1024 + (2 * wm + 1) * 1024 + wn * 512);
+    conv_w4_epilogue<GNK>(p, accB, m0 + wm * 128 + 64, n0 + wn * 128, l32, hi32, ldsepi + wn * 512,
+                          ldsepi + 1024 + (2 * wm + 1) * 1024 + wn * 512, lbuf);
     if (TR) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         ts[5] = __builtin_amdgcn_s_memtime();
@@ -2090,7 +2278,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_sk_kernel(ConvArgs p) {
 #ifdef UAV_DEV_W4_ONLY          // development: compile conv_gemm256w_kernel alone (seconds instead of minutes)
 extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     ConvArgs a = {};
-    hipLaunchKernelGGL(conv_gemm256w_kernel<0>, dim3(1), dim3(256), 2 * LSTAGE + LEPI_BYTES, (hipStream_t)stream, a);
+#ifndef UAV_DEV_W4_GNK
+#define UAV_DEV_W4_GNK 0        // -DUAV_DEV_W4_GNK=1|2|3: the statistics-reducing instances
+#endif
+    hipLaunchKernelGGL(conv_gemm256w_kernel<UAV_DEV_W4_GNK>, dim3(1), dim3(256), 2 * LSTAGE + LEPI_BYTES, (hipStream_t)stream, a);
     return q ? 0 : 1;
 }
 #else
