@@ -98,7 +98,7 @@ def predicted_scaling(args, world, value):
         return args.ddim_steps * math.ceil(units / n) * win_flop + math.ceil(chunks / n) * chunk_flop
     base = value if world == 1 else None
     return {"mode": "one clip, units dealt over the ranks (strong scaling)", "units_per_step": units, "decode_chunks": chunks,
-            "unit_costs": "window : chunk FLOP ratio of the default 320x320 shape" + ("" if (args.height, args.width) == (320, 320) else " (another shape runs: approximate)"),
+            "unit_costs": "window : chunk FLOP ratio of the default 320x320 shape" + ("" if (getattr(args, "height", 320), getattr(args, "width", 320)) == (320, 320) else " (another shape runs: approximate)"),
             "speedup_vs_1_gpu": {str(n): t(1) / t(n) for n in ns},
             "frames_per_s": ({str(n): base * t(1) / t(n) * (1.0 if n == 1 else 0.99) for n in ns} if base else None)}
 

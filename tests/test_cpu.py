@@ -965,9 +965,12 @@ def test_bench_predicted_scaling_on_the_line():
     a = types.SimpleNamespace(shard_windows=False, shard_cfg=False, frames=8, ddim_steps=30)
     p = bench.predicted_scaling(a, 1, 1.0)
     assert p["frames_per_s"]["1"] == 1.0 and abs(p["frames_per_s"]["8"] - 8 * 0.97) < 1e-9
-    a = types.SimpleNamespace(shard_windows=True, shard_cfg=False, frames=32, ddim_steps=30)
+    a = types.SimpleNamespace(shard_windows=True, shard_cfg=False, frames=32, ddim_steps=30, height=320, width=320)
     p = bench.predicted_scaling(a, 1, 0.7)
-    assert p["units_per_step"] == 5 and p["decode_chunks"] == 11
+    assert p["units_per_step"] == 5 and p["decode_chunks"] == 11 and "approximate" not in p["unit_costs"]
+    a.height = 256
+    assert "approximate" in bench.predicted_scaling(a, 1, 0.7)["unit_costs"]      # the unit costs are those of the default shape
+    a.height = 320
     assert 1.6 < p["speedup_vs_1_gpu"]["2"] < 1.7 and 2.4 < p["speedup_vs_1_gpu"]["4"] < 2.6 and 4.9 < p["speedup_vs_1_gpu"]["8"] < 5.1
     a.shard_cfg = True
     p = bench.predicted_scaling(a, 1, 0.7)

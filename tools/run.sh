@@ -33,6 +33,12 @@ for step in "$@"; do
     trace_small) UAV_TRACE_SMALL=1 UAV_CONV_TILE=256 UAV_CONV_W4_MINK=0 UAV_CONV_W4_TRACE=1 timeout 300 python $R/tools/trace_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_trace_small_grids.log ;;
     bench1_lnfold) (cd $R && UAV_LN_FOLD=1 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_lnfold.json) ;;
     parity_lnfold) (cd $R && rm -f gpurun_out/parity.jsonl; UAV_LN_FOLD=1 timeout 900 python -m pytest tests/test_parity_r4_gpu.py -m gpu -q -k "headline" 2>&1 | tail -15 | tee $O/${TAG}_parity_lnfold.log; mv gpurun_out/parity.jsonl $O/${TAG}_parity_lnfold.jsonl 2> /dev/null) ;;
+    bench1_nt) (cd $R && UAV_HIP_LIB=$R/tools/ab/libuav_hip_nt.so timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee -a $O/${TAG}_bench1_nt_lib.json) ;;
+    bench1_rep) (cd $R && timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee -a $O/${TAG}_bench1_rep.json) ;;
+    mink_sweep) for mk in ${UAV_MINKS:-0 256 512 1024}; do (cd $R && UAV_CONV_W4_MINK=$mk timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); kb = d['kernel_breakdown']
+print(json.dumps({'UAV_CONV_W4_MINK': $mk, 'frames_per_s': round(d['value'], 4), 'ms_per_clip': round(d['ms_per_step'], 1), 'conv_ms': kb['conv_gemm']['ms'], 'conv_tflops': kb['conv_gemm']['tflops']}))" | tee -a $O/${TAG}_w4_mink_sweep.jsonl); done ;;
     bench1_head) (cd $R && UAV_HIP_LIB=$R/tools/ab/libuav_hip_head.so timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_head_lib.json) ;;
     trace0)   UAV_CONV_W4_MINK=0 UAV_CONV_W4_TRACE=1 timeout 300 python $R/tools/trace_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_trace.log ;;
     w4ab)     timeout 500 python $R/tools/bench_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_vs_8wave.log ;;

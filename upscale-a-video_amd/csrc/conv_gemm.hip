@@ -223,6 +223,8 @@ UAV_DEVINL void conv_gn_store(const ConvArgs& p, float (&st)[NI][GnAcc<GNM>::NG]
 //     pipelined D column tiles ahead (statistics instances / fp32 residual, whose registers do not hold everything).
 // A conv without residual now ends in 16 back-to-back stores; one with a residual pays ONE round trip instead of four.
 typedef __attribute__((address_space(3))) const float4_t* lds_f4ptr_t;
+// (Round 5, run 24: non-temporal residual loads / result stores in the fp32 epilogues — `nt` on every global_load / store of them — cost
+// 6 % of the clip, conv 5 564 -> 6 024 ms: the fp32 stream IS re-read a few launches later, from L2 / the Infinity Cache.  Plain accesses.)
 UAV_DEVINL float4_t lds_f4(unsigned byte_addr) { return *(lds_f4ptr_t)(size_t)byte_addr; }
 
 // RF32: the residual is an fp32 row (fp32 residual stream, fp16 result: a block output that is only read as an MFMA operand);
@@ -2298,7 +2300,7 @@ const ConvEnv& conv_env() {
         return ConvEnv{geti("UAV_CONV_KORDER", 1), geti("UAV_CONV_TILE_ORDER", 1), geti("UAV_CONV_TILE", 0),
                        geti("UAV_CONV_DBG", 0), geti("UAV_CONV_PERSIST", 0), geti("UAV_CONV_DMAV", 6),       // 6: rotated k-step (round 4 default); 1: round 2-3 loop
                        geti("UAV_CONV_SK", 0), geti("UAV_CONV_SK_MAXK", 1024),                                // short-K kernel (round 5 candidate, measured neutral: off) for 1x1 launches with K <= SK_MAXK
-                       geti("UAV_CONV_W4", 1), geti("UAV_CONV_W4_MINK", 1024)};                             // W4 for K = taps x C_in >= MINK (same-box clip A/B, run 10: 1.000 -> 1.057 everywhere -> 1.070 from K = 1024)                                                               // four-wave 128x128-wave-tile kernel (round 5) instead of conv_gemm256i_kernel
+                       geti("UAV_CONV_W4", 1), geti("UAV_CONV_W4_MINK", 0)};                                // W4 for K = taps x C_in >= MINK.  Same-box clip A/Bs: run 10 (lane-per-row epilogues) 1.000 (8-wave everywhere) -> 1.057 (W4 everywhere) -> 1.070 (from K = 1024); run 25 (fp32 epilogues through LDS) 1.141 (from 1024) -> 1.142 (768) -> 1.152 (512) -> 1.154 (256) -> 1.155 (everywhere): 0                                                               // four-wave 128x128-wave-tile kernel (round 5) instead of conv_gemm256i_kernel
     }();
     return env;
 }
