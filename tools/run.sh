@@ -28,6 +28,8 @@ for step in "$@"; do
     ktests)   timeout 600 python -m pytest $R/tests/test_kernels_gpu.py -m gpu -x -q -n 2 -k "conv or linear or shortk or w4 or phase or shortcut or broadcast or groupnorm_stat" 2>&1 | tail -5 | tee $O/${TAG}_ktests.log ;;
     tests)    timeout 1500 python -m pytest $R/tests -m gpu -x -q 2>&1 | tail -15 | tee $O/${TAG}_tests.log
               (cd $R && timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee -a $O/${TAG}_tests.log) ;;
+    tests_all) timeout 1500 python -m pytest $R/tests -m gpu -q 2>&1 | tail -40 | tee $O/${TAG}_tests.log
+              (cd $R && timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee -a $O/${TAG}_tests.log) ;;
     shortk)   timeout 400 python $R/tools/bench_shortk.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_shortk.log ;;
     shortk2)  UAV_CONV_SK=2 timeout 400 python $R/tools/bench_shortk.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_shortk_compiler_kstep.log ;;
     trace)    UAV_CONV_W4_TRACE=1 timeout 300 python $R/tools/trace_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_trace.log ;;
@@ -40,6 +42,7 @@ for step in "$@"; do
 import sys, json
 d = json.loads(sys.stdin.read()); kb = d['kernel_breakdown']
 print(json.dumps({'UAV_CONV_W4_MINK': $mk, 'frames_per_s': round(d['value'], 4), 'ms_per_clip': round(d['ms_per_step'], 1), 'conv_ms': kb['conv_gemm']['ms'], 'conv_tflops': kb['conv_gemm']['tflops']}))" | tee -a $O/${TAG}_w4_mink_sweep.jsonl); done ;;
+    bench1_f32lds) (cd $R && UAV_HIP_LIB=$R/tools/ab/libuav_hip_f32lds.so timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee -a $O/${TAG}_bench1_f32lds_lib.json) ;;
     bench1_head) (cd $R && UAV_HIP_LIB=$R/tools/ab/libuav_hip_head.so timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_head_lib.json) ;;
     trace0)   UAV_CONV_W4_MINK=0 UAV_CONV_W4_TRACE=1 timeout 300 python $R/tools/trace_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_trace.log ;;
     w4ab)     timeout 500 python $R/tools/bench_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_vs_8wave.log ;;
@@ -79,10 +82,10 @@ PY
     bench1)   (cd $R && timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> $O/${TAG}_bench1.err | tee $O/${TAG}_bench1.json) ;;
     bench1_sk0) (cd $R && UAV_CONV_SK=0 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2> /dev/null | tee $O/${TAG}_bench1_sk0.json) ;;
     shape)    (cd $R && UAV_BENCH_DETAIL=1 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> $O/${TAG}_per_shape.txt > $O/${TAG}_bench_detail.json; grep -v amdgpu.ids $O/${TAG}_per_shape.txt | head -70) ;;
-    prof)     rm -rf /tmp/prof; (cd $R && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof -o b -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/${TAG}_bench_under_rocprof.json 2> /dev/null)
+    prof)     rm -rf /tmp/prof; (cd $R && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof -o b -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-throughput-mode > $O/${TAG}_bench_under_rocprof.json 2> /dev/null)
               # ROCm 7.2 rocprofv3 writes a rocpd database, not a csv: its `top_kernels` view IS the --stats kernel summary
               db=$(find /tmp/prof -name "*.db" | head -1)
-              [ -n "$db" ] && python $R/tools/rocpd_top_kernels.py "$db" $O/${TAG}_rocprofv3_kernel_stats.csv "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (MI355X; rocpd view top_kernels; 1 warm-up + 2 timed clips + the two-clip throughput leg + 1 instrumented clip)" && head -14 $O/${TAG}_rocprofv3_kernel_stats.csv | cut -c1-200 ;;
+              [ -n "$db" ] && python $R/tools/rocpd_top_kernels.py "$db" $O/${TAG}_rocprofv3_kernel_stats.csv "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-throughput-mode (MI355X; rocpd view top_kernels; 1 warm-up + 2 timed clips + 1 instrumented clip, all serial)" && head -14 $O/${TAG}_rocprofv3_kernel_stats.csv | cut -c1-200 ;;
     traffic)  (cd $R && bash tools/pmc_traffic.sh 2>&1 | tail -5); cp $O/pmc_conv_traffic.json $O/${TAG}_pmc_conv_traffic.json 2> /dev/null ;;
     digest)   timeout 200 python $R/tools/conv_digest.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_digest.log ;;
     *)        echo "unknown step $step" ;;
