@@ -9,6 +9,8 @@
 #   calib           tools/calib_gemm.py (plain GEMM vs conv 1x1 vs conv 3x3);   calib_pmc: its SQ / GRBM counter passes
 #   bench           python bench.py (default line);   bench_sk0: the same with UAV_CONV_SK=0 (same-box A/B)
 #   bench_driver    python bench.py --steps 20 --warmup 2 (the way the driver runs it)
+#   bench_prop / bench_high / bench_f16   one clip of --propagation (configs[2]) / --precision high / --unet-stream f16
+#   tests_all       the GPU suite without -x (every failure in one call)
 #   bench1          python bench.py --steps 1 --no-cpu-baseline (quick line with the kernel breakdown)
 #   prof            rocprofv3 --kernel-trace --stats over bench.py --steps 2
 #   traffic         tools/pmc_traffic.sh (conv HBM bytes per launch, own --pmc passes)
@@ -78,6 +80,9 @@ PY
       cat $L ;;
     bench)    (cd $R && timeout 900 python bench.py 2> $O/${TAG}_bench.err | tee $O/${TAG}_bench.json) ;;
     bench_driver) (cd $R && timeout 1200 python bench.py --steps 20 --warmup 2 2> /dev/null | tee $O/${TAG}_bench_driver_style_steps20.json) ;;
+    bench_prop) (cd $R && timeout 600 python bench.py --propagation --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench_configs2_propagation.json) ;;
+    bench_high) (cd $R && timeout 600 python bench.py --precision high --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench_precision_high.json) ;;
+    bench_f16)  (cd $R && timeout 600 python bench.py --unet-stream f16 --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench_unet_stream_f16.json) ;;
     bench_sk0) (cd $R && UAV_CONV_SK=0 timeout 900 python bench.py --no-cpu-baseline 2> /dev/null | tee $O/${TAG}_bench_sk0.json) ;;
     bench1)   (cd $R && timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> $O/${TAG}_bench1.err | tee $O/${TAG}_bench1.json) ;;
     bench1_sk0) (cd $R && UAV_CONV_SK=0 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline 2> /dev/null | tee $O/${TAG}_bench1_sk0.json) ;;
