@@ -195,6 +195,8 @@ def test_layernorm(ops, dev, c):
     (64, 8, 4, 300, 77, 2),        # text cross-attention, 2 frames per text
     (128, 8, 2, 200, 200, 1),      # spatial self-attention, ragged L
     (64, 2, 2, 130, 33, 1),
+    (128, 8, 2, 200, 77, 1),       # text cross-attention at the 1024-channel level (short-key kernel, d = 128, ragged last block)
+    (64, 8, 2, 1600, 77, 2),       # ... whole 128-query blocks
     (128, 2, 1, 1600, 1600, 1),
     (512, 1, 2, 160, 160, 1),      # VAE mid-block attention, single head
     (512, 1, 1, 100, 1000, 1),

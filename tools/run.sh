@@ -45,6 +45,8 @@ import sys, json
 d = json.loads(sys.stdin.read()); kb = d['kernel_breakdown']
 print(json.dumps({'UAV_CONV_W4_MINK': $mk, 'frames_per_s': round(d['value'], 4), 'ms_per_clip': round(d['ms_per_step'], 1), 'conv_ms': kb['conv_gemm']['ms'], 'conv_tflops': kb['conv_gemm']['tflops']}))" | tee -a $O/${TAG}_w4_mink_sweep.jsonl); done ;;
     bench1_f32lds) (cd $R && UAV_HIP_LIB=$R/tools/ab/libuav_hip_f32lds.so timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee -a $O/${TAG}_bench1_f32lds_lib.json) ;;
+    atests)   timeout 600 python -m pytest $R/tests/test_kernels_gpu.py $R/tests/test_clip_text_gpu.py -m gpu -x -q -k "attention or clip" 2>&1 | tail -5 | tee $O/${TAG}_attention_tests.log ;;
+    bench1_prev) (cd $R && UAV_HIP_LIB=$R/tools/ab/libuav_hip_prev.so timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee -a $O/${TAG}_bench1_prev_lib.json) ;;
     bench1_head) (cd $R && UAV_HIP_LIB=$R/tools/ab/libuav_hip_head.so timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_head_lib.json) ;;
     trace0)   UAV_CONV_W4_MINK=0 UAV_CONV_W4_TRACE=1 timeout 300 python $R/tools/trace_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_trace.log ;;
     w4ab)     timeout 500 python $R/tools/bench_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_vs_8wave.log ;;

@@ -230,12 +230,36 @@ __global__ __launch_bounds__(256, 2) void attn_short_kernel(AttnArgs p) {
     const char* vbase = p.v + ((long long)bk * p.lk * p.v_stride + (long long)h * D) * 2;
     const int nt = (p.lk + KV - 1) / KV;            // <= NTS (host)
 
+    // Q rows (and, at the end, O rows) move ROW-COALESCED through a wave-private LDS image (round 5): with a lane owning a query, the 64
+    // lanes of one 16-B load touch 32 rows x 32 B — quarter cache lines, the transaction-bound pattern measured on the conv epilogues
+    //  — and this kernel does little else than read Q and write O (77 keys: 3.1 TB/s before).  Here D / 8 lanes read one row's
+    // D halves contiguously (whole lines), the image (rows of 2 D + 16 B: conflict-free both ways) hands every lane its query's fragments.
+    // d = 64 only (measured, run 29: text cross-attention 101.7 -> 94.0 ms per clip, 3.09 -> 3.35 TB/s): at d = 128 the images take the
+    // second workgroup's LDS and the kernel got slower, so that instance keeps the lane-per-row accesses.
+    constexpr bool XCO = D <= 64;
+    constexpr int CH = D / 8;                       // 16-B chunks per row = lanes per row
+    constexpr int RPI = 64 / CH;                    // rows per wave-wide access
+    constexpr int XROW = 2 * D + 16;                // bytes per staged row
+    char* const xw = smem + NTS * (C::KS_BYTES + C::VT_BYTES) + wave * (32 * XROW);
     const int qrow = q0 + l32;
-    const int qr = qrow < p.lq ? qrow : p.lq - 1;
-    const char* qptr = p.q + (((long long)b * p.lq + qr) * p.q_stride + (long long)h * D) * 2;
     half8_t qf[D / 16];
+    if constexpr (!XCO) {
+        const int qr = qrow < p.lq ? qrow : p.lq - 1;
+        const char* qptr = p.q + (((long long)b * p.lq + qr) * p.q_stride + (long long)h * D) * 2;
 #pragma unroll
-    for (int s = 0; s < D / 16; ++s) qf[s] = *(const half8_t*)(qptr + (16 * s + 8 * hi) * 2);
+        for (int s = 0; s < D / 16; ++s) qf[s] = *(const half8_t*)(qptr + (16 * s + 8 * hi) * 2);
+    } else {
+        const int xr = lane / CH, xc = lane % CH;
+#pragma unroll
+        for (int i = 0; i < D / 16; ++i) {
+            const int r = i * RPI + xr;             // row of this wave's 32
+            const int qg = q0 + r < p.lq ? q0 + r : p.lq - 1;
+            const half8_t v = *(const half8_t*)(p.q + (((long long)b * p.lq + qg) * p.q_stride + (long long)h * D) * 2 + xc * 16);
+            *(half8_t*)(xw + r * XROW + xc * 16) = v;
+        }
+#pragma unroll
+        for (int s = 0; s < D / 16; ++s) qf[s] = *(const half8_t*)(xw + l32 * XROW + (16 * s + 8 * hi) * 2);
+    }
 
     // ---- all K tiles by DMA, all V tiles into registers: nothing is waited for in between -----
 #pragma unroll
@@ -336,16 +360,38 @@ __global__ __launch_bounds__(256, 2) void attn_short_kernel(AttnArgs p) {
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
-    if (qrow < p.lq) {
-        char* optr = p.o + (((long long)b * p.lq + qrow) * p.o_stride + (long long)h * D) * 2;
+    if constexpr (!XCO) {
+        if (qrow < p.lq) {
+            char* optr = p.o + (((long long)b * p.lq + qrow) * p.o_stride + (long long)h * D) * 2;
 #pragma unroll
-        for (int i = 0; i < D / 32; ++i)
+            for (int i = 0; i < D / 32; ++i)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                half4_t o = {(half_t)(oacc[i][4 * g] * inv), (half_t)(oacc[i][4 * g + 1] * inv),
-                             (half_t)(oacc[i][4 * g + 2] * inv), (half_t)(oacc[i][4 * g + 3] * inv)};
-                *(half4_t*)(optr + (i * 32 + 8 * g + 4 * hi) * 2) = o;
-            }
+                for (int g = 0; g < 4; ++g) {
+                    half4_t o = {(half_t)(oacc[i][4 * g] * inv), (half_t)(oacc[i][4 * g + 1] * inv),
+                                 (half_t)(oacc[i][4 * g + 2] * inv), (half_t)(oacc[i][4 * g + 3] * inv)};
+                    *(half4_t*)(optr + (i * 32 + 8 * g + 4 * hi) * 2) = o;
+                }
+        }
+        return;
+    }
+    // O rows leave the same way: the lane's 8-B pieces into the wave's image (the Q fragments are in registers since the top), whole rows out
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            half4_t o = {(half_t)(oacc[i][4 * g] * inv), (half_t)(oacc[i][4 * g + 1] * inv),
+                         (half_t)(oacc[i][4 * g + 2] * inv), (half_t)(oacc[i][4 * g + 3] * inv)};
+            *(half4_t*)(xw + l32 * XROW + (i * 32 + 8 * g + 4 * hi) * 2) = o;
+        }
+    {
+        const int xr = lane / CH, xc = lane % CH;
+#pragma unroll
+        for (int i = 0; i < D / 16; ++i) {
+            const int r = i * RPI + xr;
+            const half8_t v = *(const half8_t*)(xw + r * XROW + xc * 16);
+            if (q0 + r < p.lq)
+                *(half8_t*)(p.o + (((long long)b * p.lq + q0 + r) * p.o_stride + (long long)h * D) * 2 + xc * 16) = v;
+        }
     }
 }
 
@@ -771,8 +817,9 @@ int launch_attn(const AttnArgs& a, hipStream_t s) {
     using C = AttnCfg<D>;
     if constexpr (D <= 256) {
         static const int short_on = [] { const char* e = getenv("UAV_ATTN_SHORT"); return e ? atoi(e) : 1; }();   // 0: A/B
-        if (short_on && a.lk <= NTS * KV && !a.causal) {
-            constexpr int smem = NTS * (C::KS_BYTES + C::VT_BYTES);
+        // (d = 64: its row-coalesced O stores are 16-B pieces: rows of o_stride % 8 == 0 halves on a 16-B aligned base, else the generic kernel)
+        if (short_on && a.lk <= NTS * KV && !a.causal && (D > 64 || (!(a.o_stride % 8) && !((size_t)a.o & 15)))) {
+            constexpr int smem = NTS * (C::KS_BYTES + C::VT_BYTES) + (D <= 64 ? 4 * 32 * (2 * D + 16) : 0);      // + the four waves' Q / O row images (d = 64)
             static UavDynLds lds_s;
             if (smem > 65536)
                 if (int rc = uav_set_dyn_lds(lds_s, (const void*)attn_short_kernel<D>, smem)) return rc;
