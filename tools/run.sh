@@ -57,6 +57,18 @@ print(json.dumps({'UAV_CONV_W4_MINK': $mk, 'frames_per_s': round(d['value'], 4),
     bench1_w40) (cd $R && UAV_CONV_W4=0 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_8wave.json) ;;
     calib)    timeout 300 python $R/tools/calib_gemm.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_calib.jsonl ;;
     blas)     timeout 300 python $R/tools/calib_blas_shapes.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_calib_blas_shapes.jsonl ;;
+    w4_pmc)     # SQ / clock counters of the product conv kernel (four-wave) on the two calibration arms; one SQ pass + one clock pass per arm
+      L=$O/${TAG}_w4_pmc.jsonl; : > $L
+      for arm in conv3x3 conv1x1; do
+        rm -rf /tmp/pmc_c
+        UAV_CALIB_ITERS=2 timeout 200 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU \
+          -d /tmp/pmc_c -o sq -- python $R/tools/calib_gemm.py $arm > /dev/null 2>&1
+        python $R/tools/pmc_reduce.py "$(find /tmp/pmc_c -name '*.db' | head -1)" "${arm}_w4_sq" "%conv_gemm256w%" >> $L
+        rm -rf /tmp/pmc_c
+        UAV_CALIB_ITERS=2 timeout 200 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE GRBM_COUNT -d /tmp/pmc_c -o g -- python $R/tools/calib_gemm.py $arm > /dev/null 2>&1
+        python $R/tools/pmc_reduce.py "$(find /tmp/pmc_c -name '*.db' | head -1)" "${arm}_w4_clock" "%conv_gemm256w%" >> $L
+      done
+      cat $L ;;
     calib_pmc)
       L=$O/${TAG}_calib_pmc.jsonl; : > $L
       for arm in blas conv1x1 conv3x3; do
