@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define UAV_ABI_VERSION 5
+#define UAV_ABI_VERSION 6
 
 #define UAV_EINVAL   (-1)   /* bad argument (null pointer, size not supported) */
 #define UAV_EALIGN   (-2)   /* pointer / stride alignment requirement violated */
@@ -211,6 +211,28 @@ int uav_attention_f16(const void* q, int64_t q_stride, const void* k, int64_t k_
                       int32_t heads, int32_t head_dim, float scale,
                       int32_t causal /* 1: key j visible to query i only if j <= i (CLIP text encoder; lq == lk, d 64|128) */,
                       const void* zero_page /* >=16 B of device zeros */, void* stream);
+
+/* ---- K5b (round 6): fused text cross-attention SUB-LAYER of BasicTransformerBlock ----------
+ * Replaces, for the 512-channel levels of the UNet (8 heads x 64, <= 96 text keys), the four launches of one
+ * `hidden = attn(norm(hidden), encoder_hidden_states) + hidden` step (attention.py:523-564 steps attn1 with
+ * only_cross_attention / attn2; CrossAttention.forward :177-238 = to_q, _attention :209-238, to_out):
+ *
+ *     out[m][:] = x[m][:] + b_out + W_out . softmax(scale * (W_q . LayerNorm(x[m][:])) . K_b^T) . V_b ,   b = m / rows_per_kv
+ *
+ * x / out: fp32 token-stream rows [rows][channels] (out may alias x: a workgroup reads its 128 rows before it writes them);
+ * LayerNorm, Q, P and the attention output are rounded to fp16 exactly where the unfused chain stores them.
+ *   wq_packed / wo_packed: the to_q / to_out weights [channels][channels] fp16 in MFMA-fragment stream order, kv_packed: the
+ *   text K | V of every kv batch in the same order — uav_xattn_pack_kv (activations) and uav.ops.pack_xattn_weight (weights)
+ *   produce them; csrc/xattn_fused.hip states the order.
+ *   rows_per_kv % 128 == 0, rows % rows_per_kv == 0, channels == 512, heads == 8, lk <= 96; else UAV_ESHAPE (the caller
+ *   keeps the four-launch chain for such shapes). */
+int uav_xattn_sublayer_f32(const float* x, float* out, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                           const void* wq_packed, const void* kv_packed, const void* wo_packed, const float* out_bias,
+                           int64_t rows, int32_t rows_per_kv, int32_t lk, int32_t channels, int32_t heads, float scale,
+                           void* stream);
+/* k, v: fp16 rows [n_batch * lk][stride] (head h in columns h*head_dim ..) -> out: n_batch * heads * 32 KiB */
+int uav_xattn_pack_kv(const void* k, int64_t k_stride, const void* v, int64_t v_stride, int32_t n_batch, int32_t lk,
+                      int32_t heads, int32_t head_dim, void* out, void* stream);
 
 /* ---- K7: per-pixel temporal attention --------------------------------------------------
  * Replaces TemporalAttention._attention (attention.py:699-733): q*scale -> RoPE on the first

@@ -162,6 +162,59 @@ def attention(q, k, v, *, bq, lq, lk, heads, head_dim, q_per_kv=1, scale=None, q
     return _h((p @ vh).permute(0, 2, 1, 3).reshape(bq * lq, c))
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Fused text cross-attention sub-layer (csrc/xattn_fused.hip).  The stand-ins DECODE the MFMA-fragment streams (uav.ops.pack_xattn_weight
+# and the layout uav_xattn_pack_kv writes) back to plain matrices, so the host-side packing is checked on CPU too.
+def _unpack_xattn_weight(packed, kind):
+    if kind == "q":        # [h][ks][mt][hi][l32][e2][e1] -> rows (h, mt, l32) x k (ks, e2, hi, e1)
+        return packed.float().reshape(8, 32, 2, 2, 32, 2, 4).permute(0, 2, 4, 1, 5, 3, 6).reshape(512, 512)
+    # [h][npair][ks][par][hi][l32][e2][e1] -> rows (npair, par, l32) x k (h, ks, e2, hi, e1)
+    return packed.float().reshape(8, 8, 4, 2, 2, 32, 2, 4).permute(1, 3, 5, 0, 2, 6, 4, 7).reshape(512, 512)
+
+
+def xattn_pack_kv(k, v, *, n_batch, lk, k_stride=None, v_stride=None):
+    """[n_batch][8 heads][32 fragments][64 lanes][8 halves]: 0..11 K (key tile f % 3, k-step f / 3), 12..23 V^T (k-step g >> 1, tile g & 1)."""
+    out = torch.zeros(n_batch, 8, 32, 2, 32, 2, 4, dtype=HALF)                       # (b, h, f, hi, l32, e2, e1)
+    kk = torch.zeros(n_batch, 96, 8, 64, dtype=HALF); vv = torch.zeros(n_batch, 96, 8, 64, dtype=HALF)
+    kk[:, :lk] = k.reshape(n_batch, lk, 8, 64); vv[:, :lk] = v.reshape(n_batch, lk, 8, 64)
+    # K fragment f = kt + 3 ks: rows key = 32 kt + l32, k = channel 16 ks + 8 e2 + 4 hi + e1
+    kf = kk.reshape(n_batch, 3, 32, 8, 4, 2, 2, 4)                                    # (b, kt, l32, h, ks, e2, hi, e1)
+    out[:, :, :12] = kf.permute(0, 3, 4, 1, 6, 2, 5, 7).reshape(n_batch, 8, 12, 2, 32, 2, 4)      # (b, h, ks, kt, hi, l32, e2, e1): f = 3 ks + kt
+    # V^T fragment g = 2 ks + mt: rows channel 32 mt + l32, k = key 16 ks + 8 e2 + 4 hi + e1
+    vf = vv.reshape(n_batch, 6, 2, 2, 4, 8, 2, 32)                                    # (b, ks, e2, hi, e1, h, mt, l32)
+    out[:, :, 12:24] = vf.permute(0, 5, 1, 6, 3, 7, 2, 4).reshape(n_batch, 8, 12, 2, 32, 2, 4)    # (b, h, ks, mt, hi, l32, e2, e1)
+    return out.reshape(n_batch, 8, 32 * 64 * 8)
+
+
+def _unpack_xattn_kv(kvp, lk):
+    n_batch = kvp.shape[0]
+    f = kvp.reshape(n_batch, 8, 32, 2, 32, 2, 4)
+    kf = f[:, :, :12].reshape(n_batch, 8, 4, 3, 2, 32, 2, 4)                          # (b, h, ks, kt, hi, l32, e2, e1)
+    k = kf.permute(0, 3, 5, 1, 2, 6, 4, 7).reshape(n_batch, 96, 8, 64)                # key (kt, l32), head, channel (ks, e2, hi, e1)
+    vf = f[:, :, 12:24].reshape(n_batch, 8, 6, 2, 2, 32, 2, 4)                        # (b, h, ks, mt, hi, l32, e2, e1)
+    v = vf.permute(0, 2, 6, 4, 7, 1, 3, 5).reshape(n_batch, 96, 8, 64)                # key (ks, e2, hi, e1), head, channel (mt, l32)
+    return k[:, :lk].float(), v[:, :lk].float()
+
+
+def xattn_sublayer(x, gamma, beta, eps, wq_packed, kv_packed, wo_packed, out_bias, *, rows_per_kv, lk, scale, out=None):
+    wq = _unpack_xattn_weight(wq_packed, "q"); wo = _unpack_xattn_weight(wo_packed, "out")
+    k, v = _unpack_xattn_kv(kv_packed, lk)                                            # (B, lk, 8, 64)
+    m = x.shape[0]
+    nb = m // rows_per_kv
+    n = _h(F.layer_norm(x.float(), (512,), gamma.float(), beta.float(), eps)).float()
+    q = _h(n @ wq.t()).float().reshape(nb, rows_per_kv, 8, 64).permute(0, 2, 1, 3)
+    sc = q @ k.permute(0, 2, 3, 1) * scale                                            # (B, 8, rows, lk)
+    sc = sc - sc.amax(-1, keepdim=True)
+    e = torch.exp(sc)
+    o = (_h(e).float() @ v.permute(0, 2, 1, 3)) / e.sum(-1, keepdim=True)             # P rounded to fp16 unnormalised, like the kernel
+    o = _h(o.permute(0, 2, 1, 3).reshape(m, 512)).float()
+    y = x.float() + out_bias.float() + o @ wo.t()
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 def temporal_attention(qkv, *, n_batch, t_len, hw, c, heads, scale, rope_cos, rope_sin, rot_dim, bias):
     d = c // heads
     x = qkv.float().reshape(n_batch, t_len, hw, 3, heads, d)
@@ -284,7 +337,7 @@ def sft_fuse(dec, scale, shift, w, out_f32=False):
     return y if out_f32 else _h(y)
 
 
-_OPS = ("ln_fold_ok", "resize_area_f32", "cast_f16", "cast_hilo", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "temporal_attention", "linear_small",
+_OPS = ("ln_fold_ok", "resize_area_f32", "cast_f16", "cast_hilo", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "xattn_pack_kv", "xattn_sublayer", "temporal_attention", "linear_small",
         "timestep_embedding", "pack_nhwc", "unpack_ncthw", "axpby", "cfg_ddim_v0", "ddim_vt")
 
 

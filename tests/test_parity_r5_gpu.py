@@ -50,7 +50,11 @@ def test_t14_window_schedule_full_width_30_steps_vs_reference_pipeline(dev):
     assert e_unsat < T14_BARS[2], (e_all, e_unsat)
 
 
-def test_tiled_video_vae_full_width_vs_reference_cli_loop(dev):
+@pytest.mark.parametrize("case", ["pipe_tiled_full_videovae", "pipe_tiled_full_videovae_30"], ids=["5_step_stress_case", "30_steps_configs4_schedule"])
+def test_tiled_video_vae_full_width_vs_reference_cli_loop(dev, case):
+    """BASELINE configs[4]'s path — the reference CLI's tile loop around the pipeline with `--use_video_vae` — at the released width:
+    at the 30-step schedule the config really runs (round 6; asserted at the STATED 1e-3 over all pixels, like T = 14 and the
+    headline) and at a 5-step schedule kept as a labelled STRESS case (200-timestep strides weigh every UNet error ~6x: 2.3e-3)."""
     import golden_cases as GC
     import synth
     from uav import configs, tiling
@@ -58,11 +62,12 @@ def test_tiled_video_vae_full_width_vs_reference_cli_loop(dev):
     from models_video.pipeline_upscale_a_video import VideoUpscalePipeline
     from models_video.scheduling_ddim import DDIMScheduler, DDPMScheduler
     from uav.standin_text import StandInTextEncoder, StandInTokenizer
-    path = os.path.join(ROOT, "tests", "golden", "pipe_tiled_full_videovae.pt")
+    path = os.path.join(ROOT, "tests", "golden", case + ".pt")
     if not os.path.exists(path):
-        pytest.skip("fixture pipe_tiled_full_videovae.pt not generated")
+        pytest.skip(f"fixture {case}.pt not generated")
     gold = torch.load(path)
-    pc = GC.FULL_CASES["pipe_tiled_full_videovae"]
+    pc = GC.FULL_CASES[case]
+    bars = TILED_BARS[pc["steps"]]
     unet, usd, _, _ = build_models(dev)
     vae = AutoencoderKLVideo.from_config(dict(configs.VAE_VIDEO))
     vae.load_state_dict(synth.synth_state_dict(vae.state_dict(), seed=4321), strict=True)
@@ -82,15 +87,16 @@ def test_tiled_video_vae_full_width_vs_reference_cli_loop(dev):
     o = out.float().cpu()
     e_all, e_unsat, sat = image_errors(o[..., ::2, ::2], gold["sub2"].float())
     s_all, s_unsat, _ = image_errors(o[..., :, 240:272], gold["seam"].float())
-    report("r5_pipe_tiled_full_videovae_vs_reference_cli_loop", images_rel_l2_all_pixels=e_all, images_rel_l2_unsaturated=e_unsat,
+    report("r5_" + case + "_vs_reference_cli_loop", ddim_steps=pc["steps"], images_rel_l2_all_pixels=e_all, images_rel_l2_unsaturated=e_unsat,
            images_saturated_fraction=sat, seam_strip_rel_l2_all_pixels=s_all, seam_strip_rel_l2_unsaturated=s_unsat, tiles=len(tiles))
-    assert e_all < TILED_BARS[0], (e_all, e_unsat)
-    assert e_unsat < TILED_BARS[1], (e_all, e_unsat)
-    assert s_all < TILED_BARS[0] * 1.5, (s_all, s_unsat)
+    assert e_all < bars[0], (e_all, e_unsat)
+    assert e_unsat < bars[1], (e_all, e_unsat)
+    assert s_all < bars[0] * 1.5, (s_all, s_unsat)
 
 
 # bars = measured + 10 % (round 5, run 18, profiles/r05_parity_full_suite_run18.jsonl):
 #   T = 14, 30 steps:  latents 7.7e-4, .images 9.2e-4 over all pixels / 1.20e-3 over the 87 % the reference does not clamp
 #   tiled vae_video, 5 steps: .images 2.32e-3 / 3.08e-3 (the 5-step schedule weighs each UNet error ~6x, like configs[0]); seam strip 2.17e-3
 T14_BARS = (8.5e-4, 1.02e-3, 1.32e-3)
-TILED_BARS = (2.55e-3, 3.4e-3)
+#   tiled vae_video, 30 steps (round 6): asserted at the stated 1e-3 over all pixels; unclamped-pixel bar = measured + 10 %
+TILED_BARS = {5: (2.55e-3, 3.4e-3), 30: (1.0e-3, 1.35e-3)}

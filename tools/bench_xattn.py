@@ -1,0 +1,73 @@
+"""Same-process, interleaved A/B of the fused text cross-attention sub-layer kernel (csrc/xattn_fused.hip) against the four launches it
+replaces (LayerNorm -> to_q -> 77-key attention -> to_out + residual) on the two 512-channel levels of BASELINE configs[1].
+One JSON line per shape: median / min ms of the fused launch, of the chain and of each of its four launches; algorithmic TFLOP/s and the
+HBM rate of the 8 B per element the fused kernel must move; max |difference| of the two results.
+usage: python tools/bench_xattn.py"""
+import json
+import os
+import statistics
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "upscale-a-video_amd"))
+from uav import ops  # noqa: E402
+
+dev = torch.device("cuda:0")
+ROUNDS, PER = int(os.environ.get("UAV_XA_ROUNDS", "5")), int(os.environ.get("UAV_XA_PER", "6"))
+C, H, D, LK = 512, 8, 64, 77
+
+
+def time_once(fn, n):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+
+
+def case(name, nb, rpk):
+    m = nb * rpk
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(m, C, generator=g) * 1.3 + 0.2).to(dev)
+    gamma = (torch.randn(C, generator=g) * 0.2 + 1).to(dev); beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+    wq = (torch.randn(C, C, generator=g) * C ** -0.5).half().float().to(dev); wo = (torch.randn(C, C, generator=g) * C ** -0.5).half().float().to(dev)
+    bo = (torch.randn(C, generator=g) * 0.1).to(dev)
+    kv = torch.randn(nb * LK, 2 * C, generator=g).half().to(dev)
+    k, v = kv[:, :C], kv[:, C:]
+    cq, co = ops.pack_conv(wq, None, device=dev), ops.pack_conv(wo, bo, device=dev)
+    wqp, wop = ops.pack_xattn_weight(wq, "q", dev), ops.pack_xattn_weight(wo, "out", dev)
+    kvp = ops.xattn_pack_kv(k, v, n_batch=nb, lk=LK, k_stride=2 * C, v_stride=2 * C)
+    scale = D ** -0.5
+    st = {}
+
+    def ln(): st["n"] = ops.layernorm(x, gamma, beta, 1e-5)
+    def toq(): st["q"] = ops.linear(st["n"], cq)
+    def att(): st["o"] = ops.attention(st["q"], k, v, bq=nb, lq=rpk, lk=LK, heads=H, head_dim=D, scale=scale, q_stride=C, k_stride=2 * C, v_stride=2 * C)
+    def out(): st["y"] = ops.linear(st["o"], co, residual=x, out_f32=True)
+    def chain(): ln(); toq(); att(); out()
+    def fused(): st["f"] = ops.xattn_sublayer(x, gamma, beta, 1e-5, wqp, kvp, wop, bo, rows_per_kv=rpk, lk=LK, scale=scale)
+
+    fns = {"fused": fused, "chain": chain, "layernorm": ln, "to_q": toq, "attention": att, "to_out": out}
+    chain(); fused(); chain(); fused()
+    torch.cuda.synchronize()
+    t = {kk: [] for kk in fns}
+    for _ in range(ROUNDS):
+        for kk, f in fns.items():
+            t[kk].append(time_once(f, PER))
+    fl = 2.0 * m * 2 * C * C + 4.0 * m * LK * C
+    d = {"case": name, "rows": m, "max_abs_diff_fused_vs_chain": float((st["f"] - st["y"]).abs().max())}
+    for kk in fns:
+        d[kk + "_ms"] = {"median": round(statistics.median(t[kk]), 4), "min": round(min(t[kk]), 4)}
+    med = d["fused_ms"]["median"]
+    d["fused_tflops"] = round(fl / med / 1e9, 1)
+    d["fused_algorithmic_GBps"] = round(8.0 * m * C / med / 1e6, 0)
+    d["speedup_vs_chain"] = round(d["chain_ms"]["median"] / med, 3)
+    print(json.dumps(d), flush=True)
+
+
+if __name__ == "__main__":
+    case("160x160 level: 2 x 8 frames x 160 x 160 tokens", 2, 8 * 160 * 160)
+    case("80x80 level: 2 x 8 frames x 80 x 80 tokens", 2, 8 * 80 * 80)

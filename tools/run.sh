@@ -17,6 +17,11 @@
 #   digest          tools/conv_digest.py
 #   bench1_head     bench1 on tools/ab/libuav_hip_head.so (a build of the library from HEAD's sources, same-box A/B of uncommitted kernel work)
 #   trace0 / trace_small   phase stamps of the four-wave kernel on the K = 512 linears (full grid / 64..3200-tile grids)
+#   xattn / xtests  fused cross-attention sub-layer: tools/bench_xattn.py (vs the four-launch chain) / its kernel tests;  bench1_nox: bench1 with UAV_XATTN_FUSED=0
+#   t32             configs[3] at its real length: T = 32, 320x320, 30 steps vs the GPU oracle (tests/test_parity_r6_gpu.py, ~12 min)
+#   bench1_cfgsplit one 8-frame clip with its two guidance branches on two HIP streams
+#   bench_noev      event-overhead A/B: default vs --no-kernel-events, twice interleaved
+#   bench_c3 / bench_c4 / bench_2clips   configs[3] schedule on one GPU / one configs[4] tile with vae_video / two clips per GPU
 #   bench1_lnfold / parity_lnfold   the LayerNorm-fold switch (UAV_LN_FOLD=1): clip time and the headline parity test
 # Environment: any UAV_* variable is passed through to every step.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -92,6 +97,15 @@ PY
         python $R/tools/pmc_reduce.py "$(find /tmp/pmc_c -name '*.db' | head -1)" "${arm}_clock" "$pat" >> $L
       done
       cat $L ;;
+    xattn)    timeout 300 python $R/tools/bench_xattn.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_xattn_fused_vs_chain.jsonl ;;
+    xtests)   timeout 600 python -m pytest $R/tests/test_kernels_gpu.py -m gpu -x -q -k "fused_cross or attention" 2>&1 | tail -8 | tee $O/${TAG}_xattn_tests.log ;;
+    bench1_nox) (cd $R && UAV_XATTN_FUSED=0 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_four_launch_chain.json) ;;
+    t32)      (cd $R && rm -f gpurun_out/parity.jsonl; UAV_PARITY_T32=1 timeout 1500 python -m pytest tests/test_parity_r6_gpu.py -m gpu -q -x 2>&1 | tail -8 | tee $O/${TAG}_parity_t32.log; mv gpurun_out/parity.jsonl $O/${TAG}_parity_configs3_t32_320.jsonl 2> /dev/null) ;;
+    bench1_cfgsplit) (cd $R && timeout 400 python bench.py --overlap-streams 2 --overlap-split-cfg --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_cfg_branches_on_two_streams.json) ;;
+    bench_noev) (cd $R && for i in 1 2; do timeout 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee -a $O/${TAG}_event_overhead_ab_default.jsonl; timeout 400 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-throughput-mode --no-kernel-events 2> /dev/null | tee -a $O/${TAG}_event_overhead_ab_no_kernel_events.jsonl; done) ;;
+    bench_c3)  (cd $R && timeout 900 python bench.py --frames 32 --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench_configs3_schedule_t32_one_gpu.json) ;;
+    bench_c4)  (cd $R && timeout 900 python bench.py --video-vae --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench_configs4_tile_video_vae.json) ;;
+    bench_2clips) (cd $R && timeout 900 python bench.py --clips-per-step 2 --steps 2 --warmup 1 --no-cpu-baseline 2> /dev/null | tee $O/${TAG}_bench_two_clips_per_gpu.json) ;;
     bench)    (cd $R && timeout 900 python bench.py 2> $O/${TAG}_bench.err | tee $O/${TAG}_bench.json) ;;
     bench_driver) (cd $R && timeout 1200 python bench.py --steps 20 --warmup 2 2> /dev/null | tee $O/${TAG}_bench_driver_style_steps20.json) ;;
     bench_prop) (cd $R && timeout 600 python bench.py --propagation --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench_configs2_propagation.json) ;;

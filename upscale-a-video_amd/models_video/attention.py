@@ -97,8 +97,17 @@ class CrossAttention(E.EngineModule):
         (engine.ln_linear); text: TextKV cache entry (k, v, lk) for cross-attention."""
         c = self.heads * self.dim_head
         if self.is_cross:
+            k, v, lk = text[:3]
+            kvp = text[3] if len(text) > 3 else None
+            if (kvp is not None and ln is not None and residual is x and E.XATTN_FUSED and not E.LN_FOLD and self.to_q.bias is None
+                    and self.to_out[0].bias is not None and ops.xattn_ok(x, heads=self.heads, head_dim=self.dim_head, lk=lk, rows_per_kv=q_per_kv * lq)):
+                # the whole sub-layer in one launch (csrc/xattn_fused.hip): the fp32 stream is read once and written once
+                wq = self._cache().get(("xattn", "q"), lambda: ops.pack_xattn_weight(self.to_q.weight, "q", E._dev(self.to_q.weight)), (self.to_q.weight,))
+                wo = self._cache().get(("xattn", "out"), lambda: ops.pack_xattn_weight(self.to_out[0].weight, "out", E._dev(self.to_q.weight)),
+                                       (self.to_out[0].weight,))
+                return ops.xattn_sublayer(x, E.f32_param(self, "xattn.g", ln.weight), E.f32_param(self, "xattn.b", ln.bias), ln.eps, wq, kvp, wo,
+                                          E.f32_param(self, "xattn.ob", self.to_out[0].bias), rows_per_kv=q_per_kv * lq, lk=lk, scale=self.scale)
             q = ops.linear(x, E.packed_conv(self, "q", self.to_q)) if ln is None else E.ln_linear(self, "q", ln, x, [self.to_q])
-            k, v, lk = text
             o = ops.attention(q, k, v, bq=bq, lq=lq, lk=lk, heads=self.heads, head_dim=self.dim_head, q_per_kv=q_per_kv,
                               scale=self.scale, q_stride=c, k_stride=2 * c, v_stride=2 * c)
         else:
@@ -109,11 +118,17 @@ class CrossAttention(E.EngineModule):
         s32 = residual.dtype == torch.float32
         return ops.linear(o, E.packed_conv(self, "out", self.to_out[0]), residual=residual, out_f32=s32, ln_produce=s32 and E.LN_FOLD)
 
-    def project_text(self, ehs_rows):
-        """K|V of the text tokens: [B*77][2C] (fused GEMM), computed once per prompt tensor."""
+    def project_text(self, ehs_rows, n_text=None):
+        """K|V of the text tokens: [B*77][2C] (fused GEMM), computed once per prompt tensor — and, where the fused sub-layer kernel
+        takes the block (512 channels, 8 heads), the same values in its MFMA-fragment stream order (third entry, else None)."""
         kv = ops.linear(ehs_rows, E.packed_cat(self, "kv", [self.to_k, self.to_v]))
         c = self.heads * self.dim_head
-        return kv[:, :c], kv[:, c:]
+        k, v = kv[:, :c], kv[:, c:]
+        packed = None
+        if (E.XATTN_FUSED and n_text and c == ops.XATTN_C and self.heads == ops.XATTN_HEADS and n_text <= ops.XATTN_MAX_KEYS
+                and ehs_rows.shape[0] % n_text == 0):
+            packed = ops.xattn_pack_kv(k, v, n_batch=ehs_rows.shape[0] // n_text, lk=n_text, k_stride=2 * c, v_stride=2 * c)
+        return k, v, packed
 
 
 class TemporalAttention(CrossAttention):
@@ -200,7 +215,7 @@ class BasicTransformerBlock(E.EngineModule):
         self.ff = FeedForward(dim, dropout=dropout, activation_fn=activation_fn)
         self.norm3 = nn.LayerNorm(dim)
 
-    def _text_kv(self, attn, ehs_rows, tag):
+    def _text_kv(self, attn, ehs_rows, tag, n_text=None):
         """K/V of the text tokens, cached per prompt tensor: the cache holds a reference to
         `ehs_rows` (so its storage cannot be recycled) and is keyed on identity + version."""
         c = self._cache()
@@ -209,7 +224,7 @@ class BasicTransformerBlock(E.EngineModule):
         for hit in hits:
             if hit[0] is ehs_rows and hit[1] == ehs_rows._version and hit[3] == wstamp:
                 return E.acquire(hit[2])
-        kv = E.publish(attn.project_text(ehs_rows))
+        kv = E.publish(attn.project_text(ehs_rows, n_text))
         # a few entries: the guidance branches evaluated one by one (pipeline.shard_cfg / overlap_streams) alternate between
         # two prompt tensors
         c.store[("textkv", tag)] = ((ehs_rows, ehs_rows._version, kv, wstamp),) + tuple(hits)[:TEXT_KV_ENTRIES - 1]
@@ -222,13 +237,13 @@ class BasicTransformerBlock(E.EngineModule):
         # every LayerNorm is handed to its consumer together with the un-normalised stream: engine.ln_linear folds it into
         # the projection when the stream is fp32 and its producer wrote the operand copy, else runs the LayerNorm pass
         if self.only_cross_attention:
-            k, v = self._text_kv(self.attn1, ehs_rows, "a1")
-            x = self.attn1.run(x, x, bq=bq, lq=lq, text=(k, v, n_text), q_per_kv=g.t, ln=self.norm1)
+            k, v, kvp = self._text_kv(self.attn1, ehs_rows, "a1", n_text)
+            x = self.attn1.run(x, x, bq=bq, lq=lq, text=(k, v, n_text, kvp), q_per_kv=g.t, ln=self.norm1)
         else:
             x = self.attn1.run(x, x, bq=bq, lq=lq, ln=self.norm1)
         if self.attn2 is not None:
-            k, v = self._text_kv(self.attn2, ehs_rows, "a2")
-            x = self.attn2.run(x, x, bq=bq, lq=lq, text=(k, v, n_text), q_per_kv=g.t, ln=self.norm2)
+            k, v, kvp = self._text_kv(self.attn2, ehs_rows, "a2", n_text)
+            x = self.attn2.run(x, x, bq=bq, lq=lq, text=(k, v, n_text, kvp), q_per_kv=g.t, ln=self.norm2)
         x = self.attn_temporal.run_temporal(x, x, g, ln=self.norm_temporal)
         return self.ff.run(x, x, out_f32, ln=self.norm3)
 
@@ -263,7 +278,7 @@ class Transformer3DModel(ModelMixin, ConfigMixin, E.EngineModule):
         tok32 = s32 and E.TOKEN_F32 and (E.TOKEN_F32_MAX_HW <= 0 or g.hw <= E.TOKEN_F32_MAX_HW)
         tok = ops.linear(n, E.packed_conv(self, "proj_in", self.proj_in), out_f32=tok32, ln_produce=tok32 and E.LN_FOLD)
         last = len(self.transformer_blocks) - 1
-        tail_hilo = tok32 and E.TAIL_HILO
+        tail_hilo = tok32 and E.tail_hilo()
         for i, blk in enumerate(self.transformer_blocks):
             # proj_out reads the last block's output as an operand: fp16, or (TAIL_HILO) the fp32 rows as a hi | lo pair
             tok = blk.run(tok, g, ehs_rows, n_text, out_f32=False if (i == last and not tail_hilo) else None)

@@ -219,6 +219,7 @@ class VideoUpscalePipeline(ConfigMixin):
         unique temporal windows, or the guidance branches when `overlap_split_cfg` asks for them.  Every side stream owns a
         caching-allocator pool (blocks freed there are not reusable by the caller's stream) and two units are live at once, so
         the overlap is skipped when less than `overlap_min_free_fraction` of the device memory is free."""
+        self.last_overlap_mode = "serial"             # every early return below leaves the truth behind, not the previous call's value
         if self.overlap_streams <= 1 or self.shard_windows or torch.device(device).type != "cuda":
             return None
         try:

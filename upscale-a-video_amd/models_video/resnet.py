@@ -222,7 +222,7 @@ class _ResnetBase(E.EngineModule):
         if want_raw:
             h, raw16 = h
         rb = _temb_rows(self, temb) if (temb is not None and self.time_emb_proj is not None) else None
-        h = self.conv1.run(h, g, rowbias=rb, out_f32=s32 and E.BRANCH_F32, gn_groups=self.norm2.num_groups)
+        h = self.conv1.run(h, g, rowbias=rb, out_f32=s32 and E.branch_f32(), gn_groups=self.norm2.num_groups)
         h = E.group_norm(self, "norm2", self.norm2, h, n_inst=g.b, rows_per_inst=g.rows_per_batch, silu=True)
         osc = 1.0 / self.output_scale_factor
         if self.conv_shortcut is not None and raw16 is not None and E.FUSE_SHORTCUT and isinstance(self.conv2, InflatedConv3d) \

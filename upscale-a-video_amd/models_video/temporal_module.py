@@ -43,7 +43,7 @@ class TemporalModule3D(E.EngineModule):
     def run(self, x, g: E.Geom, temb=None, w=1.0):
         s32 = x.dtype == torch.float32           # fp32 residual stream (UNetVideoModel.stream_dtype)
         h = self.resblocks_3d_temporal.run(x, g, temb)
-        tail_hilo = s32 and E.TAIL_HILO and self.in_channels % 64 == 0
+        tail_hilo = s32 and E.tail_hilo() and self.in_channels % 64 == 0
         # the tail block's output is only read as shift_conv's MFMA operand: fp16, or (TAIL_HILO) fp32 rows as a hi | lo pair
         h = self.resblocks_3d_spatial.run(h, g, temb, out_f32=None if tail_hilo else False)
         if w != 1.0:

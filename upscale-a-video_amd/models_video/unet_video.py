@@ -248,14 +248,10 @@ class UNetVideoModel(ModelMixin, ConfigMixin, E.EngineModule):
             raise ValueError(f"expected {self.config.in_channels} input channels, got {sample.shape[1]}+{low_res.shape[1]}")
         if self.precision not in ("default", "high"):
             raise ValueError(f"UNetVideoModel.precision must be 'default' or 'high', got {self.precision!r}")
-        if self.precision == "high" and not (E.TAIL_HILO and E.BRANCH_F32):
-            saved = (E.TAIL_HILO, E.BRANCH_F32)
-            E.TAIL_HILO, E.BRANCH_F32 = True, True
-            try:
+        if self.precision == "high" and not (E.tail_hilo() and E.branch_f32()):
+            with E.precision_high():         # thread-local scope: other host threads sharing this UNet are not affected
                 return self.forward(sample, timestep, low_res, encoder_hidden_states, class_labels, attention_mask, return_dict,
                                     cfg_shared_input)
-            finally:
-                E.TAIL_HILO, E.BRANCH_F32 = saved
         dev = sample.device
         s32 = self.stream_f32()
         if self.config.center_input_sample:

@@ -65,6 +65,8 @@ SIGNATURES = {
     "uav_layernorm_f16": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, f32, c_p]),
     "uav_layernorm_f32in": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, f32, c_p]),
     "uav_attention_f16": (C.c_int, [c_p, i64, c_p, i64, c_p, i64, c_p, i64, i32, i32, i32, i32, i32, i32, f32, i32, c_p, c_p]),
+    "uav_xattn_sublayer_f32": (C.c_int, [c_p, c_p, c_p, c_p, f32, c_p, c_p, c_p, c_p, i64, i32, i32, i32, i32, f32, c_p]),
+    "uav_xattn_pack_kv": (C.c_int, [c_p, i64, c_p, i64, i32, i32, i32, i32, c_p, c_p]),
     "uav_temporal_attention_f16": (C.c_int, [c_p, c_p, i32, i32, i64, i32, i32, f32, c_p, c_p, i32, c_p, c_p]),
     "uav_linear_small": (C.c_int, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, c_p]),
     "uav_timestep_embedding": (C.c_int, [c_p, i32, i32, i32, f32, c_p, c_p]),
@@ -98,7 +100,7 @@ SIGNATURES = {
     "uav_propagate_step_f32": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i32, i32, i32, i64, i64, i32, f32, f32, f32, c_p]),
 }
 
-EXPECTED_ABI = 5          # include/uav_hip.h UAV_ABI_VERSION this binding was written against
+EXPECTED_ABI = 6          # include/uav_hip.h UAV_ABI_VERSION this binding was written against
 
 
 class UavError(RuntimeError):

@@ -135,13 +135,26 @@ def audit_accumulator_file():
                            + "\n  ".join(bad[:8]))
 
 
+def _readelf():
+    """llvm-readelf: $UAV_READELF, else <rocm>/lib/llvm/bin next to hipcc, else whatever PATH offers."""
+    import shutil
+    cands = [os.environ.get("UAV_READELF"), os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(HIPCC))), "lib", "llvm", "bin", "llvm-readelf"),
+             os.path.join(os.path.dirname(os.path.dirname(HIPCC)), "lib", "llvm", "bin", "llvm-readelf"),
+             shutil.which("llvm-readelf")]
+    for c in cands:
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("llvm-readelf not found (set UAV_READELF): the build audit reads the code-object metadata with it; tried "
+                       + ", ".join(str(c) for c in cands if c))
+
+
 def kernel_metadata(lib=None):
     """{kernel symbol: {metadata field: value}} of every gfx950 code object bundled in the library, read from the AMDGPU
     metadata note (llvm-readelf --notes) of each offload bundle entry."""
     import re
     import struct
     import tempfile
-    readelf = os.path.join(os.path.dirname(os.path.dirname(HIPCC)), "lib", "llvm", "bin", "llvm-readelf")
+    readelf = _readelf()
     with open(lib or LIB, "rb") as fh:
         blob = fh.read()
     magic = b"__CLANG_OFFLOAD_BUNDLE__"

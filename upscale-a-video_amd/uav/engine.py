@@ -299,6 +299,36 @@ FUSE_SHORTCUT = _os.environ.get("UAV_FUSE_SHORTCUT", "1") != "0"
 # hi | lo pair by their 1x1 consumer?  UAV_TAIL_HILO (CPU emulation: 7.5e-4 -> 6.5e-4 per forward).
 TAIL_HILO = _os.environ.get("UAV_TAIL_HILO", "0") != "0"
 # samplers left on a single fp16 operand although SAMPLER_HILO is on: ("up" | "down", input height) pairs (numerics experiments)
+import threading as _threading
+
+_PRECISION = _threading.local()        # .high: depth of `precision_high()` scopes open on THIS host thread
+
+
+class precision_high:
+    """Scope in which THIS host thread's launches lift the two cheap roundings (`UNetVideoModel.precision = "high"`): block
+    tails as hi | lo pairs and the fp32 ResNet branch tensor.  Thread-local by design: one UNet is shared by the
+    host threads of the two-clip mode and of `uav.streams`, so the switch must not be a process global that one thread's
+    `finally` clears under another thread's forward."""
+
+    def __enter__(self):
+        _PRECISION.high = getattr(_PRECISION, "high", 0) + 1
+        return self
+
+    def __exit__(self, *exc):
+        _PRECISION.high -= 1
+        return False
+
+
+def tail_hilo():
+    """Block tails read as an fp16 hi | lo pair by their 1x1 consumer?  (UAV_TAIL_HILO, or inside `precision_high()`.)"""
+    return TAIL_HILO or getattr(_PRECISION, "high", 0) > 0
+
+
+def branch_f32():
+    """ResNet branch tensor conv1 -> norm2 kept in fp32?  (UAV_BRANCH_F32, or inside `precision_high()`.)"""
+    return BRANCH_F32 or getattr(_PRECISION, "high", 0) > 0
+
+
 SAMPLER_HILO_SKIP = set()
 SAMPLER_HILO = {"0": False, "1": True}.get(_os.environ.get("UAV_SAMPLER_HILO", "1"), _os.environ.get("UAV_SAMPLER_HILO", "1"))
 
@@ -324,6 +354,12 @@ def group_norm(mod: EngineModule, name, gn: nn.GroupNorm, x, *, n_inst, rows_per
 # accuracy where the row mean is not small against its spread: 8.5e-4 -> 8.8e-4 per forward and 8.8e-4 -> 9.5e-4 after the 30-step
 # schedule — too close to the stated 1e-3.  OFF by default; UAV_LN_FOLD=1 turns it on.
 LN_FOLD = _os.environ.get("UAV_LN_FOLD", "0") != "0"
+
+
+# Text cross-attention sub-layers of the 512-channel levels (LayerNorm -> to_q -> 77-key softmax -> to_out -> + residual) as ONE
+# launch (csrc/xattn_fused.hip, round 6): the fp32 token stream is read once and written once instead of 24 B per element over four
+# launches.  UAV_XATTN_FUSED=0 keeps the four-launch chain (A/B and the equivalence test).
+XATTN_FUSED = _os.environ.get("UAV_XATTN_FUSED", "1") != "0"
 
 
 def packed_ln_linear(mod: EngineModule, name, ln: nn.LayerNorm, linears, geglu=False):

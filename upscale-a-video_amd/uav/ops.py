@@ -631,6 +631,62 @@ def attention(q, k, v, *, bq, lq, lk, heads, head_dim, q_per_kv=1, scale=None,
     return out
 
 
+# ------------------------------------------------------------------------------------------------
+# Fused text cross-attention sub-layer (csrc/xattn_fused.hip): LayerNorm -> to_q -> softmax(Q K^T) V -> to_out -> + residual
+XATTN_C, XATTN_HEADS, XATTN_D, XATTN_MAX_KEYS, XATTN_TILE = 512, 8, 64, 96, 128
+
+
+def pack_xattn_weight(weight, kind, device=None):
+    """nn.Linear weight [512 out][512 in] of to_q (kind 'q') / to_out (kind 'out') -> the A-fragment stream the fused sub-layer
+    kernel walks: 1-KiB fragments of 32 rows x 16 k, lane (hi, l32) holds row l32 and k = 16 ks + 8 e2 + 4 hi + e1 in slots
+    e = 4 e2 + e1.  'q': head h, fragment g = (k-step g >> 1, channel tile g & 1) of rows 64 h + 32 tile + l32;
+    'out': head h, fragment g = (channel tile 2 (g >> 3) + (g & 1), k-step (g >> 1) & 3) of rows 32 tile + l32, k inside head h."""
+    w = weight.detach().float()
+    if tuple(w.shape) != (XATTN_C, XATTN_C):
+        raise _lib.UavError(f"fused cross-attention weights must be {XATTN_C}x{XATTN_C}, got {tuple(w.shape)}")
+    if kind == "q":
+        # rows = (h, mt, l32); k = (ks, e2, hi, e1)  ->  [h][ks][mt][hi][l32][e2][e1]
+        p = w.reshape(8, 2, 32, 32, 2, 2, 4).permute(0, 3, 1, 5, 2, 4, 6)
+    elif kind == "out":
+        # rows = (npair, par, l32) with tile = 2 npair + par; k = (h, ks, e2, hi, e1)  ->  [h][npair][ks][par][hi][l32][e2][e1]
+        p = w.reshape(8, 2, 32, 8, 4, 2, 2, 4).permute(3, 0, 4, 1, 6, 2, 5, 7)
+    else:
+        raise ValueError(kind)
+    out = p.contiguous().to(HALF).reshape(-1)
+    assert out.numel() == XATTN_C * XATTN_C
+    return out.to(device if device is not None else weight.device)
+
+
+def xattn_pack_kv(k, v, *, n_batch, lk, k_stride=None, v_stride=None):
+    """Text K / V rows (fp16 views of the fused k|v projection) -> fragment stream [n_batch][8][32 KiB]."""
+    lib = _lib.load()
+    out = torch.empty((n_batch, XATTN_HEADS, 32 * 64 * 8), dtype=HALF, device=k.device)
+    rc = lib.uav_xattn_pack_kv(_p(k), k_stride or k.stride(-2), _p(v), v_stride or v.stride(-2), n_batch, lk, XATTN_HEADS, XATTN_D,
+                               _p(out), _stream())
+    _lib.check(rc, "uav_xattn_pack_kv")
+    return out
+
+
+def xattn_ok(x, *, heads, head_dim, lk, rows_per_kv):
+    """Shapes the fused sub-layer kernel takes (else the caller keeps the four-launch chain)."""
+    return (x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == XATTN_C and heads == XATTN_HEADS and head_dim == XATTN_D
+            and 0 < lk <= XATTN_MAX_KEYS and rows_per_kv % XATTN_TILE == 0 and x.shape[0] % rows_per_kv == 0)
+
+
+def xattn_sublayer(x, gamma, beta, eps, wq_packed, kv_packed, wo_packed, out_bias, *, rows_per_kv, lk, scale, out=None):
+    """x + to_out(attention(to_q(LayerNorm(x)), K, V)) + bias on fp32 stream rows [M][512] in one launch."""
+    lib = _lib.load()
+    _req(x, torch.float32, "x")
+    m = x.shape[0]
+    y = torch.empty_like(x) if out is None else out
+    ev = PROFILER.begin("xattn_sublayer")
+    rc = lib.uav_xattn_sublayer_f32(_p(x), _p(y), _p(gamma), _p(beta), eps, _p(wq_packed), _p(kv_packed), _p(wo_packed), _p(out_bias),
+                                    m, rows_per_kv, lk, XATTN_C, XATTN_HEADS, scale, _stream())
+    _lib.check(rc, "uav_xattn_sublayer_f32")
+    PROFILER.end(ev, "xattn_sublayer", 2.0 * m * (2 * XATTN_C * XATTN_C) + 4.0 * m * lk * XATTN_C, 8.0 * m * XATTN_C)
+    return y
+
+
 def temporal_attention(qkv, *, n_batch, t_len, hw, c, heads, scale, rope_cos, rope_sin, rot_dim, bias):
     lib = _lib.load()
     _req(qkv, HALF, "qkv")
