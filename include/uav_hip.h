@@ -67,6 +67,12 @@ int  uav_device_check(int dev, char* name_out);
  * tiles, accumulators in the accumulator file) — same results bit for bit as the 8-wave kernel.  This flag keeps a launch in the
  * 8-wave kernel (A/B measurements and the bit-identity tests). */
 #define UAV_CONV_NO_W4 2048u
+/* Round 6: with UAV_CONV_OUT_F32, store every fp32 result v as the fp16 pair hi = fp16(v), lo = fp16(v - hi) instead: `out` is
+ * fp16 [M][out_stride >= 2 n], hi in columns 0 .. n-1, lo in n .. 2n-1 — the operand rows of a 1x1 consumer whose weights are
+ * repeated along K (block tails: the last feed-forward of a Transformer3DModel -> proj_out, attention.py:389-398; the tail ResNet of
+ * a TemporalModule3D -> shift_conv, temporal_module.py:175-194).  Bit-identical to the fp32 result followed by
+ * uav_cast_f32_hilo, without the pass.  Only launches uav_conv_gemm_hilo_ok() accepts. */
+#define UAV_CONV_OUT_HILO 4096u
 
 typedef struct {
     const void*  a1;            /* fp16 source 1, rows of c1 channels */
@@ -147,6 +153,9 @@ int uav_conv_gemm_ln_ok(const uav_conv_params* p);
  * launches, N tails, GEGLU / activation epilogues, groups of other than 4..128 channels): decide BEFORE setting
  * gn_partials — a launch that cannot honour the request returns UAV_ESHAPE.  Host-only, no device work. */
 int uav_conv_gemm_gn_chunk_rows(const uav_conv_params* p);
+/* 1 if this launch can store its result as the hi | lo pair (UAV_CONV_OUT_HILO): four-wave kernel, every wave tile on the
+ * row-coalesced fp32 epilogue with an fp32 residual (bias, M % 64 == 0, n % 128 == 0, no time-embedding row, no statistics) */
+int uav_conv_gemm_hilo_ok(const uav_conv_params* p);
 
 /* ---- K3: GroupNorm statistics + apply (+SiLU) ---------------------------------------
  * Replaces nn.GroupNorm on 5-D tensors (statistics over C/G x T x H x W: resnet.py:267,278,

@@ -24,7 +24,7 @@ def _h(x):
 # ---------------------------------------------------------------------------------------------------------------------
 def conv_gemm(a1, wt, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None, rowbias=None, rows_per_batch=0,
               residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None, persistent=False, act=None, gn_groups=None,
-              out_map=None, a2_center=False, ln_produce=False, ln_consume=None, gn_shared=None):
+              out_map=None, a2_center=False, ln_produce=False, ln_consume=None, gn_shared=None, out_hilo=False):
     c1 = a1.shape[-1]
     c2 = 0 if a2 is None else a2.shape[-1]
     assert c1 + c2 == wt.cin_p, (c1, c2, wt.cin_p)
@@ -84,6 +84,9 @@ def conv_gemm(a1, wt, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=Fals
         assert residual.shape[0] == m
         y = y + residual.float()[:, : y.shape[1]]
     y = y * out_scale
+    if out_hilo:                             # the fp32 result as its fp16 operand pair (UAV_CONV_OUT_HILO == cast_hilo of it)
+        assert out_f32 and out is None and out_map is None
+        return cast_hilo(y)
     res = y if out_f32 else _h(y)
     if ln_produce and out_f32 and res.shape[1] % 128 == 0 and out is None:
         from uav import ops as _ops
@@ -108,9 +111,10 @@ def _factor_rows(m):
 
 
 def linear(x, wt, *, residual=None, out_scale=1.0, rowbias=None, rows_per_batch=0, out_f32=False, act=None, gn_groups=None,
-           ln_produce=False, ln_consume=None):
+           ln_produce=False, ln_consume=None, out_hilo=False):
     return conv_gemm(x, wt, n_img=1, t_len=1, hi=x.shape[0], wi=1, residual=residual, out_scale=out_scale, rowbias=rowbias,
-                     rows_per_batch=rows_per_batch, out_f32=out_f32, act=act, ln_produce=ln_produce, ln_consume=ln_consume)
+                     rows_per_batch=rows_per_batch, out_f32=out_f32, act=act, ln_produce=ln_produce, ln_consume=ln_consume,
+                     out_hilo=out_hilo)
 
 
 def ln_fold_ok(m, k, wt):

@@ -1,0 +1,49 @@
+"""Prints the four asm walk macros of csrc/xattn_fused.hip (XG_WQ / XG_WO / XG_K / XG_V): the step sequence of a fragment group —
+D reads in flight, one MFMA per fragment with an exact lgkmcnt wait, the freed register refilled at once, and the eight LDS-DMA pieces
+of the group three ahead spread between the MFMAs (one piece per four MFMAs).  The macro text in the .hip file is this script's output
+(python tools/gen_xattn_groups.py); edit the schedule here."""
+D = 6                                  # fragment reads in flight
+
+
+def fmt(name, seq):
+    lines, cur = [], "    "
+    for s in seq:
+        if len(cur) + len(s) + 1 > 122:
+            lines.append(cur.rstrip()); cur = "    "
+        cur += s + " "
+    lines.append(cur.rstrip())
+    return f"#define {name} \\\n" + " \\\n".join(lines) + "\n"
+
+
+def group(n, base, cb, dma, first=False):
+    """n fragments at slot offsets (base + f) KiB; cb(f) -> (accumulator, B operand); dma: {step: piece} issued behind that step's MFMA;
+    first: the group opens its accumulators — the first MFMA on each takes the inline constant 0 as C (no zeroing, no live zero tuple)."""
+    out = [f"XRD(t{f}, {(base + f) * 1024})" for f in range(D)]
+    seen = set()
+    for f in range(n):
+        c, b = cb(f)
+        t = f"t{f % D}"
+        z = "0" if (first and c not in seen) else ""
+        seen.add(c)
+        if f + D < n:
+            out.append(f"XS{z}({t}, {c}, {b}, {D - 1}, {(base + f + D) * 1024})")
+        else:
+            out.append(f"XT{z}({t}, {c}, {b}, {min(D - 1, n - 1 - f)})")
+        if f in dma:
+            p = dma[f]
+            out.append(f"XD({p * 1024}, {(p & 3) * 1024})")
+            if p == 3:
+                out.append("XDADV")
+    return out
+
+
+if __name__ == "__main__":
+    d32 = {4 * i + 2: i for i in range(8)}                      # pieces 0..7 behind MFMAs 2, 6, ..., 30
+    dk = {1: 0, 4: 1, 7: 2, 10: 3}                              # K part: pieces 0..3
+    dv = {1: 4, 4: 5, 7: 6, 10: 7}                              # V part: pieces 4..7
+    txt = fmt("XG_WQ_FIRST", group(32, 0, lambda f: (f"q{f & 1}", f"b{f >> 1}"), d32, first=True)) + "\n"
+    txt += fmt("XG_WQ", group(32, 0, lambda f: (f"q{f & 1}", f"b{f >> 1}"), d32)) + "\n"
+    txt += fmt("XG_WO", group(32, 0, lambda f: (f"c{2 * (f >> 3) + (f & 1)}", f"b{(f >> 1) & 3}"), d32)) + "\n"
+    txt += fmt("XG_K", group(12, 0, lambda f: (f"c{f % 3}", f"b{f // 3}"), dk, first=True)) + "\n"
+    txt += fmt("XG_V", group(12, 12, lambda f: (f"c{f & 1}", f"b{f >> 1}"), dv, first=True))
+    print(txt, end="")

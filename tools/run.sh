@@ -98,7 +98,10 @@ PY
       done
       cat $L ;;
     xattn)    timeout 300 python $R/tools/bench_xattn.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_xattn_fused_vs_chain.jsonl ;;
-    xtests)   timeout 600 python -m pytest $R/tests/test_kernels_gpu.py -m gpu -x -q -k "fused_cross or attention" 2>&1 | tail -8 | tee $O/${TAG}_xattn_tests.log ;;
+    xtests)   timeout 600 python -m pytest $R/tests/test_kernels_gpu.py -m gpu -x -q -k "fused_cross or attention or hilo" 2>&1 | tail -8 | tee $O/${TAG}_xattn_tests.log ;;
+    bench1_tail) (cd $R && UAV_TAIL_HILO=1 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_tail_hilo.json) ;;
+    parity_head) (cd $R && rm -f gpurun_out/parity.jsonl; timeout 900 python -m pytest tests/test_parity_r4_gpu.py -m gpu -q -k "headline" 2>&1 | tail -6 | tee $O/${TAG}_parity_headline.log; mv gpurun_out/parity.jsonl $O/${TAG}_parity_headline.jsonl 2> /dev/null) ;;
+    parity_head_tail) (cd $R && rm -f gpurun_out/parity.jsonl; UAV_TAIL_HILO=1 timeout 900 python -m pytest tests/test_parity_r4_gpu.py -m gpu -q -k "headline" 2>&1 | tail -6 | tee $O/${TAG}_parity_headline_tail_hilo.log; mv gpurun_out/parity.jsonl $O/${TAG}_parity_headline_tail_hilo.jsonl 2> /dev/null) ;;
     bench1_nox) (cd $R && UAV_XATTN_FUSED=0 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_four_launch_chain.json) ;;
     t32)      (cd $R && rm -f gpurun_out/parity.jsonl; UAV_PARITY_T32=1 timeout 1500 python -m pytest tests/test_parity_r6_gpu.py -m gpu -q -x 2>&1 | tail -8 | tee $O/${TAG}_parity_t32.log; mv gpurun_out/parity.jsonl $O/${TAG}_parity_configs3_t32_320.jsonl 2> /dev/null) ;;
     bench1_cfgsplit) (cd $R && timeout 400 python bench.py --overlap-streams 2 --overlap-split-cfg --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_cfg_branches_on_two_streams.json) ;;

@@ -540,12 +540,13 @@ UAV_DEVINL int conv_co_kind(const ConvArgs& p, long long mw0, int nw0) {
     }
 }
 
-template <bool RES, int GNM, bool RB>
+template <bool RES, int GNM, bool RB, bool HILO = false>
 UAV_DEVINL void conv_epilogue_f32_lds(const ConvArgs& p, long long mw0, int nw0, unsigned lb, unsigned lr, unsigned lbuf) {
     constexpr int NI = 4, NK = 8;
     constexpr bool GN = GNM != 0;
     const float osc = p.out_scale;
-    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    if constexpr (HILO) asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\nv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));     // (see conv_w4_epilogue)
     const int tr = lane >> 3, tq = lane & 7;                 // row 8k + tr, columns 4 tq .. 4 tq + 3 of every 32-column block
     const unsigned rbase = lbuf + tr * CO_ROW + ((tq ^ tr) << 4);     // + k * 8 rows + ni * 128 B  ((8k + tr) & 7 == tr)
     float4_t R[RES ? NI : 1][NK];
@@ -582,7 +583,15 @@ UAV_DEVINL void conv_epilogue_f32_lds(const ConvArgs& p, long long mw0, int nw0,
                 if (RES) v += R[RES ? ni : 0][k][j];
                 o[j] = v * osc;
             }
-            *(float4_t*)(obase + (long long)orow[k] * p.out_stride + ni * 32) = o;
+            if constexpr (HILO) {          // block tails: the fp32 value leaves as the two fp16 operands of its 1x1 consumer, hi = fp16(v), lo = fp16(v - hi)
+                half4_t hv, lv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { hv[j] = (half_t)o[j]; lv[j] = (half_t)(o[j] - (float)hv[j]); }
+                half_t* const oh = (half_t*)p.out + (long long)orow[k] * p.out_stride + nw0 + 4 * tq + ni * 32;
+                *(half4_t*)oh = hv;
+                *(half4_t*)(oh + p.n) = lv;
+            } else
+                *(float4_t*)(obase + (long long)orow[k] * p.out_stride + ni * 32) = o;
             if (GN) {
                 s1[GN ? ni : 0] += (o[0] + o[1]) + (o[2] + o[3]);
                 s2[GN ? ni : 0] += (o[0] * o[0] + o[1] * o[1]) + (o[2] * o[2] + o[3] * o[3]);
@@ -924,12 +933,23 @@ UAV_DEVINL void conv_epilogue(const ConvArgs& p, float16_t (&acc)[NI][MI], long 
 }
 
 // One 64 x 128 half tile of the four-wave kernel: through LDS when it takes an fp32-result fast path, else the shared epilogue.
-template <int GNK>
+template <int GNK, bool HILO = false>
 UAV_DEVINL void conv_w4_epilogue(const ConvArgs& p, float16_t (&acc)[4][2], long long mw0, int nw0, int l32, int hi32,
                                  unsigned lb, unsigned lr, unsigned lbuf) {
+    if constexpr (HILO) {
+        // lane-derived address pieces of the epilogue re-derived HERE from a fresh lane id: kept live from the top of the kernel they
+        // were what hipcc spilled across the k-loop in this instance (4 VGPRs; the loop itself sits at exactly 256)
+        int lane_;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\nv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
+        l32 = lane_ & 31; hi32 = lane_ >> 5;
+    }
     const int kind = conv_co_kind<GNK>(p, mw0, nw0);
-    if (kind == 0) { conv_epilogue<4, 2, GNK, true, 0, true>(p, acc, mw0, nw0, l32, hi32, lb, lr); return; }
-    conv_co_dump<GNK == 2 ? 1 : 0>(acc, lbuf, l32, hi32);
+    if (!HILO && kind == 0) { conv_epilogue<4, 2, GNK, true, 0, true>(p, acc, mw0, nw0, l32, hi32, lb, lr); return; }
+    conv_co_dump<(GNK == 2) ? 1 : 0>(acc, lbuf, l32, hi32);
+    if constexpr (HILO) {                           // the kernel instance of UAV_CONV_OUT_HILO launches: every wave tile has kind != 0 (conv_hilo_ok)
+        conv_epilogue_f32_lds<true, 0, false, true>(p, mw0, nw0, lb, lr, lbuf);     // kind == 2 by contract: fp32 residual, no time-embedding row
+        return;
+    }
     if (kind == 2) conv_epilogue_f32_lds<true, GNK, false>(p, mw0, nw0, lb, lr, lbuf);
     else if (kind == 3) conv_epilogue_f32_lds<false, GNK, true>(p, mw0, nw0, lb, lr, lbuf);
     else conv_epilogue_f32_lds<false, GNK, false>(p, mw0, nw0, lb, lr, lbuf);
@@ -1756,7 +1776,9 @@ UAV_DEVINL uint4_t w4_srd(const char* base, unsigned bytes) {
 UAV_DEVINL unsigned udiv_magic(unsigned n, unsigned mul, unsigned sh) { return sh >= 32u ? n : (__umulhi(n, mul) >> sh); }
 
 // TR = 1: development instance (UAV_CONV_W4_TRACE=1) that stamps s_memtime at the phase boundaries of every workgroup.
-template <int GNK, int TR = 0>
+// HILO: the instance of UAV_CONV_OUT_HILO launches (a kernel of its own: one more epilogue instantiation inside the default
+// instance moved hipcc's allocation of the k-loop and spilled 4 VGPRs there — measured, round 6).
+template <int GNK, int TR = 0, bool HILO = false>
 __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -2087,10 +2109,10 @@ __global__ __launch_bounds__(256, 1) void conv_gemm256w_kernel(ConvArgs p) {
     // row-coalesced fp32 epilogues dump the half tile into this wave's quarter of the stage buffers: every wave's fragment reads must be done
     __builtin_amdgcn_s_barrier();
     const unsigned lbuf = ldsb + wave * CO_BYTES;
-    conv_w4_epilogue<GNK>(p, accA, m0 + wm * 128, n0 + wn * 128, l32, hi32, ldsepi + wn * 512,
+    conv_w4_epilogue<GNK, HILO>(p, accA, m0 + wm * 128, n0 + wn * 128, l32, hi32, ldsepi + wn * 512,
                           ldsepi + 1024 + (2 * wm) * 1024 + wn * 512, lbuf);
     if (TR) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ts[4] = __builtin_amdgcn_s_memtime(); }
-    conv_w4_epilogue<GNK>(p, accB, m0 + wm * 128 + 64, n0 + wn * 128, l32, hi32, ldsepi + wn * 512,
+    conv_w4_epilogue<GNK, HILO>(p, accB, m0 + wm * 128 + 64, n0 + wn * 128, l32, hi32, ldsepi + wn * 512,
                           ldsepi + 1024 + (2 * wm + 1) * 1024 + wn * 512, lbuf);
     if (TR) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2283,7 +2305,11 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
 #ifndef UAV_DEV_W4_GNK
 #define UAV_DEV_W4_GNK 0        // -DUAV_DEV_W4_GNK=1|2|3: the statistics-reducing instances
 #endif
+#ifdef UAV_DEV_W4_HILO
+    hipLaunchKernelGGL((conv_gemm256w_kernel<0, 0, true>), dim3(1), dim3(256), 2 * LSTAGE + LEPI_BYTES, (hipStream_t)stream, a);
+#else
     hipLaunchKernelGGL(conv_gemm256w_kernel<UAV_DEV_W4_GNK>, dim3(1), dim3(256), 2 * LSTAGE + LEPI_BYTES, (hipStream_t)stream, a);
+#endif
     return q ? 0 : 1;
 }
 #else
@@ -2332,6 +2358,17 @@ bool conv_uses_w4(const uav_conv_params* q) {
     const unsigned long long halo = 2ull * (((unsigned long long)q->pad_t * q->hi + q->pad_h) * q->wi + q->pad_w) + 16;   // pixels of displacement range
     if ((px + halo) * q->c1 * 2 >= 0xfffffff0ull || (a2px + halo) * q->c2 * 2 >= 0xfffffff0ull) return false;
     return conv_uses_big_tile(q);
+}
+// UAV_CONV_OUT_HILO (block tails written as the hi | lo fp16 operand pair of their 1x1 consumer): only the row-coalesced fp32
+// epilogue of the four-wave kernel stores that form, so the launch must run there and EVERY wave tile must take it (conv_co_kind).
+bool conv_hilo_ok(const uav_conv_params* q) {
+    if (!(q->flags & UAV_CONV_OUT_F32) || !conv_uses_w4(q)) return false;
+    const long long M = (long long)q->n_img * q->ho * q->wo;
+    const bool rf32 = q->flags & UAV_CONV_RES_F32;
+    if ((q->flags & (UAV_CONV_GELU | UAV_CONV_QUICK_GELU | UAV_CONV_GEGLU)) || !q->bias || (M % 64) || (q->n % 128) || (q->out_stride & 3) ||
+        q->out_stride < 2 * q->n || !q->residual || !rf32 || (q->res_stride & 3) || q->rowbias)
+        return false;                        // block tails are residual sums on the fp32 stream: the one epilogue form instantiated
+    return !q->gn_partials;                  // (the statistics instances do not carry the pair store)
 }
 // Short-K kernel: 1x1 / stride 1 launches of the big-tile class with K <= UAV_CONV_SK_MAXK and whole 256-column tiles.
 bool conv_uses_sk(const uav_conv_params* q) {
@@ -2396,6 +2433,11 @@ extern "C" int uav_conv_gemm_ln_ok(const uav_conv_params* q) {
     return conv_ln_ok(q) ? 1 : 0;
 }
 
+extern "C" int uav_conv_gemm_hilo_ok(const uav_conv_params* q) {
+    if (!q || q->n_pad <= 0) return 0;
+    return conv_hilo_ok(q) ? 1 : 0;
+}
+
 extern "C" int uav_conv_gemm_gn_chunk_rows(const uav_conv_params* q) {
     if (!q || q->n_pad <= 0 || q->gn_groups <= 0) return 0;
     return conv_gn_cpg_log2(q) >= 0 ? 64 : 0;
@@ -2418,6 +2460,7 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
     if ((q->flags & UAV_CONV_GEGLU) && ((q->flags & UAV_CONV_OUT_F32) || q->residual || q->rowbias || (q->n % 64)))
         return UAV_ESHAPE;
     if ((q->flags & UAV_CONV_RES_F32) && !q->residual) return UAV_EINVAL;
+    if ((q->flags & UAV_CONV_OUT_HILO) && !conv_hilo_ok(q)) return UAV_ESHAPE;      // ask uav_conv_gemm_hilo_ok() first
     if ((q->flags & (UAV_CONV_GELU | UAV_CONV_QUICK_GELU)) && (q->flags & UAV_CONV_GEGLU)) return UAV_ESHAPE;
     if (q->upsample && (q->stride != 1 || q->ho != 2 * q->hi || q->wo != 2 * q->wi)) return UAV_ESHAPE;
     if (q->t_len <= 0 || q->n_img % q->t_len) return UAV_ESHAPE;
@@ -2524,7 +2567,8 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
         if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAXDEV) return UAV_EINVAL;
         std::call_once(w4_once[dev], [] {
             const void* fns[] = {(const void*)conv_gemm256w_kernel<0>, (const void*)conv_gemm256w_kernel<1>,
-                                 (const void*)conv_gemm256w_kernel<2>, (const void*)conv_gemm256w_kernel<3>};
+                                 (const void*)conv_gemm256w_kernel<2>, (const void*)conv_gemm256w_kernel<3>,
+                                 (const void*)conv_gemm256w_kernel<0, 0, true>};
             for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * LSTAGE + LEPI_BYTES);
         });
         const unsigned long long px = (unsigned long long)q->n_img * q->hi * q->wi;
@@ -2560,7 +2604,8 @@ extern "C" int uav_conv_gemm_f16(const uav_conv_params* q, void* stream) {
                     sum[4] / grid256, tmax - tmin);
             return uav_launch_status();
         }
-        if (gnm == 0) hipLaunchKernelGGL(conv_gemm256w_kernel<0>, dim3((unsigned)grid256), dim3(256), lds, s, a);
+        if (q->flags & UAV_CONV_OUT_HILO) hipLaunchKernelGGL((conv_gemm256w_kernel<0, 0, true>), dim3((unsigned)grid256), dim3(256), lds, s, a);
+        else if (gnm == 0) hipLaunchKernelGGL(conv_gemm256w_kernel<0>, dim3((unsigned)grid256), dim3(256), lds, s, a);
         else if (gnm == 1) hipLaunchKernelGGL(conv_gemm256w_kernel<1>, dim3((unsigned)grid256), dim3(256), lds, s, a);
         else if (gnm == 2) hipLaunchKernelGGL(conv_gemm256w_kernel<2>, dim3((unsigned)grid256), dim3(256), lds, s, a);
         else hipLaunchKernelGGL(conv_gemm256w_kernel<3>, dim3((unsigned)grid256), dim3(256), lds, s, a);

@@ -13,7 +13,9 @@
 // the next one once the k index is read in the order  slot e of half h  <->  k = 16 ks + 8 (e >> 2) + 4 h + (e & 3)  (a contraction
 // index may be permuted freely as long as both operands agree).  All A operands — W_q, K, V^T, W_out — are therefore PRE-PACKED on
 // that k order into 1-KiB MFMA fragments (64 lanes x 16 B, exactly what one `ds_read_b128` hands a wave) and streamed in
-// consumption order through an LDS ring by LDS-DMA (`buffer_load ... lds`, contiguous 32-KiB groups straight from L2); nothing an
+// consumption order through an LDS ring by LDS-DMA (`buffer_load ... lds`, contiguous 32-KiB groups straight from L2, the pieces of
+// the group three ahead issued BETWEEN the MFMAs of the current one: in a burst behind the barrier they cost ~80 cycles each with the
+// matrix pipe idle — 0.98 ms per launch at M = 409 600 in the first version, run 1 of round 6); nothing an
 // accumulator holds ever moves between lanes except the two half-wave reductions of LayerNorm and softmax:
 //
 //   x (fp32, D layout) -> 256 accumulators (the residual is the accumulators' initial value) -> LayerNorm in registers ->
@@ -73,43 +75,63 @@ UAV_DEVINL float swap32(float v) { return __shfl_xor(v, 32, 64); }
 #define XMF(C, A, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #A "], %[" #B "], %[" #C "]\n"
 #define XS(T, C, B, WN, OFF) "s_waitcnt lgkmcnt(" #WN ")\n" XMF(C, T, B) XRD(T, OFF)
 #define XT(T, C, B, WN) "s_waitcnt lgkmcnt(" #WN ")\n" XMF(C, T, B)
+// the first MFMA on an accumulator: C = the inline constant 0 (the accumulator is a pure output: nothing to zero, no zero tuple kept live)
+#define XMF0(C, A, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #A "], %[" #B "], 0\n"
+#define XS0(T, C, B, WN, OFF) "s_waitcnt lgkmcnt(" #WN ")\n" XMF0(C, T, B) XRD(T, OFF)
+#define XT0(T, C, B, WN) "s_waitcnt lgkmcnt(" #WN ")\n" XMF0(C, T, B)
+// one 1-KiB LDS-DMA piece of the group three ahead, between two MFMAs: M0 = its place in the ring slot, 16 B per lane from
+// srd.base + voff + so + GOFF (XDADV steps `so` over the four pieces addressed through the 12-bit immediate)
+#define XD(LOFF, GOFF) "s_add_u32 m0, %[ldsn], " #LOFF "\n" "s_nop 0\n" "buffer_load_dwordx4 %[voff], %[srd], %[so] offen offset:" #GOFF " lds\n"
+#define XDADV "s_add_u32 %[so], %[so], 4096\n"
 // W_q group: fragment f = (k-step f >> 1, channel tile f & 1);  W_out group: (channel tile 2 (f >> 3) + (f & 1), k-step (f >> 1) & 3);
 // K: (key tile f % 3, k-step f / 3);  V^T (fragments 12 .. 23 of the K | V group): (k-step f >> 1, channel tile f & 1) — consecutive
 // MFMAs never share an accumulator.
+#define XG_WQ_FIRST \
+    XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XS0(t0, q0, b0, 5, 6144) \
+    XS0(t1, q1, b0, 5, 7168) XS(t2, q0, b1, 5, 8192) XD(0, 0) XS(t3, q1, b1, 5, 9216) XS(t4, q0, b2, 5, 10240) \
+    XS(t5, q1, b2, 5, 11264) XS(t0, q0, b3, 5, 12288) XD(1024, 1024) XS(t1, q1, b3, 5, 13312) XS(t2, q0, b4, 5, 14336) \
+    XS(t3, q1, b4, 5, 15360) XS(t4, q0, b5, 5, 16384) XD(2048, 2048) XS(t5, q1, b5, 5, 17408) XS(t0, q0, b6, 5, 18432) \
+    XS(t1, q1, b6, 5, 19456) XS(t2, q0, b7, 5, 20480) XD(3072, 3072) XDADV XS(t3, q1, b7, 5, 21504) \
+    XS(t4, q0, b8, 5, 22528) XS(t5, q1, b8, 5, 23552) XS(t0, q0, b9, 5, 24576) XD(4096, 0) XS(t1, q1, b9, 5, 25600) \
+    XS(t2, q0, b10, 5, 26624) XS(t3, q1, b10, 5, 27648) XS(t4, q0, b11, 5, 28672) XD(5120, 1024) \
+    XS(t5, q1, b11, 5, 29696) XS(t0, q0, b12, 5, 30720) XS(t1, q1, b12, 5, 31744) XT(t2, q0, b13, 5) XD(6144, 2048) \
+    XT(t3, q1, b13, 4) XT(t4, q0, b14, 3) XT(t5, q1, b14, 2) XT(t0, q0, b15, 1) XD(7168, 3072) XT(t1, q1, b15, 0)
+
 #define XG_WQ \
     XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XS(t0, q0, b0, 5, 6144) \
-    XS(t1, q1, b0, 5, 7168) XS(t2, q0, b1, 5, 8192) XS(t3, q1, b1, 5, 9216) XS(t4, q0, b2, 5, 10240) \
-    XS(t5, q1, b2, 5, 11264) XS(t0, q0, b3, 5, 12288) XS(t1, q1, b3, 5, 13312) XS(t2, q0, b4, 5, 14336) \
-    XS(t3, q1, b4, 5, 15360) XS(t4, q0, b5, 5, 16384) XS(t5, q1, b5, 5, 17408) XS(t0, q0, b6, 5, 18432) \
-    XS(t1, q1, b6, 5, 19456) XS(t2, q0, b7, 5, 20480) XS(t3, q1, b7, 5, 21504) XS(t4, q0, b8, 5, 22528) \
-    XS(t5, q1, b8, 5, 23552) XS(t0, q0, b9, 5, 24576) XS(t1, q1, b9, 5, 25600) XS(t2, q0, b10, 5, 26624) \
-    XS(t3, q1, b10, 5, 27648) XS(t4, q0, b11, 5, 28672) XS(t5, q1, b11, 5, 29696) XS(t0, q0, b12, 5, 30720) \
-    XS(t1, q1, b12, 5, 31744) XT(t2, q0, b13, 5) XT(t3, q1, b13, 4) XT(t4, q0, b14, 3) XT(t5, q1, b14, 2) \
-    XT(t0, q0, b15, 1) XT(t1, q1, b15, 0)
+    XS(t1, q1, b0, 5, 7168) XS(t2, q0, b1, 5, 8192) XD(0, 0) XS(t3, q1, b1, 5, 9216) XS(t4, q0, b2, 5, 10240) \
+    XS(t5, q1, b2, 5, 11264) XS(t0, q0, b3, 5, 12288) XD(1024, 1024) XS(t1, q1, b3, 5, 13312) XS(t2, q0, b4, 5, 14336) \
+    XS(t3, q1, b4, 5, 15360) XS(t4, q0, b5, 5, 16384) XD(2048, 2048) XS(t5, q1, b5, 5, 17408) XS(t0, q0, b6, 5, 18432) \
+    XS(t1, q1, b6, 5, 19456) XS(t2, q0, b7, 5, 20480) XD(3072, 3072) XDADV XS(t3, q1, b7, 5, 21504) \
+    XS(t4, q0, b8, 5, 22528) XS(t5, q1, b8, 5, 23552) XS(t0, q0, b9, 5, 24576) XD(4096, 0) XS(t1, q1, b9, 5, 25600) \
+    XS(t2, q0, b10, 5, 26624) XS(t3, q1, b10, 5, 27648) XS(t4, q0, b11, 5, 28672) XD(5120, 1024) \
+    XS(t5, q1, b11, 5, 29696) XS(t0, q0, b12, 5, 30720) XS(t1, q1, b12, 5, 31744) XT(t2, q0, b13, 5) XD(6144, 2048) \
+    XT(t3, q1, b13, 4) XT(t4, q0, b14, 3) XT(t5, q1, b14, 2) XT(t0, q0, b15, 1) XD(7168, 3072) XT(t1, q1, b15, 0)
 
 #define XG_WO \
     XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XS(t0, c0, b0, 5, 6144) \
-    XS(t1, c1, b0, 5, 7168) XS(t2, c0, b1, 5, 8192) XS(t3, c1, b1, 5, 9216) XS(t4, c0, b2, 5, 10240) \
-    XS(t5, c1, b2, 5, 11264) XS(t0, c0, b3, 5, 12288) XS(t1, c1, b3, 5, 13312) XS(t2, c2, b0, 5, 14336) \
-    XS(t3, c3, b0, 5, 15360) XS(t4, c2, b1, 5, 16384) XS(t5, c3, b1, 5, 17408) XS(t0, c2, b2, 5, 18432) \
-    XS(t1, c3, b2, 5, 19456) XS(t2, c2, b3, 5, 20480) XS(t3, c3, b3, 5, 21504) XS(t4, c4, b0, 5, 22528) \
-    XS(t5, c5, b0, 5, 23552) XS(t0, c4, b1, 5, 24576) XS(t1, c5, b1, 5, 25600) XS(t2, c4, b2, 5, 26624) \
-    XS(t3, c5, b2, 5, 27648) XS(t4, c4, b3, 5, 28672) XS(t5, c5, b3, 5, 29696) XS(t0, c6, b0, 5, 30720) \
-    XS(t1, c7, b0, 5, 31744) XT(t2, c6, b1, 5) XT(t3, c7, b1, 4) XT(t4, c6, b2, 3) XT(t5, c7, b2, 2) XT(t0, c6, b3, 1) \
-    XT(t1, c7, b3, 0)
+    XS(t1, c1, b0, 5, 7168) XS(t2, c0, b1, 5, 8192) XD(0, 0) XS(t3, c1, b1, 5, 9216) XS(t4, c0, b2, 5, 10240) \
+    XS(t5, c1, b2, 5, 11264) XS(t0, c0, b3, 5, 12288) XD(1024, 1024) XS(t1, c1, b3, 5, 13312) XS(t2, c2, b0, 5, 14336) \
+    XS(t3, c3, b0, 5, 15360) XS(t4, c2, b1, 5, 16384) XD(2048, 2048) XS(t5, c3, b1, 5, 17408) XS(t0, c2, b2, 5, 18432) \
+    XS(t1, c3, b2, 5, 19456) XS(t2, c2, b3, 5, 20480) XD(3072, 3072) XDADV XS(t3, c3, b3, 5, 21504) \
+    XS(t4, c4, b0, 5, 22528) XS(t5, c5, b0, 5, 23552) XS(t0, c4, b1, 5, 24576) XD(4096, 0) XS(t1, c5, b1, 5, 25600) \
+    XS(t2, c4, b2, 5, 26624) XS(t3, c5, b2, 5, 27648) XS(t4, c4, b3, 5, 28672) XD(5120, 1024) XS(t5, c5, b3, 5, 29696) \
+    XS(t0, c6, b0, 5, 30720) XS(t1, c7, b0, 5, 31744) XT(t2, c6, b1, 5) XD(6144, 2048) XT(t3, c7, b1, 4) \
+    XT(t4, c6, b2, 3) XT(t5, c7, b2, 2) XT(t0, c6, b3, 1) XD(7168, 3072) XT(t1, c7, b3, 0)
 
 #define XG_K \
-    XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XS(t0, c0, b0, 5, 6144) \
-    XS(t1, c1, b0, 5, 7168) XS(t2, c2, b0, 5, 8192) XS(t3, c0, b1, 5, 9216) XS(t4, c1, b1, 5, 10240) \
-    XS(t5, c2, b1, 5, 11264) XT(t0, c0, b2, 5) XT(t1, c1, b2, 4) XT(t2, c2, b2, 3) XT(t3, c0, b3, 2) XT(t4, c1, b3, 1) \
-    XT(t5, c2, b3, 0)
+    XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XS0(t0, c0, b0, 5, 6144) \
+    XS0(t1, c1, b0, 5, 7168) XD(0, 0) XS0(t2, c2, b0, 5, 8192) XS(t3, c0, b1, 5, 9216) XS(t4, c1, b1, 5, 10240) \
+    XD(1024, 1024) XS(t5, c2, b1, 5, 11264) XT(t0, c0, b2, 5) XT(t1, c1, b2, 4) XD(2048, 2048) XT(t2, c2, b2, 3) \
+    XT(t3, c0, b3, 2) XT(t4, c1, b3, 1) XD(3072, 3072) XDADV XT(t5, c2, b3, 0)
 
 #define XG_V \
-    XRD(t0, 12288) XRD(t1, 13312) XRD(t2, 14336) XRD(t3, 15360) XRD(t4, 16384) XRD(t5, 17408) XS(t0, c0, b0, 5, 18432) \
-    XS(t1, c1, b0, 5, 19456) XS(t2, c0, b1, 5, 20480) XS(t3, c1, b1, 5, 21504) XS(t4, c0, b2, 5, 22528) \
-    XS(t5, c1, b2, 5, 23552) XT(t0, c0, b3, 5) XT(t1, c1, b3, 4) XT(t2, c0, b4, 3) XT(t3, c1, b4, 2) XT(t4, c0, b5, 1) \
-    XT(t5, c1, b5, 0)
-#define XTMP_OUT [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5)
+    XRD(t0, 12288) XRD(t1, 13312) XRD(t2, 14336) XRD(t3, 15360) XRD(t4, 16384) XRD(t5, 17408) XS0(t0, c0, b0, 5, 18432) \
+    XS0(t1, c1, b0, 5, 19456) XD(4096, 0) XS(t2, c0, b1, 5, 20480) XS(t3, c1, b1, 5, 21504) XS(t4, c0, b2, 5, 22528) \
+    XD(5120, 1024) XS(t5, c1, b2, 5, 23552) XT(t0, c0, b3, 5) XT(t1, c1, b3, 4) XD(6144, 2048) XT(t2, c0, b4, 3) \
+    XT(t3, c1, b4, 2) XT(t4, c0, b5, 1) XD(7168, 3072) XT(t5, c1, b5, 0)
+#define XTMP_OUT [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [so] "+s"(nx.so)
+#define XDMA_IN [ldsn] "s"(nx.ldsn), [srd] "s"(nx.srd), [voff] "v"(voff)
 
 __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -125,28 +147,34 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
     const uint4_t srd_wo = make_srd(p.wo, XHEADS * 2 * XGROUP);
     const uint4_t srd_kv = make_srd(p.kv + (long long)b * XHEADS * XGROUP, XHEADS * XGROUP);
     const unsigned voff = (unsigned)(wave * XPPW * XFRAG + lane * 16);
-    auto issue = [&](int h, int j) {                       // group j (0, 1: W_q; 2: K | V; 3, 4: W_out) of head h
-        const unsigned dst = lds0 + (unsigned)(((h * XGPH + j) & (XRING - 1)) * XGROUP + wave * XPPW * XFRAG);
-        uint4_t srd; unsigned so;
-        if (j < 2) { srd = srd_wq; so = (unsigned)((h * 2 + j) * XGROUP); }
-        else if (j == 2) { srd = srd_kv; so = (unsigned)(h * XGROUP); }
-        else { srd = srd_wo; so = (unsigned)((h * 2 + (j - 3)) * XGROUP); }
-#pragma unroll
-        for (int i = 0; i < XPPW; ++i) dma_piece(srd, voff, so + i * XFRAG, dst + i * XFRAG);
-    };
-    // before group (h, j) is read: this wave's pieces of it have landed (the XRING - 2 groups issued behind it may still fly), then
-    // every wave's have (barrier) — which also says every wave is done with the group before it, whose slot the group XRING - 1
-    // ahead now overwrites.  Returns the slot's LDS address for this lane.
-    auto group_sync = [&](int h, int j) -> unsigned {
+    struct Next { uint4_t srd; unsigned so, ldsn; };       // the group XRING - 1 = 3 ahead: its source and its ring slot
+    auto next_of = [&](int h, int j) -> Next {            // (h, j): group j (0, 1: W_q; 2: K | V; 3, 4: W_out) of head h
+        Next n;
         const int s = h * XGPH + j;
-        const int behind = XNG - 1 - s;                    // groups issued after s so far (capped by the ring)
-        if (behind >= XRING - 2) wait_vmcnt<XPPW * (XRING - 2)>();
-        else if (behind == 1) wait_vmcnt<XPPW>();
-        else wait_vmcnt<0>();
+        n.ldsn = lds0 + (unsigned)((s & (XRING - 1)) * XGROUP + wave * XPPW * XFRAG);
+        if (j < 2) { n.srd = srd_wq; n.so = (unsigned)((h * 2 + j) * XGROUP); }
+        else if (j == 2) { n.srd = srd_kv; n.so = (unsigned)(h * XGROUP); }
+        else { n.srd = srd_wo; n.so = (unsigned)((h * 2 + (j - 3)) * XGROUP); }
+        // behind the last group of the tile: the same eight pieces with every lane out of the descriptor's range — the hardware fetches
+        // nothing and zero-fills a slot nobody reads again, and the vmcnt arithmetic below stays the same for every group
+        if (s >= XNG) n.so = 0x80000000u;
+        return n;
+    };
+    auto issue = [&](int h, int j) {                       // prologue: a whole group at once
+        Next n = next_of(h, j);
+#pragma unroll
+        for (int i = 0; i < XPPW; ++i) dma_piece(n.srd, voff, n.so + i * XFRAG, n.ldsn + i * XFRAG);
+    };
+    // before group (h, j) is read: this wave's pieces of it have landed (the two groups issued behind it may still fly: 16 pieces),
+    // then every wave's have (barrier) — which also says every wave is done with the group before it, whose slot the group three
+    // ahead is written into WHILE this group is multiplied (the pieces sit between the MFMAs of the asm walk).
+    Next nx;
+    auto group_sync = [&](int h, int j) -> unsigned {
+        wait_vmcnt<XPPW * (XRING - 2)>();
         __syncthreads();
-        const int jn = j + XRING - 1;                      // the group XRING - 1 = 3 ahead: (h, j + 3) or (h + 1, j - 2)
-        if (s + XRING - 1 < XNG) issue(jn < XGPH ? h : h + 1, jn < XGPH ? jn : jn - XGPH);
-        return lds0 + (unsigned)((s & (XRING - 1)) * XGROUP) + lane * 16;
+        const int jn = j + XRING - 1;                      // (h, j + 3) or (h + 1, j - 2)
+        nx = next_of(jn < XGPH ? h : h + 1, jn < XGPH ? jn : jn - XGPH);
+        return lds0 + (unsigned)(((h * XGPH + j) & (XRING - 1)) * XGROUP) + lane * 16;
     };
 
 #pragma unroll
@@ -209,30 +237,34 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
         half8_t t0, t1, t2, t3, t4, t5;
         // Q_h^T [64 ch][32 tokens] = Wq_h . Xn^T
         float16_t q0, q1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { q0[r] = 0.f; q1[r] = 0.f; }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        {
+            const unsigned st = group_sync(h, 0);
+            const int j = 0;
+            asm volatile(XG_WQ_FIRST : [q0] "=&v"(q0), [q1] "=&v"(q1), XTMP_OUT
+                         : [st] "v"(st), [b0] "v"(xn[16 * j + 0]), [b1] "v"(xn[16 * j + 1]), [b2] "v"(xn[16 * j + 2]), [b3] "v"(xn[16 * j + 3]),
+                           [b4] "v"(xn[16 * j + 4]), [b5] "v"(xn[16 * j + 5]), [b6] "v"(xn[16 * j + 6]), [b7] "v"(xn[16 * j + 7]),
+                           [b8] "v"(xn[16 * j + 8]), [b9] "v"(xn[16 * j + 9]), [b10] "v"(xn[16 * j + 10]), [b11] "v"(xn[16 * j + 11]),
+                           [b12] "v"(xn[16 * j + 12]), [b13] "v"(xn[16 * j + 13]), [b14] "v"(xn[16 * j + 14]), [b15] "v"(xn[16 * j + 15]), XDMA_IN
+                         : "memory", "scc");
+        }
+        {
+            const int j = 1;
             const unsigned st = group_sync(h, j);
             asm volatile(XG_WQ : [q0] "+v"(q0), [q1] "+v"(q1), XTMP_OUT
                          : [st] "v"(st), [b0] "v"(xn[16 * j + 0]), [b1] "v"(xn[16 * j + 1]), [b2] "v"(xn[16 * j + 2]), [b3] "v"(xn[16 * j + 3]),
                            [b4] "v"(xn[16 * j + 4]), [b5] "v"(xn[16 * j + 5]), [b6] "v"(xn[16 * j + 6]), [b7] "v"(xn[16 * j + 7]),
                            [b8] "v"(xn[16 * j + 8]), [b9] "v"(xn[16 * j + 9]), [b10] "v"(xn[16 * j + 10]), [b11] "v"(xn[16 * j + 11]),
-                           [b12] "v"(xn[16 * j + 12]), [b13] "v"(xn[16 * j + 13]), [b14] "v"(xn[16 * j + 14]), [b15] "v"(xn[16 * j + 15])
-                         : "memory");
+                           [b12] "v"(xn[16 * j + 12]), [b13] "v"(xn[16 * j + 13]), [b14] "v"(xn[16 * j + 14]), [b15] "v"(xn[16 * j + 15]), XDMA_IN
+                         : "memory", "scc");
         }
         half8_t qf[4];                                      // Q rounded to fp16 like the stored q of the unfused chain
 #pragma unroll
         for (int e = 0; e < 8; ++e) { qf[0][e] = (half_t)q0[e]; qf[1][e] = (half_t)q0[8 + e]; qf[2][e] = (half_t)q1[e]; qf[3][e] = (half_t)q1[8 + e]; }
         // S^T [96 keys][32 tokens] = K_h . Q^T
         float16_t sacc[3];
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[t][r] = 0.f;
         const unsigned stkv = group_sync(h, 2);
-        asm volatile(XG_K : [c0] "+v"(sacc[0]), [c1] "+v"(sacc[1]), [c2] "+v"(sacc[2]), XTMP_OUT
-                     : [st] "v"(stkv), [b0] "v"(qf[0]), [b1] "v"(qf[1]), [b2] "v"(qf[2]), [b3] "v"(qf[3]) : "memory");
+        asm volatile(XG_K : [c0] "=&v"(sacc[0]), [c1] "=&v"(sacc[1]), [c2] "=&v"(sacc[2]), XTMP_OUT
+                     : [st] "v"(stkv), [b0] "v"(qf[0]), [b1] "v"(qf[1]), [b2] "v"(qf[2]), [b3] "v"(qf[3]), XDMA_IN : "memory", "scc");
         // softmax over the keys: this lane holds keys 32 t + (r & 3) + 8 (r >> 2) + 4 hi, lane ^ 32 the others
         float mx = -INFINITY;
 #pragma unroll
@@ -248,22 +280,22 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
         float ps = 0.f;
         half8_t pf[6];                                      // P^T B fragments: k-step 2 t + (r >> 3)
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < 3; ++t) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float e = __builtin_amdgcn_exp2f(sacc[t][r] - mx);
                 ps += e;
                 pf[2 * t + (r >> 3)][r & 7] = (half_t)e;
             }
+            __builtin_amdgcn_sched_barrier(0);              // one key tile at a time: hipcc otherwise keeps all 48 exponentials in fp32 beside S and P
+        }
         ps += swap32(ps);
         const float inv = 1.0f / ps;
         // O^T [64 ch][32 tokens] = V_h^T . P^T (same LDS slot, fragments 12 .. 23)
         float16_t o0, o1;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-        asm volatile(XG_V : [c0] "+v"(o0), [c1] "+v"(o1), XTMP_OUT
-                     : [st] "v"(stkv), [b0] "v"(pf[0]), [b1] "v"(pf[1]), [b2] "v"(pf[2]), [b3] "v"(pf[3]), [b4] "v"(pf[4]), [b5] "v"(pf[5])
-                     : "memory");
+        asm volatile(XG_V : [c0] "=&v"(o0), [c1] "=&v"(o1), XTMP_OUT
+                     : [st] "v"(stkv), [b0] "v"(pf[0]), [b1] "v"(pf[1]), [b2] "v"(pf[2]), [b3] "v"(pf[3]), [b4] "v"(pf[4]), [b5] "v"(pf[5]), XDMA_IN
+                     : "memory", "scc");
         half8_t of[4];                                      // O / l rounded to fp16 like the stored attention output
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -276,10 +308,11 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
             const unsigned st = group_sync(h, 3 + j);
             asm volatile(XG_WO : [c0] "+a"(acc[8 * j + 0]), [c1] "+a"(acc[8 * j + 1]), [c2] "+a"(acc[8 * j + 2]), [c3] "+a"(acc[8 * j + 3]),
                            [c4] "+a"(acc[8 * j + 4]), [c5] "+a"(acc[8 * j + 5]), [c6] "+a"(acc[8 * j + 6]), [c7] "+a"(acc[8 * j + 7]), XTMP_OUT
-                         : [st] "v"(st), [b0] "v"(of[0]), [b1] "v"(of[1]), [b2] "v"(of[2]), [b3] "v"(of[3]) : "memory");
+                         : [st] "v"(st), [b0] "v"(of[0]), [b1] "v"(of[1]), [b2] "v"(of[2]), [b3] "v"(of[3]), XDMA_IN : "memory", "scc");
         }
     }
 
+    wait_vmcnt<0>();                                       // the zero-fill pieces behind the last group (LDS-DMA must not outlive the workgroup)
     // ---- store ------------------------------------------------------------------------------------------------------------------
     {
         float* orow = p.out + row * XC + 4 * hi;

@@ -184,9 +184,12 @@ class FeedForward(E.EngineModule):
         inner = int(dim * mult)
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim_out or dim)])
 
-    def run(self, x, residual, out_f32=None, ln=None):
+    def run(self, x, residual, out_f32=None, ln=None, out_hilo=False):
+        """out_hilo (fp32 stream): the fp32 sum leaves as the fp16 hi | lo operand pair of proj_out ([M][2 C], engine.tail_hilo)."""
         h = ops.linear(x, E.packed_conv(self, "up", self.net[0].proj, geglu=True)) if ln is None else \
             E.ln_linear(self, "up", ln, x, [self.net[0].proj], geglu=True)
+        if out_hilo:
+            return ops.linear(h, E.packed_conv(self, "down", self.net[2]), residual=residual, out_f32=True, out_hilo=True)
         return ops.linear(h, E.packed_conv(self, "down", self.net[2]), residual=residual,
                           out_f32=(residual.dtype == torch.float32) if out_f32 is None else out_f32)
 
@@ -230,9 +233,10 @@ class BasicTransformerBlock(E.EngineModule):
         c.store[("textkv", tag)] = ((ehs_rows, ehs_rows._version, kv, wstamp),) + tuple(hits)[:TEXT_KV_ENTRIES - 1]
         return kv
 
-    def run(self, x, g: E.Geom, ehs_rows, n_text, out_f32=None):
+    def run(self, x, g: E.Geom, ehs_rows, n_text, out_f32=None, out_hilo=False):
         """x: tokens [B*T*HW][C] (rows ordered b,t,p), fp16 or fp32 (residual stream); ehs_rows: [B*n_text][Cx] fp16.
-        out_f32=False: the block's output is only read as an MFMA operand (proj_out) -> written in fp16."""
+        out_f32=False: the block's output is only read as an MFMA operand (proj_out) -> written in fp16;
+        out_hilo: ... as the fp16 hi | lo pair of the fp32 rows instead (FeedForward.run)."""
         bq, lq = g.n_img, g.hw
         # every LayerNorm is handed to its consumer together with the un-normalised stream: engine.ln_linear folds it into
         # the projection when the stream is fp32 and its producer wrote the operand copy, else runs the LayerNorm pass
@@ -245,7 +249,7 @@ class BasicTransformerBlock(E.EngineModule):
             k, v, kvp = self._text_kv(self.attn2, ehs_rows, "a2", n_text)
             x = self.attn2.run(x, x, bq=bq, lq=lq, text=(k, v, n_text, kvp), q_per_kv=g.t, ln=self.norm2)
         x = self.attn_temporal.run_temporal(x, x, g, ln=self.norm_temporal)
-        return self.ff.run(x, x, out_f32, ln=self.norm3)
+        return self.ff.run(x, x, out_f32, ln=self.norm3, out_hilo=out_hilo)
 
 
 class Transformer3DModel(ModelMixin, ConfigMixin, E.EngineModule):
@@ -281,9 +285,10 @@ class Transformer3DModel(ModelMixin, ConfigMixin, E.EngineModule):
         tail_hilo = tok32 and E.tail_hilo()
         for i, blk in enumerate(self.transformer_blocks):
             # proj_out reads the last block's output as an operand: fp16, or (TAIL_HILO) the fp32 rows as a hi | lo pair
-            tok = blk.run(tok, g, ehs_rows, n_text, out_f32=False if (i == last and not tail_hilo) else None)
-        if tail_hilo:
-            return ops.linear(E.hilo_rows(tok), E.packed_conv_hilo(self, "proj_out", self.proj_out), residual=res, out_f32=s32,
+            tok = blk.run(tok, g, ehs_rows, n_text, out_f32=False if (i == last and not tail_hilo) else None,
+                          out_hilo=(i == last and tail_hilo))
+        if tail_hilo:          # the last feed-forward wrote the hi | lo pair itself (ops.conv_gemm out_hilo; a cast pass where it cannot)
+            return ops.linear(tok, E.packed_conv_hilo(self, "proj_out", self.proj_out), residual=res, out_f32=s32,
                               gn_groups=self.norm.num_groups)
         return ops.linear(tok, E.packed_conv(self, "proj_out", self.proj_out), residual=res, out_f32=s32,
                           gn_groups=self.norm.num_groups)

@@ -44,7 +44,7 @@ class InflatedConv3d(nn.Conv2d, E.EngineModule):
     """Per-frame 2-D convolution on a video tensor (reference resnet.py:94-101)."""
 
     def run(self, x, g: E.Geom, *, x2=None, residual=None, out_scale=1.0, upsample=False, out_f32=False, rowbias=None,
-            out_hw=None, out=None, gn_groups=None, hilo=False):
+            out_hw=None, out=None, gn_groups=None, hilo=False, out_hilo=False):
         """gn_groups: the output is (probably) normalised next by a GroupNorm of that many groups — the epilogue then
         reduces its statistics partials where it can (ops.conv_gemm); a wrong guess only costs the unused partials.
         hilo: x carries [hi | lo] fp16 halves of fp32 rows (2*C_in channels per pixel), the weights are repeated along C_in."""
@@ -52,7 +52,7 @@ class InflatedConv3d(nn.Conv2d, E.EngineModule):
         return ops.conv_gemm(x, cw, a2=x2, n_img=g.n_img, t_len=g.t, hi=g.h, wi=g.w, stride=self.stride[0],
                              pad=(0, self.padding[0], self.padding[1]), upsample=upsample, residual=residual,
                              out_scale=out_scale, out_f32=out_f32, rowbias=rowbias, rows_per_batch=g.rows_per_batch,
-                             out_hw=out_hw, out=out, gn_groups=gn_groups)
+                             out_hw=out_hw, out=out, gn_groups=gn_groups, out_hilo=out_hilo)
 
     def out_geom(self, g: E.Geom, upsample=False):
         if upsample:
@@ -69,11 +69,11 @@ class InflatedConv3d(nn.Conv2d, E.EngineModule):
 class Conv3dK11(nn.Conv3d, E.EngineModule):
     """nn.Conv3d container (temporal (k,1,1) and 3x3x3 kernels) executed by the implicit GEMM."""
 
-    def run(self, x, g: E.Geom, *, residual=None, out_scale=1.0, rowbias=None, out_f32=False, gn_groups=None):
+    def run(self, x, g: E.Geom, *, residual=None, out_scale=1.0, rowbias=None, out_f32=False, gn_groups=None, out_hilo=False):
         cw = E.packed_conv(self, "w", self)
         return ops.conv_gemm(x, cw, n_img=g.n_img, t_len=g.t, hi=g.h, wi=g.w, stride=1, pad=tuple(self.padding),
                              residual=residual, out_scale=out_scale, rowbias=rowbias, rows_per_batch=g.rows_per_batch,
-                             out_f32=out_f32, gn_groups=gn_groups)
+                             out_f32=out_f32, gn_groups=gn_groups, out_hilo=out_hilo)
 
 
 class Upsample3D(E.EngineModule):
@@ -199,8 +199,10 @@ class _ResnetBase(E.EngineModule):
         self.use_in_shortcut = in_channels != out_channels if use_in_shortcut is None else use_in_shortcut
         self.conv_shortcut = make_shortcut(in_channels, out_channels) if self.use_in_shortcut else None
 
-    def run(self, x, g: E.Geom, temb=None, x2=None, c_real=None, stream_f32=None, out_f32=None):
+    def run(self, x, g: E.Geom, temb=None, x2=None, c_real=None, stream_f32=None, out_f32=None, out_hilo=False):
         """x (and optional channel-concatenated x2): rows of in_channels; temb: fp32 [B][temb_ch].
+        out_hilo (fp32 stream, identity shortcut): the block's fp32 output leaves as the fp16 hi | lo operand pair of a 1x1 consumer
+        ([M][2 C], engine.tail_hilo), written by conv2's epilogue.
         out_f32=False: the block's OUTPUT is only ever read as an MFMA operand (TemporalModule3D's tail block feeds the
         1x1 shift_conv), so it is written in fp16 even when the block runs on an fp32 stream.
 
@@ -251,6 +253,10 @@ class _ResnetBase(E.EngineModule):
             if s32 and x.dtype != torch.float32:
                 raise ops._lib.UavError("fp32 stream requested for an fp16 identity shortcut")
             res = x
+        if out_hilo:
+            if not o32:
+                raise ops._lib.UavError("out_hilo needs an fp32 result")
+            return self.conv2.run(h, g, residual=res, out_scale=osc, out_f32=True, out_hilo=True)
         # the block's output is the stream the next block normalises (with this block's group count, as a rule)
         return self.conv2.run(h, g, residual=res, out_scale=osc, out_f32=o32, gn_groups=self.norm2.num_groups)
 

@@ -45,11 +45,12 @@ class TemporalModule3D(E.EngineModule):
         h = self.resblocks_3d_temporal.run(x, g, temb)
         tail_hilo = s32 and E.tail_hilo() and self.in_channels % 64 == 0
         # the tail block's output is only read as shift_conv's MFMA operand: fp16, or (TAIL_HILO) fp32 rows as a hi | lo pair
-        h = self.resblocks_3d_spatial.run(h, g, temb, out_f32=None if tail_hilo else False)
+        fused_pair = tail_hilo and self.resblocks_3d_spatial.conv_shortcut is None      # conv2's epilogue writes the pair (no cast pass)
+        h = self.resblocks_3d_spatial.run(h, g, temb, out_f32=None if tail_hilo else False, out_hilo=fused_pair)
         if w != 1.0:
             raise NotImplementedError("w != 1 is never used by the pipeline")
         if tail_hilo:
-            return self.shift_conv.run(E.hilo_rows(h), g, residual=x, out_f32=s32, gn_groups=E.GN_GROUPS_HINT, hilo=True)
+            return self.shift_conv.run(h if fused_pair else E.hilo_rows(h), g, residual=x, out_f32=s32, gn_groups=E.GN_GROUPS_HINT, hilo=True)
         return self.shift_conv.run(h, g, residual=x, out_f32=s32, gn_groups=E.GN_GROUPS_HINT)
 
     def forward(self, hidden_states, w=1, encoder_hidden_states=None, timesteps=None, temb=None, attention_mask=None):

@@ -46,6 +46,7 @@ CONV_RES_F32 = 128
 CONV_GELU, CONV_QUICK_GELU = 256, 512
 CONV_NO_SHORTK = 1024
 CONV_NO_W4 = 2048
+CONV_OUT_HILO = 4096
 CONV_RELU, CONV_SIGMOID, CONV_TANH = 4, 8, 16
 
 # name -> (restype, argtypes); the complete export list of include/uav_hip.h
@@ -54,6 +55,7 @@ SIGNATURES = {
     "uav_device_check": (C.c_int, [C.c_int, C.c_char_p]),
     "uav_conv_gemm_f16": (C.c_int, [C.POINTER(ConvParams), c_p]),
     "uav_conv_gemm_gn_chunk_rows": (C.c_int, [C.POINTER(ConvParams)]),
+    "uav_conv_gemm_hilo_ok": (C.c_int, [C.POINTER(ConvParams)]),
     "uav_groupnorm_finalize_partials": (C.c_int, [c_p, i64, i32, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p]),
     "uav_groupnorm_workspace_bytes": (i64, [i32, i32]),
     "uav_groupnorm_scale_shift": (C.c_int, [c_p, c_p, i32, i32, i32, i64, i32, i32, i64, i32, f32, c_p, c_p, c_p, c_p, c_p, i64, c_p]),

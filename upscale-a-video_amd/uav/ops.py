@@ -246,8 +246,11 @@ def upsample_phase_weights(weight):
 def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsample=False, a2=None,
               rowbias=None, rows_per_batch=0, residual=None, out_scale=1.0, out_f32=False, out=None, out_hw=None,
               persistent=False, act=None, gn_groups=None, out_map=None, a2_center=False, ln_produce=False, ln_consume=None,
-              gn_shared=None, no_shortk=False, no_w4=False):
+              gn_shared=None, no_shortk=False, no_w4=False, out_hilo=False):
     """out[M][n_out] = scale*(conv(a1|a2, W) + bias + rowbias[m//rows_per_batch] + residual).
+
+    out_hilo (with out_f32): return the fp32 result as its fp16 operand pair [M][2 n_out] = [fp16(v) | fp16(v - fp16(v))] — what
+    `cast_hilo` makes of it, written by the epilogue itself where the launch allows (uav_conv_gemm_hilo_ok), else by that pass.
 
     no_shortk: keep a 1x1 launch out of the short-K kernel (UAV_CONV_NO_SHORTK: A/B measurements, bit-identity test).
 
@@ -295,9 +298,14 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
     n_out = wt.n_out
     if out_map is not None and (out is None or residual is not None):
         raise _lib.UavError("out_map needs a caller-supplied `out` and no residual")
+    if out_hilo and (not out_f32 or out is not None or out_map is not None or ln_produce or wt.geglu):
+        raise _lib.UavError("out_hilo is a storage form of a plain fp32 result (out_f32, library-allocated output)")
     if out is None:
-        out = torch.empty((m, n_out), dtype=torch.float32 if out_f32 else HALF, device=a1.device)
+        out = torch.empty((m, 2 * n_out), dtype=HALF, device=a1.device) if out_hilo else \
+            torch.empty((m, n_out), dtype=torch.float32 if out_f32 else HALF, device=a1.device)
     flags = (_lib.CONV_GEGLU if wt.geglu else 0) | (_lib.CONV_OUT_F32 if out_f32 else 0) | (_lib.CONV_PERSISTENT if persistent else 0)
+    if out_hilo:
+        flags |= _lib.CONV_OUT_HILO
     if act is not None:
         flags |= {"gelu": _lib.CONV_GELU, "quick_gelu": _lib.CONV_QUICK_GELU}[act]
     if no_shortk:
@@ -335,6 +343,12 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
         p.out_map_w, p.out_map_sy, p.out_map_sx, p.out_map_off = (int(v) for v in out_map)
         if (m // out_map[0] - 1) * out_map[1] + (out_map[0] - 1) * out_map[2] + out_map[3] >= out.shape[0]:
             raise _lib.UavError("out_map places rows past the end of `out`")
+    hilo_pass = False
+    if out_hilo and not lib.uav_conv_gemm_hilo_ok(C.byref(p)):
+        # this launch cannot store the pair itself (small grid, tile tails, ...): fp32 result + the cast pass
+        hilo_pass = True
+        out = torch.empty((m, n_out), dtype=torch.float32, device=a1.device)
+        p.out = _p(out); p.out_stride = n_out; p.flags = flags & ~_lib.CONV_OUT_HILO
     lnop = None
     if ln_produce and out_f32 and n_out % 128 == 0 and out.shape[-1] == n_out:
         lnop = LnOperand(torch.empty((m, n_out), dtype=HALF, device=a1.device),
@@ -357,7 +371,7 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
             sh.filled += 1
         else:
             p.gn_groups = 0; p.gn_chunk_cpi = 0
-    elif gn_groups and FUSE_GN_STATS and out_map is None and lnop is None:
+    elif gn_groups and FUSE_GN_STATS and out_map is None and lnop is None and not out_hilo:
         p.gn_groups = int(gn_groups)
         rows = lib.uav_conv_gemm_gn_chunk_rows(C.byref(p))
         if rows > 0:
@@ -392,6 +406,8 @@ def conv_gemm(a1, wt: ConvW, *, n_img, t_len, hi, wi, stride=1, pad=None, upsamp
                  # algorithmic bytes: every operand once — X and W fp16, the result and the residual in their stored type
                  2.0 * n_img * hi * wi * wt.cin + 2.0 * wt.n * wt.kt * wt.kh * wt.kw * wt.cin + (4.0 if out_f32 else 2.0) * m * n_out
                  + (0.0 if residual is None else (4.0 if residual.dtype == torch.float32 else 2.0) * m * n_out))
+    if hilo_pass:
+        return cast_hilo(out)
     return out
 
 
@@ -408,12 +424,12 @@ def _factor_rows(m):
 
 
 def linear(x, wt: ConvW, *, residual=None, out_scale=1.0, rowbias=None, rows_per_batch=0, out_f32=False, act=None,
-           gn_groups=None, ln_produce=False, ln_consume=None, no_shortk=False, no_w4=False):
+           gn_groups=None, ln_produce=False, ln_consume=None, no_shortk=False, no_w4=False, out_hilo=False):
     """nn.Linear over token rows x[M][K] (a 1x1 'conv': every row is one pixel)."""
     n_img, hi = _factor_rows(x.shape[0])
     return conv_gemm(x, wt, n_img=n_img, t_len=1, hi=hi, wi=1, residual=residual, out_scale=out_scale,
                      rowbias=rowbias, rows_per_batch=rows_per_batch, out_f32=out_f32, act=act, gn_groups=gn_groups,
-                     ln_produce=ln_produce, ln_consume=ln_consume, no_shortk=no_shortk, no_w4=no_w4)
+                     ln_produce=ln_produce, ln_consume=ln_consume, no_shortk=no_shortk, no_w4=no_w4, out_hilo=out_hilo)
 
 
 def ln_fold_ok(m, k, wt: ConvW):
