@@ -31,7 +31,7 @@ def group(n, base, cb, dma, first=False):
             out.append(f"XT{z}({t}, {c}, {b}, {min(D - 1, n - 1 - f)})")
         if f in dma:
             p = dma[f]
-            out.append(f"XD({p * 1024}, {(p & 3) * 1024})")
+            out.append(f"XD({(p & ~3) * 1024}, {(p & 3) * 1024})")       # the instruction offset moves BOTH the global and the LDS address
             if p == 3:
                 out.append("XDADV")
     return out

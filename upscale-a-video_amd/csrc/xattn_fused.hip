@@ -46,6 +46,7 @@ struct XattnArgs {
     const float* x; float* out; const float* gamma; const float* beta; const float* bias;
     const char* wq; const char* kv; const char* wo;
     long long rows; int rows_per_kv; int lk; float eps, scale_log2;
+    unsigned long long* trace;                 // development instance only (UAV_DEV_KERNELS): 16 s_memtime stamps per workgroup
 };
 
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -79,8 +80,10 @@ UAV_DEVINL float swap32(float v) { return __shfl_xor(v, 32, 64); }
 #define XMF0(C, A, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #A "], %[" #B "], 0\n"
 #define XS0(T, C, B, WN, OFF) "s_waitcnt lgkmcnt(" #WN ")\n" XMF0(C, T, B) XRD(T, OFF)
 #define XT0(T, C, B, WN) "s_waitcnt lgkmcnt(" #WN ")\n" XMF0(C, T, B)
-// one 1-KiB LDS-DMA piece of the group three ahead, between two MFMAs: M0 = its place in the ring slot, 16 B per lane from
-// srd.base + voff + so + GOFF (XDADV steps `so` over the four pieces addressed through the 12-bit immediate)
+// one 1-KiB LDS-DMA piece of the group three ahead, between two MFMAs: 16 B per lane from srd.base + voff + so + GOFF to LDS
+// M0 + GOFF + 16 lane — the 12-bit instruction offset moves BOTH addresses (the first interleaved version set M0 to the piece's own
+// place and added GOFF on top: pieces 1-3 of every half landed 1-3 KiB too far, NaN; run 2 of round 6) —, so M0 = the half group's
+// base; XDADV steps `so` over the four pieces addressed through the immediate
 #define XD(LOFF, GOFF) "s_add_u32 m0, %[ldsn], " #LOFF "\n" "s_nop 0\n" "buffer_load_dwordx4 %[voff], %[srd], %[so] offen offset:" #GOFF " lds\n"
 #define XDADV "s_add_u32 %[so], %[so], 4096\n"
 // W_q group: fragment f = (k-step f >> 1, channel tile f & 1);  W_out group: (channel tile 2 (f >> 3) + (f & 1), k-step (f >> 1) & 3);
@@ -89,52 +92,56 @@ UAV_DEVINL float swap32(float v) { return __shfl_xor(v, 32, 64); }
 #define XG_WQ_FIRST \
     XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XS0(t0, q0, b0, 5, 6144) \
     XS0(t1, q1, b0, 5, 7168) XS(t2, q0, b1, 5, 8192) XD(0, 0) XS(t3, q1, b1, 5, 9216) XS(t4, q0, b2, 5, 10240) \
-    XS(t5, q1, b2, 5, 11264) XS(t0, q0, b3, 5, 12288) XD(1024, 1024) XS(t1, q1, b3, 5, 13312) XS(t2, q0, b4, 5, 14336) \
-    XS(t3, q1, b4, 5, 15360) XS(t4, q0, b5, 5, 16384) XD(2048, 2048) XS(t5, q1, b5, 5, 17408) XS(t0, q0, b6, 5, 18432) \
-    XS(t1, q1, b6, 5, 19456) XS(t2, q0, b7, 5, 20480) XD(3072, 3072) XDADV XS(t3, q1, b7, 5, 21504) \
-    XS(t4, q0, b8, 5, 22528) XS(t5, q1, b8, 5, 23552) XS(t0, q0, b9, 5, 24576) XD(4096, 0) XS(t1, q1, b9, 5, 25600) \
-    XS(t2, q0, b10, 5, 26624) XS(t3, q1, b10, 5, 27648) XS(t4, q0, b11, 5, 28672) XD(5120, 1024) \
-    XS(t5, q1, b11, 5, 29696) XS(t0, q0, b12, 5, 30720) XS(t1, q1, b12, 5, 31744) XT(t2, q0, b13, 5) XD(6144, 2048) \
-    XT(t3, q1, b13, 4) XT(t4, q0, b14, 3) XT(t5, q1, b14, 2) XT(t0, q0, b15, 1) XD(7168, 3072) XT(t1, q1, b15, 0)
+    XS(t5, q1, b2, 5, 11264) XS(t0, q0, b3, 5, 12288) XD(0, 1024) XS(t1, q1, b3, 5, 13312) XS(t2, q0, b4, 5, 14336) \
+    XS(t3, q1, b4, 5, 15360) XS(t4, q0, b5, 5, 16384) XD(0, 2048) XS(t5, q1, b5, 5, 17408) XS(t0, q0, b6, 5, 18432) \
+    XS(t1, q1, b6, 5, 19456) XS(t2, q0, b7, 5, 20480) XD(0, 3072) XDADV XS(t3, q1, b7, 5, 21504) XS(t4, q0, b8, 5, 22528) \
+    XS(t5, q1, b8, 5, 23552) XS(t0, q0, b9, 5, 24576) XD(4096, 0) XS(t1, q1, b9, 5, 25600) XS(t2, q0, b10, 5, 26624) \
+    XS(t3, q1, b10, 5, 27648) XS(t4, q0, b11, 5, 28672) XD(4096, 1024) XS(t5, q1, b11, 5, 29696) \
+    XS(t0, q0, b12, 5, 30720) XS(t1, q1, b12, 5, 31744) XT(t2, q0, b13, 5) XD(4096, 2048) XT(t3, q1, b13, 4) \
+    XT(t4, q0, b14, 3) XT(t5, q1, b14, 2) XT(t0, q0, b15, 1) XD(4096, 3072) XT(t1, q1, b15, 0)
 
 #define XG_WQ \
     XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XS(t0, q0, b0, 5, 6144) \
     XS(t1, q1, b0, 5, 7168) XS(t2, q0, b1, 5, 8192) XD(0, 0) XS(t3, q1, b1, 5, 9216) XS(t4, q0, b2, 5, 10240) \
-    XS(t5, q1, b2, 5, 11264) XS(t0, q0, b3, 5, 12288) XD(1024, 1024) XS(t1, q1, b3, 5, 13312) XS(t2, q0, b4, 5, 14336) \
-    XS(t3, q1, b4, 5, 15360) XS(t4, q0, b5, 5, 16384) XD(2048, 2048) XS(t5, q1, b5, 5, 17408) XS(t0, q0, b6, 5, 18432) \
-    XS(t1, q1, b6, 5, 19456) XS(t2, q0, b7, 5, 20480) XD(3072, 3072) XDADV XS(t3, q1, b7, 5, 21504) \
-    XS(t4, q0, b8, 5, 22528) XS(t5, q1, b8, 5, 23552) XS(t0, q0, b9, 5, 24576) XD(4096, 0) XS(t1, q1, b9, 5, 25600) \
-    XS(t2, q0, b10, 5, 26624) XS(t3, q1, b10, 5, 27648) XS(t4, q0, b11, 5, 28672) XD(5120, 1024) \
-    XS(t5, q1, b11, 5, 29696) XS(t0, q0, b12, 5, 30720) XS(t1, q1, b12, 5, 31744) XT(t2, q0, b13, 5) XD(6144, 2048) \
-    XT(t3, q1, b13, 4) XT(t4, q0, b14, 3) XT(t5, q1, b14, 2) XT(t0, q0, b15, 1) XD(7168, 3072) XT(t1, q1, b15, 0)
+    XS(t5, q1, b2, 5, 11264) XS(t0, q0, b3, 5, 12288) XD(0, 1024) XS(t1, q1, b3, 5, 13312) XS(t2, q0, b4, 5, 14336) \
+    XS(t3, q1, b4, 5, 15360) XS(t4, q0, b5, 5, 16384) XD(0, 2048) XS(t5, q1, b5, 5, 17408) XS(t0, q0, b6, 5, 18432) \
+    XS(t1, q1, b6, 5, 19456) XS(t2, q0, b7, 5, 20480) XD(0, 3072) XDADV XS(t3, q1, b7, 5, 21504) XS(t4, q0, b8, 5, 22528) \
+    XS(t5, q1, b8, 5, 23552) XS(t0, q0, b9, 5, 24576) XD(4096, 0) XS(t1, q1, b9, 5, 25600) XS(t2, q0, b10, 5, 26624) \
+    XS(t3, q1, b10, 5, 27648) XS(t4, q0, b11, 5, 28672) XD(4096, 1024) XS(t5, q1, b11, 5, 29696) \
+    XS(t0, q0, b12, 5, 30720) XS(t1, q1, b12, 5, 31744) XT(t2, q0, b13, 5) XD(4096, 2048) XT(t3, q1, b13, 4) \
+    XT(t4, q0, b14, 3) XT(t5, q1, b14, 2) XT(t0, q0, b15, 1) XD(4096, 3072) XT(t1, q1, b15, 0)
 
 #define XG_WO \
     XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XS(t0, c0, b0, 5, 6144) \
     XS(t1, c1, b0, 5, 7168) XS(t2, c0, b1, 5, 8192) XD(0, 0) XS(t3, c1, b1, 5, 9216) XS(t4, c0, b2, 5, 10240) \
-    XS(t5, c1, b2, 5, 11264) XS(t0, c0, b3, 5, 12288) XD(1024, 1024) XS(t1, c1, b3, 5, 13312) XS(t2, c2, b0, 5, 14336) \
-    XS(t3, c3, b0, 5, 15360) XS(t4, c2, b1, 5, 16384) XD(2048, 2048) XS(t5, c3, b1, 5, 17408) XS(t0, c2, b2, 5, 18432) \
-    XS(t1, c3, b2, 5, 19456) XS(t2, c2, b3, 5, 20480) XD(3072, 3072) XDADV XS(t3, c3, b3, 5, 21504) \
-    XS(t4, c4, b0, 5, 22528) XS(t5, c5, b0, 5, 23552) XS(t0, c4, b1, 5, 24576) XD(4096, 0) XS(t1, c5, b1, 5, 25600) \
-    XS(t2, c4, b2, 5, 26624) XS(t3, c5, b2, 5, 27648) XS(t4, c4, b3, 5, 28672) XD(5120, 1024) XS(t5, c5, b3, 5, 29696) \
-    XS(t0, c6, b0, 5, 30720) XS(t1, c7, b0, 5, 31744) XT(t2, c6, b1, 5) XD(6144, 2048) XT(t3, c7, b1, 4) \
-    XT(t4, c6, b2, 3) XT(t5, c7, b2, 2) XT(t0, c6, b3, 1) XD(7168, 3072) XT(t1, c7, b3, 0)
+    XS(t5, c1, b2, 5, 11264) XS(t0, c0, b3, 5, 12288) XD(0, 1024) XS(t1, c1, b3, 5, 13312) XS(t2, c2, b0, 5, 14336) \
+    XS(t3, c3, b0, 5, 15360) XS(t4, c2, b1, 5, 16384) XD(0, 2048) XS(t5, c3, b1, 5, 17408) XS(t0, c2, b2, 5, 18432) \
+    XS(t1, c3, b2, 5, 19456) XS(t2, c2, b3, 5, 20480) XD(0, 3072) XDADV XS(t3, c3, b3, 5, 21504) XS(t4, c4, b0, 5, 22528) \
+    XS(t5, c5, b0, 5, 23552) XS(t0, c4, b1, 5, 24576) XD(4096, 0) XS(t1, c5, b1, 5, 25600) XS(t2, c4, b2, 5, 26624) \
+    XS(t3, c5, b2, 5, 27648) XS(t4, c4, b3, 5, 28672) XD(4096, 1024) XS(t5, c5, b3, 5, 29696) XS(t0, c6, b0, 5, 30720) \
+    XS(t1, c7, b0, 5, 31744) XT(t2, c6, b1, 5) XD(4096, 2048) XT(t3, c7, b1, 4) XT(t4, c6, b2, 3) XT(t5, c7, b2, 2) \
+    XT(t0, c6, b3, 1) XD(4096, 3072) XT(t1, c7, b3, 0)
 
 #define XG_K \
     XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XS0(t0, c0, b0, 5, 6144) \
     XS0(t1, c1, b0, 5, 7168) XD(0, 0) XS0(t2, c2, b0, 5, 8192) XS(t3, c0, b1, 5, 9216) XS(t4, c1, b1, 5, 10240) \
-    XD(1024, 1024) XS(t5, c2, b1, 5, 11264) XT(t0, c0, b2, 5) XT(t1, c1, b2, 4) XD(2048, 2048) XT(t2, c2, b2, 3) \
-    XT(t3, c0, b3, 2) XT(t4, c1, b3, 1) XD(3072, 3072) XDADV XT(t5, c2, b3, 0)
+    XD(0, 1024) XS(t5, c2, b1, 5, 11264) XT(t0, c0, b2, 5) XT(t1, c1, b2, 4) XD(0, 2048) XT(t2, c2, b2, 3) \
+    XT(t3, c0, b3, 2) XT(t4, c1, b3, 1) XD(0, 3072) XDADV XT(t5, c2, b3, 0)
 
 #define XG_V \
     XRD(t0, 12288) XRD(t1, 13312) XRD(t2, 14336) XRD(t3, 15360) XRD(t4, 16384) XRD(t5, 17408) XS0(t0, c0, b0, 5, 18432) \
     XS0(t1, c1, b0, 5, 19456) XD(4096, 0) XS(t2, c0, b1, 5, 20480) XS(t3, c1, b1, 5, 21504) XS(t4, c0, b2, 5, 22528) \
-    XD(5120, 1024) XS(t5, c1, b2, 5, 23552) XT(t0, c0, b3, 5) XT(t1, c1, b3, 4) XD(6144, 2048) XT(t2, c0, b4, 3) \
-    XT(t3, c1, b4, 2) XT(t4, c0, b5, 1) XD(7168, 3072) XT(t5, c1, b5, 0)
+    XD(4096, 1024) XS(t5, c1, b2, 5, 23552) XT(t0, c0, b3, 5) XT(t1, c1, b3, 4) XD(4096, 2048) XT(t2, c0, b4, 3) \
+    XT(t3, c1, b4, 2) XT(t4, c0, b5, 1) XD(4096, 3072) XT(t5, c1, b5, 0)
 #define XTMP_OUT [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [so] "+s"(nx.so)
 #define XDMA_IN [ldsn] "s"(nx.ldsn), [srd] "s"(nx.srd), [voff] "v"(voff)
 
+// TR = 1: development instance that stamps s_memtime at the phase boundaries (tools/trace_xattn.py); the product is TR = 0
+template <int TR>
 __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long ts[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (TR) ts[0] = __builtin_amdgcn_s_memtime();
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
@@ -207,6 +214,7 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
         __builtin_amdgcn_sched_barrier(0);
     }
     s1 += swap32(s1); s2 += swap32(s2);
+    if (TR) ts[1] = __builtin_amdgcn_s_memtime();           // statistics pass done (first read of the rows)
     const float m1 = s1 * (1.0f / XC);
     const float mean = c0 + m1;
     const float rstd = rsqrtf(fmaxf(s2 * (1.0f / XC) - m1 * m1, 0.f) + p.eps);
@@ -231,10 +239,12 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
     }
 
+    if (TR) ts[2] = __builtin_amdgcn_s_memtime();           // operand fragments and accumulators built (second read)
     // ---- heads ----------------------------------------------------------------------------------------------------------------
 #pragma unroll 1
     for (int h = 0; h < XHEADS; ++h) {
         half8_t t0, t1, t2, t3, t4, t5;
+        if (TR && h == 1) ts[3] = __builtin_amdgcn_s_memtime();    // head 1 is stamped phase by phase (head 0 carries the cold start)
         // Q_h^T [64 ch][32 tokens] = Wq_h . Xn^T
         float16_t q0, q1;
         {
@@ -257,6 +267,7 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
                            [b12] "v"(xn[16 * j + 12]), [b13] "v"(xn[16 * j + 13]), [b14] "v"(xn[16 * j + 14]), [b15] "v"(xn[16 * j + 15]), XDMA_IN
                          : "memory", "scc");
         }
+        if (TR && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[4] = __builtin_amdgcn_s_memtime(); }     // Q GEMM (64 MFMA)
         half8_t qf[4];                                      // Q rounded to fp16 like the stored q of the unfused chain
 #pragma unroll
         for (int e = 0; e < 8; ++e) { qf[0][e] = (half_t)q0[e]; qf[1][e] = (half_t)q0[8 + e]; qf[2][e] = (half_t)q1[e]; qf[3][e] = (half_t)q1[8 + e]; }
@@ -265,6 +276,7 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
         const unsigned stkv = group_sync(h, 2);
         asm volatile(XG_K : [c0] "=&v"(sacc[0]), [c1] "=&v"(sacc[1]), [c2] "=&v"(sacc[2]), XTMP_OUT
                      : [st] "v"(stkv), [b0] "v"(qf[0]), [b1] "v"(qf[1]), [b2] "v"(qf[2]), [b3] "v"(qf[3]), XDMA_IN : "memory", "scc");
+        if (TR && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[5] = __builtin_amdgcn_s_memtime(); }     // S = K Q (12 MFMA)
         // softmax over the keys: this lane holds keys 32 t + (r & 3) + 8 (r >> 2) + 4 hi, lane ^ 32 the others
         float mx = -INFINITY;
 #pragma unroll
@@ -291,11 +303,13 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
         }
         ps += swap32(ps);
         const float inv = 1.0f / ps;
+        if (TR && h == 1) ts[6] = __builtin_amdgcn_s_memtime();                                                          // softmax
         // O^T [64 ch][32 tokens] = V_h^T . P^T (same LDS slot, fragments 12 .. 23)
         float16_t o0, o1;
         asm volatile(XG_V : [c0] "=&v"(o0), [c1] "=&v"(o1), XTMP_OUT
                      : [st] "v"(stkv), [b0] "v"(pf[0]), [b1] "v"(pf[1]), [b2] "v"(pf[2]), [b3] "v"(pf[3]), [b4] "v"(pf[4]), [b5] "v"(pf[5]), XDMA_IN
                      : "memory", "scc");
+        if (TR && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[7] = __builtin_amdgcn_s_memtime(); }     // O = V P (12 MFMA)
         half8_t of[4];                                      // O / l rounded to fp16 like the stored attention output
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -310,8 +324,9 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
                            [c4] "+a"(acc[8 * j + 4]), [c5] "+a"(acc[8 * j + 5]), [c6] "+a"(acc[8 * j + 6]), [c7] "+a"(acc[8 * j + 7]), XTMP_OUT
                          : [st] "v"(st), [b0] "v"(of[0]), [b1] "v"(of[1]), [b2] "v"(of[2]), [b3] "v"(of[3]), XDMA_IN : "memory", "scc");
         }
+        if (TR && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[8] = __builtin_amdgcn_s_memtime(); }     // acc += Wout O (64 MFMA)
     }
-
+    if (TR) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[9] = __builtin_amdgcn_s_memtime(); }                         // all heads
     wait_vmcnt<0>();                                       // the zero-fill pieces behind the last group (LDS-DMA must not outlive the workgroup)
     // ---- store ------------------------------------------------------------------------------------------------------------------
     {
@@ -323,6 +338,15 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
                 const float4_t v = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
                 *(float4_t*)(orow + 32 * j + 8 * q) = v;
             }
+    }
+    if (TR) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[10] = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            unsigned long long* t = p.trace + (size_t)blockIdx.x * 16;
+#pragma unroll
+            for (int i = 0; i < 11; ++i) t[i] = ts[i];
+        }
     }
 }
 
@@ -376,9 +400,23 @@ extern "C" int uav_xattn_sublayer_f32(const float* x, float* out, const float* l
     if (rows <= 0 || rows_per_kv <= 0 || (rows_per_kv % 128) || (rows % rows_per_kv) || rows / 128 >= (1ll << 31)) return UAV_ESHAPE;
     if (((size_t)x | (size_t)out) & 15) return UAV_EALIGN;
     static UavDynLds lds;
-    if (int rc = uav_set_dyn_lds(lds, (const void*)xattn_sublayer_kernel, XSMEM)) return rc;
+    if (int rc = uav_set_dyn_lds(lds, (const void*)xattn_sublayer_kernel<0>, XSMEM)) return rc;
     XattnArgs a{x, out, ln_gamma, ln_beta, out_bias, (const char*)wq_packed, (const char*)kv_packed, (const char*)wo_packed,
-                (long long)rows, rows_per_kv, lk, ln_eps, scale * 1.44269504088896341f};
-    hipLaunchKernelGGL(xattn_sublayer_kernel, dim3((unsigned)(rows / 128)), dim3(256), XSMEM, (hipStream_t)stream, a);
+                (long long)rows, rows_per_kv, lk, ln_eps, scale * 1.44269504088896341f, nullptr};
+    hipLaunchKernelGGL(xattn_sublayer_kernel<0>, dim3((unsigned)(rows / 128)), dim3(256), XSMEM, (hipStream_t)stream, a);
     return uav_launch_status();
 }
+
+#ifdef UAV_DEV_KERNELS
+// Development build only (tools/ab/build_dev.sh): the stamped instance; trace = 16 x uint64 per workgroup (rows / 128 of them).
+extern "C" int uav_dev_xattn_sublayer_trace(const float* x, float* out, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                                            const void* wq_packed, const void* kv_packed, const void* wo_packed, const float* out_bias,
+                                            int64_t rows, int32_t rows_per_kv, int32_t lk, float scale, void* trace, void* stream) {
+    static UavDynLds lds;
+    if (int rc = uav_set_dyn_lds(lds, (const void*)xattn_sublayer_kernel<1>, XSMEM)) return rc;
+    XattnArgs a{x, out, ln_gamma, ln_beta, out_bias, (const char*)wq_packed, (const char*)kv_packed, (const char*)wo_packed,
+                (long long)rows, rows_per_kv, lk, ln_eps, scale * 1.44269504088896341f, (unsigned long long*)trace};
+    hipLaunchKernelGGL(xattn_sublayer_kernel<1>, dim3((unsigned)(rows / 128)), dim3(256), XSMEM, (hipStream_t)stream, a);
+    return uav_launch_status();
+}
+#endif
