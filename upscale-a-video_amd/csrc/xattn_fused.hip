@@ -202,9 +202,9 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
     const float c0 = p.x[row * XC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int jb = 0; jb < 16; jb += 4) {                    // batches of 16 loads (64 VGPRs in flight)
+    for (int jb = 0; jb < 16; jb += 8) {                    // two batches of 32 loads (128 VGPRs in flight: nothing else is live yet)
 #pragma unroll
-        for (int j = jb; j < jb + 4; ++j)
+        for (int j = jb; j < jb + 8; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4_t v = *(const float4_t*)(xr + 32 * j + 8 * q);
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
                 acc[j][4 * q + i] = v[i] + bo[i];           // out = (x + b_out) + sum over heads
             }
         }
-        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        if (j == 7 || j == 11) __builtin_amdgcn_sched_barrier(0);       // batches of 32, 16, 16 loads: the operand registers fill up as the rows turn into them
     }
 
     if (TR) ts[2] = __builtin_amdgcn_s_memtime();           // operand fragments and accumulators built (second read)
@@ -328,16 +328,36 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
     }
     if (TR) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[9] = __builtin_amdgcn_s_memtime(); }                         // all heads
     wait_vmcnt<0>();                                       // the zero-fill pieces behind the last group (LDS-DMA must not outlive the workgroup)
-    // ---- store ------------------------------------------------------------------------------------------------------------------
+    // ---- store: row-coalesced through the idle ring ---------------------------------------------------------------------------------
+    // A lane owns a token: stored from the accumulators' layout a wave-wide 16-B store touches 32 rows x 32 B — quarter cache lines, the
+    // transaction-bound pattern measured on the conv epilogues (here 13.5 k ticks per tile, run 3 of round 6).  The wave
+    // dumps half of its tile (32 tokens x 256 channels fp32 = 32 KiB, its quarter of the ring; 16-B piece pc of row r at physical piece
+    // pc ^ (r & 7): conflict-free both ways) and reads it back a ROW per instruction: every store is 1 KiB contiguous.
+    __syncthreads();                                        // every wave is done reading fragments: the ring is free
     {
-        float* orow = p.out + row * XC + 4 * hi;
+        const unsigned wbuf = lds0 + (unsigned)(wave * XGROUP);
+        float* const obase = p.out + (tile0 + wave * 32) * XC + lane * 4;
 #pragma unroll
-        for (int j = 0; j < 16; ++j)
+        for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4_t v = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
-                *(float4_t*)(orow + 32 * j + 8 * q) = v;
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4_t v = {acc[8 * hh + j][4 * q], acc[8 * hh + j][4 * q + 1], acc[8 * hh + j][4 * q + 2], acc[8 * hh + j][4 * q + 3]};
+                    const int pc = 8 * j + 2 * q + hi;
+                    *(lds_f4wptr_t)(size_t)(wbuf + l32 * 1024 + ((pc ^ (l32 & 7)) << 4)) = v;
+                }
+            asm volatile("" ::: "memory");                  // (LDS operations of one wave execute in order; the buffer is the wave's own)
+#pragma unroll
+            for (int kb = 0; kb < 32; kb += 8) {
+                float4_t r[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) r[k] = lds_f4(wbuf + (kb + k) * 1024 + ((lane ^ ((kb + k) & 7)) << 4));
+#pragma unroll
+                for (int k = 0; k < 8; ++k) *(float4_t*)(obase + (long long)(kb + k) * XC + hh * 256) = r[k];
             }
+            asm volatile("" ::: "memory");
+        }
     }
     if (TR) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
