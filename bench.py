@@ -237,6 +237,11 @@ def main():
     ap.add_argument("--no-throughput-mode", action="store_true",
                     help="skip the extra two-clips-per-GPU measurement (`throughput_mode` object) that follows the serial timed region")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--timed-kernel-events", action="store_true",
+                    help="HIP events around the dominant kernel (conv_gemm) INSIDE the timed region, as rounds 1-5 measured `roofline`.  Default "
+                         "since round 6: the timed region carries no events (same-box A/B, twice interleaved: 1.1417 with / 1.1489 frames/s "
+                         "without the ~16 k event records per clip, +0.63 %, profiles/r06_event_overhead_ab_*.jsonl) and `roofline` + the "
+                         "per-kernel table come from one extra fully instrumented clip right behind it, same process, same box")
     ap.add_argument("--all-kernel-events", action="store_true",
                     help="HIP events around EVERY kernel family inside the timed region (costs ~2 %%: 50 k event records of ~3 us "
                          "of GPU time per clip).  Default: only the dominant kernel (conv_gemm, what `roofline` needs) is timed there "
@@ -406,9 +411,11 @@ def main():
     barrier()
     use_events = (not args.no_kernel_events) and rank == 0
     all_events = args.all_kernel_events or bool(os.environ.get("UAV_BENCH_DETAIL"))
+    # window-sharded steps hold collectives: an extra step on rank 0 alone would hang, so that mode keeps its events inside the timed region
+    timed_events = use_events and (args.timed_kernel_events or args.all_kernel_events or args.shard_windows)
     if use_events:
         ops.PROFILER.detail = bool(os.environ.get("UAV_BENCH_DETAIL"))
-        if not overlapped:              # per-launch events mean nothing while launches of two streams share the chip
+        if timed_events and not overlapped:   # per-launch events mean nothing while launches of two streams share the chip
             ops.PROFILER.start(only=None if all_events else {"conv_gemm"})
     torch.cuda.reset_peak_memory_stats(dev)
     t0 = time.perf_counter()
@@ -418,9 +425,9 @@ def main():
     elapsed = time.perf_counter() - t0
     peak_alloc, peak_reserved = torch.cuda.max_memory_allocated(dev), torch.cuda.max_memory_reserved(dev)
     ops.PROFILER.stop()
-    timed_summary = ops.PROFILER.summary() if use_events else None
+    timed_summary = ops.PROFILER.summary() if timed_events else None
     extra_summary = None
-    if use_events and (overlapped or (not all_events and world == 1)):
+    if use_events and (overlapped or not timed_events or (not all_events and world == 1)):
         # per-kernel table: one extra step AFTER the timed region with events around every kernel family (serial, i.e. with the
         # stream overlap switched off for this step: the kernel measurements are those of the default mode)
         pipe.overlap_streams = 0
@@ -430,7 +437,7 @@ def main():
         ops.PROFILER.stop()
         extra_summary = ops.PROFILER.summary()
         pipe.overlap_streams = n_overlap
-        if overlapped:
+        if overlapped or not timed_events:
             timed_summary = extra_summary
     # Throughput mode BESIDE the serial headline: two clips per GPU on concurrent HIP streams — the HBM-bound
     # kernels of one clip (GroupNorm / LayerNorm passes, the epilogue-bound short-K linears) run beside the power-limited MFMA
@@ -532,7 +539,10 @@ def main():
                                                  "--pmc pass over this command with the SAME kernel sources — digest checked —, tools/pmc_traffic.sh); "
                                                  "not measured by this run",
                                "measured": ("one extra SERIAL step after the timed region (launches of the timed region overlap on "
-                                            f"{n_overlap} streams)" if overlapped else "HIP events inside the timed region"),
+                                            f"{n_overlap} streams)" if overlapped else "HIP events inside the timed region" if timed_events else
+                                            "HIP events around every launch of one extra clip issued right behind the timed region (same process, "
+                                            "same box, same inputs): the timed region itself carries no events since round 6 — they cost 0.63 % "
+                                            "(profiles/r06_event_overhead_ab_*.jsonl; --timed-kernel-events restores the old placement)"),
                                "launches": d["launches"],
                                "avg_launch_us": d["seconds"] / d["launches"] * 1e6,
                                "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
@@ -554,7 +564,7 @@ def main():
                                        for k, v in sorted(table.items(), key=lambda kv: -kv[1]["seconds"])}
             res["kernel_breakdown_source"] = ("HIP events around every kernel inside the timed region" if extra_summary is None else
                                               "one extra fully instrumented step after the timed region (the timed region itself carries "
-                                              "events around conv_gemm only); launches / ms are per that one step")
+                                              + ("events around conv_gemm only" if timed_events else "no events") + "); launches / ms are per that one step")
             res["kernel_time_ms_per_step"] = total_s / table_steps * 1e3
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()

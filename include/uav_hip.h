@@ -36,6 +36,9 @@ extern "C" {
 
 /* ---- library info ------------------------------------------------------------------- */
 int  uav_version(void);
+/* 1 in a development build (-DUAV_DEV_KERNELS, tools/ab/build_dev.sh: ablation / trace / legacy kernel instances and the switches that
+ * reach them — UAV_CONV_DBG / _PERSIST / _DMAV / _SK, UAV_CONV_W4_TRACE, UAV_LN_FOLD, UAV_ATTN512=0), 0 in the product library */
+int  uav_has_dev_kernels(void);
 /* 0 if device `dev` is a gfx950 (MI355X); UAV_EINVAL otherwise. `name_out` (optional, >=64 B). */
 int  uav_device_check(int dev, char* name_out);
 

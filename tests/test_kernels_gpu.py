@@ -685,7 +685,10 @@ def test_layernorm_folded_into_projection(ops, dev, k, n, geglu, res):
     (ln_consume, optionally GEGLU) applies rstd * (x16 . (W o gamma)^T - mu * colsum) + (W.beta + b) in its epilogue.  Against
     fp32 LayerNorm -> Linear (-> GEGLU) on the same rows, and against the unfused engine path (layernorm kernel + linear)."""
     import torch.nn as nn
-    from uav import engine as E
+    from uav import engine as E, _lib
+    if not _lib.load().uav_has_dev_kernels():
+        pytest.skip("the LayerNorm-fold conv instances are development kernels (measured slower and outside the parity bar, DESIGN section 6): "
+                    "tools/ab/build_dev.sh all + UAV_HIP_LIB=tools/ab/libuav_hip_dev.so")
     g = torch.Generator().manual_seed(k + n)
     m = 128 * 512                                   # 256 m-tiles x >= 2 n-tiles: the 256x256 kernel
     x0 = torch.randn(m, k, generator=g).half().to(dev)

@@ -167,13 +167,15 @@ def test_headline_configs1_end_to_end_vs_gpu_oracle(headline):
     """BASELINE configs[1] (pipeline_upscale_a_video.py:436-716): latents after 30 steps inside the stated 1e-3."""
     # measured (round 4, call 1): latents 9.0e-4, images 1.075e-3 (all pixels) / 1.39e-3 (unsaturated) without the samplers'
     # hi|lo operands; with them (default since) 8.2e-4, 9.5e-4 / 1.23e-3.  Both bars are BASELINE.json's stated 1e-3.
-    _check("r4_headline_configs1_8x320x320_30steps", headline["eng1"], headline["ora"]["c1"], bars=(1.0e-3, 1.0e-3))
+    # round 6 (block tails as hi|lo pairs by default, fused cross-attention sub-layers): 7.3e-4, 8.7e-4 / 1.12e-3 — bars 8.0e-4 / 9.2e-4
+    # (VERDICT r5 next #2: the stated 1e-3 with a margin instead of 5 % under it)
+    _check("r4_headline_configs1_8x320x320_30steps", headline["eng1"], headline["ora"]["c1"], bars=(8.0e-4, 9.2e-4))
 
 
 def test_headline_configs2_propagation_end_to_end_vs_gpu_oracle(headline):
     """BASELINE configs[2]: + RAFT flows and fp32 flow-guided propagation at steps 24/26/28 (same flows on both sides)."""
     eng, ora = headline["eng2"], headline["ora"]["c2"]
-    curve, e_lat, e_all, e_unsat = _check("r4_headline_configs2_8x320x320_30steps_propagation", eng, ora, bars=(1.0e-3, 1.0e-3))
+    curve, e_lat, e_all, e_unsat = _check("r4_headline_configs2_8x320x320_30steps_propagation", eng, ora, bars=(8.0e-4, 9.2e-4))    # measured 6.7e-4 / 8.7e-4
     # the propagation did something (vs the no-propagation run), and a nearest-neighbour index flip would show as an O(1)
     # difference on single elements: count them
     moved = rel_l2(eng["latents"], headline["eng1"]["latents"])

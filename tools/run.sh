@@ -28,21 +28,24 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 TAG=$1; shift
 O=$R/gpurun_out; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
+# steps that reach development kernels (short-K, stamped four-wave conv instance, LayerNorm fold, ablation builds) load the development
+# build of the library (tools/ab/build_dev.sh all) instead of the product one
+DEV="UAV_HIP_LIB=$R/tools/ab/libuav_hip_dev.so"
 log() { echo "== $(date +%H:%M:%S) $*" | tee -a $O/${TAG}_steps.log; }
 for step in "$@"; do
   log "$step"
   case $step in
     ktests)   timeout 600 python -m pytest $R/tests/test_kernels_gpu.py -m gpu -x -q -n 2 -k "conv or linear or shortk or w4 or phase or shortcut or broadcast or groupnorm_stat" 2>&1 | tail -5 | tee $O/${TAG}_ktests.log ;;
-    tests)    timeout 1500 python -m pytest $R/tests -m gpu -x -q 2>&1 | tail -15 | tee $O/${TAG}_tests.log
+    tests)    rm -f $O/parity.jsonl; timeout 1800 python -m pytest $R/tests -m gpu -x -q 2>&1 | tail -15 | tee $O/${TAG}_tests.log; cp $O/parity.jsonl $O/${TAG}_parity_full_suite.jsonl 2> /dev/null
               (cd $R && timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee -a $O/${TAG}_tests.log) ;;
-    tests_all) timeout 1500 python -m pytest $R/tests -m gpu -q 2>&1 | tail -40 | tee $O/${TAG}_tests.log
+    tests_all) rm -f $O/parity.jsonl; timeout 1800 python -m pytest $R/tests -m gpu -q 2>&1 | tail -40 | tee $O/${TAG}_tests.log; cp $O/parity.jsonl $O/${TAG}_parity_full_suite.jsonl 2> /dev/null
               (cd $R && timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 | tee -a $O/${TAG}_tests.log) ;;
-    shortk)   timeout 400 python $R/tools/bench_shortk.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_shortk.log ;;
-    shortk2)  UAV_CONV_SK=2 timeout 400 python $R/tools/bench_shortk.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_shortk_compiler_kstep.log ;;
-    trace)    UAV_CONV_W4_TRACE=1 timeout 300 python $R/tools/trace_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_trace.log ;;
-    trace_small) UAV_TRACE_SMALL=1 UAV_CONV_TILE=256 UAV_CONV_W4_MINK=0 UAV_CONV_W4_TRACE=1 timeout 300 python $R/tools/trace_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_trace_small_grids.log ;;
-    bench1_lnfold) (cd $R && UAV_LN_FOLD=1 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_lnfold.json) ;;
-    parity_lnfold) (cd $R && rm -f gpurun_out/parity.jsonl; UAV_LN_FOLD=1 timeout 900 python -m pytest tests/test_parity_r4_gpu.py -m gpu -q -k "headline" 2>&1 | tail -15 | tee $O/${TAG}_parity_lnfold.log; mv gpurun_out/parity.jsonl $O/${TAG}_parity_lnfold.jsonl 2> /dev/null) ;;
+    shortk) env $DEV   timeout 400 python $R/tools/bench_shortk.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_shortk.log ;;
+    shortk2) env $DEV  UAV_CONV_SK=2 timeout 400 python $R/tools/bench_shortk.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_shortk_compiler_kstep.log ;;
+    trace) env $DEV    UAV_CONV_W4_TRACE=1 timeout 300 python $R/tools/trace_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_trace.log ;;
+    trace_small) env $DEV UAV_TRACE_SMALL=1 UAV_CONV_TILE=256 UAV_CONV_W4_MINK=0 UAV_CONV_W4_TRACE=1 timeout 300 python $R/tools/trace_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_trace_small_grids.log ;;
+    bench1_lnfold) (cd $R && env $DEV UAV_LN_FOLD=1 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_lnfold.json) ;;
+    parity_lnfold) (cd $R && rm -f gpurun_out/parity.jsonl; env $DEV UAV_LN_FOLD=1 timeout 900 python -m pytest tests/test_parity_r4_gpu.py -m gpu -q -k "headline" 2>&1 | tail -15 | tee $O/${TAG}_parity_lnfold.log; mv gpurun_out/parity.jsonl $O/${TAG}_parity_lnfold.jsonl 2> /dev/null) ;;
     bench1_nt) (cd $R && UAV_HIP_LIB=$R/tools/ab/libuav_hip_nt.so timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee -a $O/${TAG}_bench1_nt_lib.json) ;;
     bench1_rep) (cd $R && timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee -a $O/${TAG}_bench1_rep.json) ;;
     mink_sweep) for mk in ${UAV_MINKS:-0 256 512 1024}; do (cd $R && UAV_CONV_W4_MINK=$mk timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | python -c "
@@ -53,7 +56,7 @@ print(json.dumps({'UAV_CONV_W4_MINK': $mk, 'frames_per_s': round(d['value'], 4),
     atests)   timeout 600 python -m pytest $R/tests/test_kernels_gpu.py $R/tests/test_clip_text_gpu.py -m gpu -x -q -k "attention or clip" 2>&1 | tail -5 | tee $O/${TAG}_attention_tests.log ;;
     bench1_prev) (cd $R && UAV_HIP_LIB=$R/tools/ab/libuav_hip_prev.so timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee -a $O/${TAG}_bench1_prev_lib.json) ;;
     bench1_head) (cd $R && UAV_HIP_LIB=$R/tools/ab/libuav_hip_head.so timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_head_lib.json) ;;
-    trace0)   UAV_CONV_W4_MINK=0 UAV_CONV_W4_TRACE=1 timeout 300 python $R/tools/trace_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_trace.log ;;
+    trace0) env $DEV   UAV_CONV_W4_MINK=0 UAV_CONV_W4_TRACE=1 timeout 300 python $R/tools/trace_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_trace.log ;;
     w4ab)     timeout 500 python $R/tools/bench_w4.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_w4_vs_8wave.log ;;
     epi)      timeout 400 python $R/tools/bench_epilogue.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_epilogue.log ;;
     epi_w40)  UAV_CONV_W4=0 timeout 400 python $R/tools/bench_epilogue.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_epilogue_8wave.log ;;
@@ -100,9 +103,9 @@ PY
     xattn)    timeout 300 python $R/tools/bench_xattn.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_xattn_fused_vs_chain.jsonl ;;
     xtrace)   timeout 300 python $R/tools/trace_xattn.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_xattn_phase_trace.jsonl ;;
     xtests)   timeout 600 python -m pytest $R/tests/test_kernels_gpu.py -m gpu -x -q -k "fused_cross or attention or hilo" 2>&1 | tail -8 | tee $O/${TAG}_xattn_tests.log ;;
-    bench1_tail) (cd $R && UAV_TAIL_HILO=1 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_tail_hilo.json) ;;
+    bench1_tail) (cd $R && UAV_TAIL_HILO=0 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_tail_hilo_off.json) ;;
     parity_head) (cd $R && rm -f gpurun_out/parity.jsonl; timeout 900 python -m pytest tests/test_parity_r4_gpu.py -m gpu -q -k "headline" 2>&1 | tail -6 | tee $O/${TAG}_parity_headline.log; mv gpurun_out/parity.jsonl $O/${TAG}_parity_headline.jsonl 2> /dev/null) ;;
-    parity_head_tail) (cd $R && rm -f gpurun_out/parity.jsonl; UAV_TAIL_HILO=1 timeout 900 python -m pytest tests/test_parity_r4_gpu.py -m gpu -q -k "headline" 2>&1 | tail -6 | tee $O/${TAG}_parity_headline_tail_hilo.log; mv gpurun_out/parity.jsonl $O/${TAG}_parity_headline_tail_hilo.jsonl 2> /dev/null) ;;
+    parity_head_tail) (cd $R && rm -f gpurun_out/parity.jsonl; UAV_TAIL_HILO=0 timeout 900 python -m pytest tests/test_parity_r4_gpu.py -m gpu -q -k "headline" 2>&1 | tail -6 | tee $O/${TAG}_parity_headline_tail_hilo_off.log; mv gpurun_out/parity.jsonl $O/${TAG}_parity_headline_tail_hilo_off.jsonl 2> /dev/null) ;;
     bench1_nox) (cd $R && UAV_XATTN_FUSED=0 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_four_launch_chain.json) ;;
     t32)      (cd $R && rm -f gpurun_out/parity.jsonl; UAV_PARITY_T32=1 timeout 1500 python -m pytest tests/test_parity_r6_gpu.py -m gpu -q -x 2>&1 | tail -8 | tee $O/${TAG}_parity_t32.log; mv gpurun_out/parity.jsonl $O/${TAG}_parity_configs3_t32_320.jsonl 2> /dev/null) ;;
     bench1_cfgsplit) (cd $R && timeout 400 python bench.py --overlap-streams 2 --overlap-split-cfg --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_cfg_branches_on_two_streams.json) ;;

@@ -410,6 +410,7 @@ constexpr int V5_BYTES = 512 * VT_STRIDE;      // 36 KiB
 constexpr int X5_BYTES = 8 * 4096;             // partial-S exchange
 constexpr int SMEM5 = 2 * K5_BYTES + V5_BYTES + X5_BYTES;
 
+#ifdef UAV_DEV_KERNELS       // round-1 pair-split form (100 B of scratch): development build only (UAV_ATTN512=0), VERDICT r5 #12
 __global__ __launch_bounds__(512, 2) void attn512_kernel(AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ks = smem;
@@ -556,6 +557,7 @@ __global__ __launch_bounds__(512, 2) void attn512_kernel(AttnArgs p) {
     }
 }
 
+#endif  // UAV_DEV_KERNELS
 // ---------------------------------------------------------------------------------------------
 // head_dim = 512, ONE WAVE PER SIMD (round 2).  The pair-split kernel above spends three barriers and a 32-KiB
 // partial-score exchange per 32-key tile because two waves share each query block.  Here a wave owns 32 queries and the
@@ -798,17 +800,19 @@ int launch_attn512(const AttnArgs& a, hipStream_t s) {
     // one wave per SIMD (attn512w) is the production kernel at every size since its fragment reads run ahead of the MFMAs:
     // 658 vs 407 TFLOP/s at L = 102 400, 428 vs 339 at L = 25 600 (200 workgroups on 256 CUs),
     // profiles/r02_ab_attn512_fragment_prefetch_run26.log; UAV_ATTN512=0 keeps the round-1 pair-split kernel reachable for A/B
+#ifdef UAV_DEV_KERNELS
     static const int variant = [] { const char* e = getenv("UAV_ATTN512"); return e ? atoi(e) : 1; }();
-    if (variant != 0) {
-        static UavDynLds ldsw;
-        if (int rc = uav_set_dyn_lds(ldsw, (const void*)attn512w_kernel, SMEM5W)) return rc;
-        hipLaunchKernelGGL(attn512w_kernel, dim3((a.lq + 127) / 128, 1, a.bq), dim3(256), SMEM5W, s, a);
+    if (variant == 0) {
+        static UavDynLds lds;
+        if (int rc = uav_set_dyn_lds(lds, (const void*)attn512_kernel, SMEM5)) return rc;
+        dim3 grid((a.lq + 127) / 128, 1, a.bq);
+        hipLaunchKernelGGL(attn512_kernel, grid, dim3(512), SMEM5, s, a);
         return uav_launch_status();
     }
-    static UavDynLds lds;
-    if (int rc = uav_set_dyn_lds(lds, (const void*)attn512_kernel, SMEM5)) return rc;
-    dim3 grid((a.lq + 127) / 128, 1, a.bq);
-    hipLaunchKernelGGL(attn512_kernel, grid, dim3(512), SMEM5, s, a);
+#endif
+    static UavDynLds ldsw;
+    if (int rc = uav_set_dyn_lds(ldsw, (const void*)attn512w_kernel, SMEM5W)) return rc;
+    hipLaunchKernelGGL(attn512w_kernel, dim3((a.lq + 127) / 128, 1, a.bq), dim3(256), SMEM5W, s, a);
     return uav_launch_status();
 }
 
@@ -852,7 +856,11 @@ extern "C" int uav_attention_f16(const void* q, int64_t q_stride, const void* k,
     switch (head_dim) {
         case 64: return launch_attn<64>(a, s);
         case 128: return launch_attn<128>(a, s);
-        case 512: return heads == 1 ? launch_attn512(a, s) : launch_attn<512>(a, s);
+#ifdef UAV_DEV_KERNELS
+        case 512: return heads == 1 ? launch_attn512(a, s) : launch_attn<512>(a, s);      // attn_kernel<512>: 1 160 B of scratch, development only
+#else
+        case 512: return heads == 1 ? launch_attn512(a, s) : UAV_ESHAPE;                  // d = 512 is the VAE's single-head attention
+#endif
         default: return UAV_ESHAPE;
     }
 }

@@ -280,6 +280,11 @@ inline unsigned nblk(long long n, int per) { return (unsigned)((n + per - 1) / p
 }  // namespace
 
 extern "C" int uav_version(void) { return UAV_ABI_VERSION; }
+#ifdef UAV_DEV_KERNELS
+extern "C" int uav_has_dev_kernels(void) { return 1; }
+#else
+extern "C" int uav_has_dev_kernels(void) { return 0; }
+#endif
 
 extern "C" int uav_device_check(int dev, char* name_out) {
     hipDeviceProp_t prop;

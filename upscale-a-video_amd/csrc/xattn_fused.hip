@@ -335,7 +335,12 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
     // pc ^ (r & 7): conflict-free both ways) and reads it back a ROW per instruction: every store is 1 KiB contiguous.
     __syncthreads();                                        // every wave is done reading fragments: the ring is free
     {
-        const unsigned wbuf = lds0 + (unsigned)(wave * XGROUP);
+        // lane-derived addresses from a FRESH lane id: kept live from the top of the kernel they are what hipcc spills across the head
+        // loop (the loop sits at the 256-VGPR limit); the build audit wants no scratch in any shipped kernel
+        int lane_;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\nv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
+        const int lane = lane_, l32 = lane_ & 31, hi = lane_ >> 5;
+        const unsigned wbuf = (unsigned)(size_t)(lptr_t)smem + (unsigned)(wave * XGROUP);
         float* const obase = p.out + (tile0 + wave * 32) * XC + lane * 4;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {

@@ -52,6 +52,7 @@ CONV_RELU, CONV_SIGMOID, CONV_TANH = 4, 8, 16
 # name -> (restype, argtypes); the complete export list of include/uav_hip.h
 SIGNATURES = {
     "uav_version": (C.c_int, []),
+    "uav_has_dev_kernels": (C.c_int, []),
     "uav_device_check": (C.c_int, [C.c_int, C.c_char_p]),
     "uav_conv_gemm_f16": (C.c_int, [C.POINTER(ConvParams), c_p]),
     "uav_conv_gemm_gn_chunk_rows": (C.c_int, [C.POINTER(ConvParams)]),

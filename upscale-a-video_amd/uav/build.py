@@ -33,10 +33,11 @@ def _digest():
 
 
 def conv_kernel_digest():
-    """Digest of the sources of the dominant kernel only (csrc/conv_gemm.hip + the shared device header): what a PMC traffic
+    """Digest of the sources of the dominant kernel family only (csrc/conv_*.hip / conv_*.h of the fp16 implicit GEMM + the shared device header): what a PMC traffic
     pass of the conv kernels stays valid for (bench.py replays profiles/pmc_conv_traffic.json only on a match)."""
     h = hashlib.sha256()
-    for f in (os.path.join(CSRC, "conv_gemm.hip"), os.path.join(CSRC, "uav_common.h")):
+    conv = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.startswith("conv_") and f.endswith((".hip", ".h")) and "f32" not in f)
+    for f in conv + [os.path.join(CSRC, "uav_common.h")]:
         with open(f, "rb") as fh:
             h.update(os.path.basename(f).encode()); h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
@@ -89,6 +90,7 @@ def _build_locked(objdir, verbose):
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
     audit_accumulator_file()
     audit_conv_scratch()
+    audit_no_scratch()
     with open(STAMP, "w") as fh:
         fh.write(_digest())
     if verbose:
@@ -196,6 +198,17 @@ def kernel_metadata(lib=None):
     return out
 
 
+def audit_no_scratch():
+    """every kernel SHIPPED in libuav_hip.so runs without a private segment and without a spilled VGPR (the legacy
+    instances that had scratch — attn512_kernel, attn_kernel<512>, the round-1 / LayerNorm-fold conv instances — are development
+    kernels now, -DUAV_DEV_KERNELS)."""
+    bad = [f"{n}: scratch {md.get('private_segment_fixed_size')} B, {md.get('vgpr_spill_count')} spilled VGPRs"
+           for n, md in kernel_metadata().items()
+           if int(md.get("private_segment_fixed_size", "0")) != 0 or int(md.get("vgpr_spill_count", "0")) != 0]
+    if bad:
+        raise RuntimeError("audit: shipped kernels must not use scratch:\n  " + "\n  ".join(bad))
+
+
 def audit_conv_scratch():
     """The rotated k-step of conv_gemm256i_kernel<6,*,0> and the one-statement k-step of conv_gemm256w_kernel carry LDS-DMA
     targets, staged constants and fragment registers across inline-asm statements with hand-counted vmcnt/lgkmcnt waits
@@ -207,12 +220,10 @@ def audit_conv_scratch():
     bad = []
     for name, md in meta.items():
         if "conv_gemm256w_kernel" in name or "conv_gemm256i_kernelILi6E" in name:
-            if name.endswith("ELi1EEEvNS_8ConvArgsE") and "conv_gemm256i_kernel" in name:
-                continue                                      # the traced 8-wave instance (s_memtime stores) is a tool, not a product path
             seen += 1
             if int(md.get("private_segment_fixed_size", "1")) != 0 or int(md.get("vgpr_spill_count", "1")) != 0:
                 bad.append(f"{name}: scratch {md.get('private_segment_fixed_size')} B, {md.get('vgpr_spill_count')} spilled VGPRs")
-    if seen < 8:
+    if seen < 9:          # conv_gemm256i_kernel<6, 0..3> + conv_gemm256w_kernel<0..3> + its hi | lo instance
         raise RuntimeError(f"audit: only {seen} conv_gemm256i<6,*>/conv_gemm256w instances found in {LIB}")
     if bad:
         raise RuntimeError("audit: the asm-scheduled conv kernels must not spill:\n  " + "\n  ".join(bad))

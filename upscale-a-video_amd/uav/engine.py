@@ -297,7 +297,10 @@ FUSE_SHORTCUT = _os.environ.get("UAV_FUSE_SHORTCUT", "1") != "0"
 # ... and the block TAILS — the last feed-forward output of a Transformer3DModel (operand of proj_out) and the tail ResNet of a
 # TemporalModule3D (operand of shift_conv), fp16 tensors that carry a whole residual sum — as fp32 rows read through the same
 # hi | lo pair by their 1x1 consumer?  UAV_TAIL_HILO (CPU emulation: 7.5e-4 -> 6.5e-4 per forward).
-TAIL_HILO = _os.environ.get("UAV_TAIL_HILO", "0") != "0"
+# Default 1 since round 6: the producer's epilogue writes the pair itself (UAV_CONV_OUT_HILO: no cast pass), which leaves the doubled K of
+# the 1x1 consumers as the only cost — measured at the headline shape (8 x 320x320, 30 steps, vs the GPU oracle, run 4 of round 6): latents
+# 8.2e-4 -> 7.3e-4, `.images` 9.5e-4 -> 8.7e-4 over all pixels / 1.23e-3 -> 1.12e-3 unclamped, for -1.2 % frames/s (1.1197 -> 1.1066 same box).
+TAIL_HILO = _os.environ.get("UAV_TAIL_HILO", "1") != "0"
 # samplers left on a single fp16 operand although SAMPLER_HILO is on: ("up" | "down", input height) pairs (numerics experiments)
 import threading as _threading
 
