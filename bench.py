@@ -240,7 +240,7 @@ def main():
     ap.add_argument("--timed-kernel-events", action="store_true",
                     help="HIP events around the dominant kernel (conv_gemm) INSIDE the timed region, as rounds 1-5 measured `roofline`.  Default "
                          "since round 6: the timed region carries no events (same-box A/B, twice interleaved: 1.1417 with / 1.1489 frames/s "
-                         "without the ~16 k event records per clip, +0.63 %, profiles/r06_event_overhead_ab_*.jsonl) and `roofline` + the "
+                         "without the ~16 k event records per clip, +0.63 %%, profiles/r06_event_overhead_ab_*.jsonl) and `roofline` + the "
                          "per-kernel table come from one extra fully instrumented clip right behind it, same process, same box")
     ap.add_argument("--all-kernel-events", action="store_true",
                     help="HIP events around EVERY kernel family inside the timed region (costs ~2 %%: 50 k event records of ~3 us "

@@ -230,6 +230,7 @@ int uav_attention_f16(const void* q, int64_t q_stride, const void* k, int64_t k_
  * only_cross_attention / attn2; CrossAttention.forward :177-238 = to_q, _attention :209-238, to_out):
  *
  *     out[m][:] = x[m][:] + b_out + W_out . softmax(scale * (W_q . LayerNorm(x[m][:])) . K_b^T) . V_b ,   b = m / rows_per_kv
+ * (applied once or twice: see n_subs)
  *
  * x / out: fp32 token-stream rows [rows][channels] (out may alias x: a workgroup reads its 128 rows before it writes them);
  * LayerNorm, Q, P and the attention output are rounded to fp16 exactly where the unfused chain stores them.
@@ -238,10 +239,20 @@ int uav_attention_f16(const void* q, int64_t q_stride, const void* k, int64_t k_
  *   produce them; csrc/xattn_fused.hip states the order.
  *   rows_per_kv % 128 == 0, rows % rows_per_kv == 0, channels == 512, heads == 8, lk <= 96; else UAV_ESHAPE (the caller
  *   keeps the four-launch chain for such shapes). */
-int uav_xattn_sublayer_f32(const float* x, float* out, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                           const void* wq_packed, const void* kv_packed, const void* wo_packed, const float* out_bias,
-                           int64_t rows, int32_t rows_per_kv, int32_t lk, int32_t channels, int32_t heads, float scale,
-                           void* stream);
+typedef struct {
+    const float* ln_gamma;      /* LayerNorm in front of the sub-layer: fp32 [channels] */
+    const float* ln_beta;
+    float        ln_eps;
+    const void*  wq_packed;     /* to_q weights, fragment stream (uav.ops.pack_xattn_weight 'q') */
+    const void*  kv_packed;     /* text K | V of this sub-layer's to_k / to_v (uav_xattn_pack_kv) */
+    const void*  wo_packed;     /* to_out weights, fragment stream ('out') */
+    const float* out_bias;      /* to_out bias: fp32 [channels] */
+} uav_xattn_params;
+/* n_subs = 1: one sub-layer; n_subs = 2: attn1 (only_cross_attention) and attn2 of one block back to back on the same rows — the
+ * first one's output stays in the accumulators, the second LayerNorm runs on it in registers (one read and one write of the stream
+ * for both). */
+int uav_xattn_sublayers_f32(const float* x, float* out, const uav_xattn_params* subs, int32_t n_subs, int64_t rows,
+                            int32_t rows_per_kv, int32_t lk, int32_t channels, int32_t heads, float scale, void* stream);
 /* k, v: fp16 rows [n_batch * lk][stride] (head h in columns h*head_dim ..) -> out: n_batch * heads * 32 KiB */
 int uav_xattn_pack_kv(const void* k, int64_t k_stride, const void* v, int64_t v_stride, int32_t n_batch, int32_t lk,
                       int32_t heads, int32_t head_dim, void* out, void* stream);

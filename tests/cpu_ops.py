@@ -200,6 +200,16 @@ def _unpack_xattn_kv(kvp, lk):
     return k[:, :lk].float(), v[:, :lk].float()
 
 
+def xattn_sublayers(x, subs, *, rows_per_kv, lk, scale, out=None):
+    y = x
+    for sub in subs:
+        y = xattn_sublayer(y, *sub, rows_per_kv=rows_per_kv, lk=lk, scale=scale)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 def xattn_sublayer(x, gamma, beta, eps, wq_packed, kv_packed, wo_packed, out_bias, *, rows_per_kv, lk, scale, out=None):
     wq = _unpack_xattn_weight(wq_packed, "q"); wo = _unpack_xattn_weight(wo_packed, "out")
     k, v = _unpack_xattn_kv(kv_packed, lk)                                            # (B, lk, 8, 64)
@@ -341,7 +351,7 @@ def sft_fuse(dec, scale, shift, w, out_f32=False):
     return y if out_f32 else _h(y)
 
 
-_OPS = ("ln_fold_ok", "resize_area_f32", "cast_f16", "cast_hilo", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "xattn_pack_kv", "xattn_sublayer", "temporal_attention", "linear_small",
+_OPS = ("ln_fold_ok", "resize_area_f32", "cast_f16", "cast_hilo", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "xattn_pack_kv", "xattn_sublayer", "xattn_sublayers", "temporal_attention", "linear_small",
         "timestep_embedding", "pack_nhwc", "unpack_ncthw", "axpby", "cfg_ddim_v0", "ddim_vt")
 
 

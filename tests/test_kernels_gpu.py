@@ -1070,3 +1070,32 @@ def test_conv_result_as_hilo_pair_is_bit_identical_to_cast_pass(ops, dev, case):
     if res is not None:
         p.residual = res.data_ptr(); p.res_stride = cout
     assert bool(lib.uav_conv_gemm_hilo_ok(C.byref(p))) == (not e.get("fallback", False))
+
+
+def test_fused_cross_attention_pair_equals_two_single_launches(ops, dev):
+    """n_subs = 2 (attn1 with only_cross_attention + attn2 of one block, attention.py:523-564): the second LayerNorm runs on the accumulators
+    that hold the first sub-layer's fp32 output — the same values a first launch would have stored and a second one re-read, so the pair
+    must reproduce two single launches up to the fp32 summation order of the LayerNorm statistics."""
+    g = torch.Generator().manual_seed(321)
+    C, D, nb, rpk, lk = 512, 64, 2, 1280, 77
+    M = nb * rpk
+    x = (torch.randn(M, C, generator=g) * 1.4 + 0.5).to(dev)
+    subs = []
+    for _ in range(2):
+        gamma = (torch.randn(C, generator=g) * 0.2 + 1.0).to(dev); beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+        wq = h16(C, C, dev=dev, scale=C ** -0.5, gen=g); wo = h16(C, C, dev=dev, scale=C ** -0.5, gen=g)
+        bo = (torch.randn(C, generator=g) * 0.1).to(dev)
+        kv = (torch.randn(nb * lk, 2 * C, generator=g) * 1.5).half().to(dev)
+        kvp = ops.xattn_pack_kv(kv[:, :C], kv[:, C:], n_batch=nb, lk=lk, k_stride=2 * C, v_stride=2 * C)
+        subs.append((gamma, beta, 1e-5, ops.pack_xattn_weight(wq, "q", dev), kvp, ops.pack_xattn_weight(wo, "out", dev), bo))
+    kw = dict(rows_per_kv=rpk, lk=lk, scale=D ** -0.5)
+    y1 = ops.xattn_sublayers(x, [subs[0]], **kw)
+    y2 = ops.xattn_sublayers(y1, [subs[1]], **kw)
+    yp = ops.xattn_sublayers(x, subs, **kw)
+    assert bool(torch.isfinite(yp).all())
+    e = rel_l2(yp, y2)
+    e_upd = rel_l2(yp - y1, y2 - y1)
+    assert e < 5e-5 and e_upd < 1e-3, (e, e_upd)              # LayerNorm statistics: two-pass in registers vs the shifted one-pass of the first read
+    assert torch.equal(ops.xattn_sublayers(x, subs, **kw), yp)
+    xin = x.clone()
+    assert ops.xattn_sublayers(xin, subs, out=xin, **kw) is xin and torch.equal(xin, yp)      # in place

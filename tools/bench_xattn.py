@@ -49,9 +49,11 @@ def case(name, nb, rpk):
     def out(): st["y"] = ops.linear(st["o"], co, residual=x, out_f32=True)
     def chain(): ln(); toq(); att(); out()
     def fused(): st["f"] = ops.xattn_sublayer(x, gamma, beta, 1e-5, wqp, kvp, wop, bo, rows_per_kv=rpk, lk=LK, scale=scale)
+    sub = (gamma, beta, 1e-5, wqp, kvp, wop, bo)
+    def pair(): st["p"] = ops.xattn_sublayers(x, [sub, sub], rows_per_kv=rpk, lk=LK, scale=scale)       # two sub-layers (same weights here) in one launch
 
-    fns = {"fused": fused, "chain": chain, "layernorm": ln, "to_q": toq, "attention": att, "to_out": out}
-    chain(); fused(); chain(); fused()
+    fns = {"fused": fused, "pair": pair, "chain": chain, "layernorm": ln, "to_q": toq, "attention": att, "to_out": out}
+    chain(); fused(); pair(); chain(); fused()
     torch.cuda.synchronize()
     t = {kk: [] for kk in fns}
     for _ in range(ROUNDS):
@@ -65,6 +67,7 @@ def case(name, nb, rpk):
     d["fused_tflops"] = round(fl / med / 1e9, 1)
     d["fused_algorithmic_GBps"] = round(8.0 * m * C / med / 1e6, 0)
     d["speedup_vs_chain"] = round(d["chain_ms"]["median"] / med, 3)
+    d["pair_speedup_vs_two_chains"] = round(2 * d["chain_ms"]["median"] / d["pair_ms"]["median"], 3)
     print(json.dumps(d), flush=True)
 
 

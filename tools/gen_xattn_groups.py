@@ -25,7 +25,13 @@ def group(n, base, cb, dma, first=False):
         t = f"t{f % D}"
         z = "0" if (first and c not in seen) else ""
         seen.add(c)
-        if f + D < n:
+        if c.startswith("A"):                       # named accumulator tile
+            lo = int(c[1:])
+            if f + D < n:
+                out.append(f"XSA({t}, {lo}, {lo + 15}, {b}, {D - 1}, {(base + f + D) * 1024})")
+            else:
+                out.append(f"XTA({t}, {lo}, {lo + 15}, {b}, {min(D - 1, n - 1 - f)})")
+        elif f + D < n:
             out.append(f"XS{z}({t}, {c}, {b}, {D - 1}, {(base + f + D) * 1024})")
         else:
             out.append(f"XT{z}({t}, {c}, {b}, {min(D - 1, n - 1 - f)})")
@@ -43,7 +49,9 @@ if __name__ == "__main__":
     dv = {1: 4, 4: 5, 7: 6, 10: 7}                              # V part: pieces 4..7
     txt = fmt("XG_WQ_FIRST", group(32, 0, lambda f: (f"q{f & 1}", f"b{f >> 1}"), d32, first=True)) + "\n"
     txt += fmt("XG_WQ", group(32, 0, lambda f: (f"q{f & 1}", f"b{f >> 1}"), d32)) + "\n"
-    txt += fmt("XG_WO", group(32, 0, lambda f: (f"c{2 * (f >> 3) + (f & 1)}", f"b{(f >> 1) & 3}"), d32)) + "\n"
+    # W_out: the 256 accumulators of the tile live in a[0:255] BY NAME (tile nt = a[16 nt : 16 nt + 15]); group j covers tiles 8 j .. 8 j + 7
+    for j in range(2):
+        txt += fmt(f"XG_WO{j}", group(32, 0, lambda f: (f"A{16 * (8 * j + 2 * (f >> 3) + (f & 1))}", f"b{(f >> 1) & 3}"), d32)) + "\n"
     txt += fmt("XG_K", group(12, 0, lambda f: (f"c{f % 3}", f"b{f // 3}"), dk, first=True)) + "\n"
     txt += fmt("XG_V", group(12, 12, lambda f: (f"c{f & 1}", f"b{f >> 1}"), dv, first=True))
     print(txt, end="")

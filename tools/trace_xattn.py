@@ -16,8 +16,9 @@ from uav import ops  # noqa: E402
 dev = torch.device("cuda:0")
 lib = C.CDLL(os.path.join(ROOT, "tools", "ab", "libuav_xattn_dev.so"))
 c_p, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
-lib.uav_dev_xattn_sublayer_trace.restype = C.c_int
-lib.uav_dev_xattn_sublayer_trace.argtypes = [c_p, c_p, c_p, c_p, f32, c_p, c_p, c_p, c_p, i64, i32, i32, f32, c_p, c_p]
+lib.uav_dev_xattn_sublayers_trace.restype = C.c_int
+lib.uav_dev_xattn_sublayers_trace.argtypes = [c_p, c_p, c_p, i32, i64, i32, i32, f32, c_p, c_p]
+from uav._lib import XattnParams  # noqa: E402
 PHASES = ["statistics pass (1st read of x)", "operands + accumulators (2nd read)", "head 0 (cold ring)", "head 1: Q GEMM, 64 MFMA",
           "head 1: S = K Q, 12 MFMA", "head 1: softmax", "head 1: O = V P, 12 MFMA", "head 1: acc += Wout O, 64 MFMA", "heads 2 .. 7",
           "drain + stores"]
@@ -39,9 +40,11 @@ def case(name, nb, rpk, lk=77):
     ntile = m // 128
     tr = torch.zeros(ntile * 16, dtype=torch.int64, device=dev)
     st = torch.cuda.current_stream().cuda_stream
+    arr = (XattnParams * 1)()
+    arr[0].ln_gamma, arr[0].ln_beta, arr[0].ln_eps = gamma.data_ptr(), beta.data_ptr(), 1e-5
+    arr[0].wq_packed, arr[0].kv_packed, arr[0].wo_packed, arr[0].out_bias = wqp.data_ptr(), kvp.data_ptr(), wop.data_ptr(), bo.data_ptr()
     for _ in range(3):
-        rc = lib.uav_dev_xattn_sublayer_trace(x.data_ptr(), out.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1e-5, wqp.data_ptr(), kvp.data_ptr(),
-                                              wop.data_ptr(), bo.data_ptr(), m, rpk, lk, D ** -0.5, tr.data_ptr(), st)
+        rc = lib.uav_dev_xattn_sublayers_trace(x.data_ptr(), out.data_ptr(), C.cast(arr, c_p), 1, m, rpk, lk, D ** -0.5, tr.data_ptr(), st)
         assert rc == 0, rc
     torch.cuda.synchronize()
     assert torch.equal(out, ref), "the stamped instance must compute what the product instance computes"

@@ -29,6 +29,7 @@
 // Roundings are those of the unfused chain (LayerNorm output, Q, P, O rounded to fp16; everything else fp32), so the result
 // agrees with it to fp32 summation order (tests/test_kernels_gpu.py::test_fused_cross_attention_sublayer).
 #include "uav_common.h"
+#include <utility>
 
 namespace {
 
@@ -39,13 +40,18 @@ constexpr int XRING = 4;                       // groups resident in LDS
 constexpr int XGPH = 5;                        // groups per head: W_q (2), K | V^T (1), W_out (2)
 constexpr int XNG = XHEADS * XGPH;             // groups per tile
 constexpr int XPPW = 8;                        // 1-KiB DMA pieces per wave and group
-constexpr int XTAB = XRING * XGROUP;           // LDS offset of gamma | beta | bias (3 x 2 KiB)
-constexpr int XSMEM = XTAB + 3 * XC * 4;
+constexpr int XTAB = XRING * XGROUP;           // LDS offset of gamma | beta | bias (3 x 2 KiB) of the first sub-layer, then of the second
+constexpr int XTABS = 3 * XC * 4;
+constexpr int XSMEM = XTAB + 2 * XTABS;
 
+struct XattnSub {                              // one sub-layer: its LayerNorm, its packed projections, the text K | V of its to_k / to_v
+    const float* gamma; const float* beta; const float* bias;
+    const char* wq; const char* kv; const char* wo; float eps;
+};
 struct XattnArgs {
-    const float* x; float* out; const float* gamma; const float* beta; const float* bias;
-    const char* wq; const char* kv; const char* wo;
-    long long rows; int rows_per_kv; int lk; float eps, scale_log2;
+    const float* x; float* out;
+    XattnSub sub[2]; int nsub;                 // 1, or 2 consecutive sub-layers of one block (attn1 with only_cross_attention, then attn2)
+    long long rows; int rows_per_kv; int lk; float scale_log2;
     unsigned long long* trace;                 // development instance only (UAV_DEV_KERNELS): 16 s_memtime stamps per workgroup
 };
 
@@ -70,12 +76,43 @@ UAV_DEVINL void dma_piece(uint4_t srd, unsigned voff, unsigned soff, unsigned ld
 template <int N> UAV_DEVINL void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 UAV_DEVINL float swap32(float v) { return __shfl_xor(v, 32, 64); }
 
+// The 256 fp32 accumulators of a wave's 32 tokens x 512 channels live in the accumulator half of the register file BY NAME — channel
+// tile nt in a[16 nt : 16 nt + 15] — like the O^T tile of attn512w_kernel (attention.hip): as C++ tuples that asm statements take as
+// "+a" operands AND the VALU touches (residual in, second LayerNorm, store) hipcc shuffled them between the two halves and spilled 34 ...
+// 1 679 registers per lane.  Every statement that names them lists the whole accumulator file as clobbered — that also makes the kernel
+// descriptor allocate it — and the compiler never uses AGPRs itself (build audit: uav/build.py audit_accumulator_file).
+#define XACC_CLOBBERS "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15", \
+    "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31", \
+    "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47", \
+    "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63", \
+    "a64", "a65", "a66", "a67", "a68", "a69", "a70", "a71", "a72", "a73", "a74", "a75", "a76", "a77", "a78", "a79", \
+    "a80", "a81", "a82", "a83", "a84", "a85", "a86", "a87", "a88", "a89", "a90", "a91", "a92", "a93", "a94", "a95", \
+    "a96", "a97", "a98", "a99", "a100", "a101", "a102", "a103", "a104", "a105", "a106", "a107", "a108", "a109", "a110", "a111", \
+    "a112", "a113", "a114", "a115", "a116", "a117", "a118", "a119", "a120", "a121", "a122", "a123", "a124", "a125", "a126", "a127", \
+    "a128", "a129", "a130", "a131", "a132", "a133", "a134", "a135", "a136", "a137", "a138", "a139", "a140", "a141", "a142", "a143", \
+    "a144", "a145", "a146", "a147", "a148", "a149", "a150", "a151", "a152", "a153", "a154", "a155", "a156", "a157", "a158", "a159", \
+    "a160", "a161", "a162", "a163", "a164", "a165", "a166", "a167", "a168", "a169", "a170", "a171", "a172", "a173", "a174", "a175", \
+    "a176", "a177", "a178", "a179", "a180", "a181", "a182", "a183", "a184", "a185", "a186", "a187", "a188", "a189", "a190", "a191", \
+    "a192", "a193", "a194", "a195", "a196", "a197", "a198", "a199", "a200", "a201", "a202", "a203", "a204", "a205", "a206", "a207", \
+    "a208", "a209", "a210", "a211", "a212", "a213", "a214", "a215", "a216", "a217", "a218", "a219", "a220", "a221", "a222", "a223", \
+    "a224", "a225", "a226", "a227", "a228", "a229", "a230", "a231", "a232", "a233", "a234", "a235", "a236", "a237", "a238", "a239", \
+    "a240", "a241", "a242", "a243", "a244", "a245", "a246", "a247", "a248", "a249", "a250", "a251", "a252", "a253", "a254", "a255"
+// accumulator N <- v / -> v (N a compile-time constant: the callers unroll over std::integral_constant)
+template <int N> UAV_DEVINL void acc_set(float v) { asm volatile("v_accvgpr_write_b32 a%c0, %1" :: "i"(N), "v"(v) : XACC_CLOBBERS); }
+template <int N> UAV_DEVINL float acc_get() { float v; asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(v) : "i"(N) : XACC_CLOBBERS); return v; }
+template <int... I, class F> UAV_DEVINL void static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F> UAV_DEVINL void static_for(F&& f) { static_for_impl(std::make_integer_sequence<int, N>{}, f); }
+
 // ---- the asm walk of a group: XRD = read fragment into t, XS = wait for the oldest read, MFMA on it, refill its register,
 // XT = the same without a refill (tail).  Fragment f of a group sits at byte f * 1024 (+ 16 * lane) of the slot.
 #define XRD(T, OFF) "ds_read_b128 %[" #T "], %[st] offset:" #OFF "\n"
 #define XMF(C, A, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #A "], %[" #B "], %[" #C "]\n"
 #define XS(T, C, B, WN, OFF) "s_waitcnt lgkmcnt(" #WN ")\n" XMF(C, T, B) XRD(T, OFF)
 #define XT(T, C, B, WN) "s_waitcnt lgkmcnt(" #WN ")\n" XMF(C, T, B)
+// MFMA on a NAMED accumulator tile a[LO:HI] (the 256 output accumulators, see XACC_CLOBBERS)
+#define XMFA(LO, HI, A, B) "v_mfma_f32_32x32x16_f16 a[" #LO ":" #HI "], %[" #A "], %[" #B "], a[" #LO ":" #HI "]\n"
+#define XSA(T, LO, HI, B, WN, OFF) "s_waitcnt lgkmcnt(" #WN ")\n" XMFA(LO, HI, T, B) XRD(T, OFF)
+#define XTA(T, LO, HI, B, WN) "s_waitcnt lgkmcnt(" #WN ")\n" XMFA(LO, HI, T, B)
 // the first MFMA on an accumulator: C = the inline constant 0 (the accumulator is a pure output: nothing to zero, no zero tuple kept live)
 #define XMF0(C, A, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #A "], %[" #B "], 0\n"
 #define XS0(T, C, B, WN, OFF) "s_waitcnt lgkmcnt(" #WN ")\n" XMF0(C, T, B) XRD(T, OFF)
@@ -111,16 +148,31 @@ UAV_DEVINL float swap32(float v) { return __shfl_xor(v, 32, 64); }
     XS(t0, q0, b12, 5, 30720) XS(t1, q1, b12, 5, 31744) XT(t2, q0, b13, 5) XD(4096, 2048) XT(t3, q1, b13, 4) \
     XT(t4, q0, b14, 3) XT(t5, q1, b14, 2) XT(t0, q0, b15, 1) XD(4096, 3072) XT(t1, q1, b15, 0)
 
-#define XG_WO \
-    XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XS(t0, c0, b0, 5, 6144) \
-    XS(t1, c1, b0, 5, 7168) XS(t2, c0, b1, 5, 8192) XD(0, 0) XS(t3, c1, b1, 5, 9216) XS(t4, c0, b2, 5, 10240) \
-    XS(t5, c1, b2, 5, 11264) XS(t0, c0, b3, 5, 12288) XD(0, 1024) XS(t1, c1, b3, 5, 13312) XS(t2, c2, b0, 5, 14336) \
-    XS(t3, c3, b0, 5, 15360) XS(t4, c2, b1, 5, 16384) XD(0, 2048) XS(t5, c3, b1, 5, 17408) XS(t0, c2, b2, 5, 18432) \
-    XS(t1, c3, b2, 5, 19456) XS(t2, c2, b3, 5, 20480) XD(0, 3072) XDADV XS(t3, c3, b3, 5, 21504) XS(t4, c4, b0, 5, 22528) \
-    XS(t5, c5, b0, 5, 23552) XS(t0, c4, b1, 5, 24576) XD(4096, 0) XS(t1, c5, b1, 5, 25600) XS(t2, c4, b2, 5, 26624) \
-    XS(t3, c5, b2, 5, 27648) XS(t4, c4, b3, 5, 28672) XD(4096, 1024) XS(t5, c5, b3, 5, 29696) XS(t0, c6, b0, 5, 30720) \
-    XS(t1, c7, b0, 5, 31744) XT(t2, c6, b1, 5) XD(4096, 2048) XT(t3, c7, b1, 4) XT(t4, c6, b2, 3) XT(t5, c7, b2, 2) \
-    XT(t0, c6, b3, 1) XD(4096, 3072) XT(t1, c7, b3, 0)
+#define XG_WO0 \
+    XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XSA(t0, 0, 15, b0, 5, 6144) \
+    XSA(t1, 16, 31, b0, 5, 7168) XSA(t2, 0, 15, b1, 5, 8192) XD(0, 0) XSA(t3, 16, 31, b1, 5, 9216) \
+    XSA(t4, 0, 15, b2, 5, 10240) XSA(t5, 16, 31, b2, 5, 11264) XSA(t0, 0, 15, b3, 5, 12288) XD(0, 1024) \
+    XSA(t1, 16, 31, b3, 5, 13312) XSA(t2, 32, 47, b0, 5, 14336) XSA(t3, 48, 63, b0, 5, 15360) \
+    XSA(t4, 32, 47, b1, 5, 16384) XD(0, 2048) XSA(t5, 48, 63, b1, 5, 17408) XSA(t0, 32, 47, b2, 5, 18432) \
+    XSA(t1, 48, 63, b2, 5, 19456) XSA(t2, 32, 47, b3, 5, 20480) XD(0, 3072) XDADV XSA(t3, 48, 63, b3, 5, 21504) \
+    XSA(t4, 64, 79, b0, 5, 22528) XSA(t5, 80, 95, b0, 5, 23552) XSA(t0, 64, 79, b1, 5, 24576) XD(4096, 0) \
+    XSA(t1, 80, 95, b1, 5, 25600) XSA(t2, 64, 79, b2, 5, 26624) XSA(t3, 80, 95, b2, 5, 27648) \
+    XSA(t4, 64, 79, b3, 5, 28672) XD(4096, 1024) XSA(t5, 80, 95, b3, 5, 29696) XSA(t0, 96, 111, b0, 5, 30720) \
+    XSA(t1, 112, 127, b0, 5, 31744) XTA(t2, 96, 111, b1, 5) XD(4096, 2048) XTA(t3, 112, 127, b1, 4) \
+    XTA(t4, 96, 111, b2, 3) XTA(t5, 112, 127, b2, 2) XTA(t0, 96, 111, b3, 1) XD(4096, 3072) XTA(t1, 112, 127, b3, 0)
+
+#define XG_WO1 \
+    XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XSA(t0, 128, 143, b0, 5, 6144) \
+    XSA(t1, 144, 159, b0, 5, 7168) XSA(t2, 128, 143, b1, 5, 8192) XD(0, 0) XSA(t3, 144, 159, b1, 5, 9216) \
+    XSA(t4, 128, 143, b2, 5, 10240) XSA(t5, 144, 159, b2, 5, 11264) XSA(t0, 128, 143, b3, 5, 12288) XD(0, 1024) \
+    XSA(t1, 144, 159, b3, 5, 13312) XSA(t2, 160, 175, b0, 5, 14336) XSA(t3, 176, 191, b0, 5, 15360) \
+    XSA(t4, 160, 175, b1, 5, 16384) XD(0, 2048) XSA(t5, 176, 191, b1, 5, 17408) XSA(t0, 160, 175, b2, 5, 18432) \
+    XSA(t1, 176, 191, b2, 5, 19456) XSA(t2, 160, 175, b3, 5, 20480) XD(0, 3072) XDADV XSA(t3, 176, 191, b3, 5, 21504) \
+    XSA(t4, 192, 207, b0, 5, 22528) XSA(t5, 208, 223, b0, 5, 23552) XSA(t0, 192, 207, b1, 5, 24576) XD(4096, 0) \
+    XSA(t1, 208, 223, b1, 5, 25600) XSA(t2, 192, 207, b2, 5, 26624) XSA(t3, 208, 223, b2, 5, 27648) \
+    XSA(t4, 192, 207, b3, 5, 28672) XD(4096, 1024) XSA(t5, 208, 223, b3, 5, 29696) XSA(t0, 224, 239, b0, 5, 30720) \
+    XSA(t1, 240, 255, b0, 5, 31744) XTA(t2, 224, 239, b1, 5) XD(4096, 2048) XTA(t3, 240, 255, b1, 4) \
+    XTA(t4, 224, 239, b2, 3) XTA(t5, 240, 255, b2, 2) XTA(t0, 224, 239, b3, 1) XD(4096, 3072) XTA(t1, 240, 255, b3, 0)
 
 #define XG_K \
     XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XS0(t0, c0, b0, 5, 6144) \
@@ -149,48 +201,53 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
     const int b = __builtin_amdgcn_readfirstlane((int)(tile0 / p.rows_per_kv));
     const long long row = tile0 + wave * 32 + l32;
 
-    // ---- the stream of A fragments: 40 groups of 32 KiB, eight 1-KiB pieces per wave and group ---------------------------------
-    const uint4_t srd_wq = make_srd(p.wq, XHEADS * 2 * XGROUP);
-    const uint4_t srd_wo = make_srd(p.wo, XHEADS * 2 * XGROUP);
-    const uint4_t srd_kv = make_srd(p.kv + (long long)b * XHEADS * XGROUP, XHEADS * XGROUP);
+    // ---- the stream of A fragments: 40 groups of 32 KiB per sub-layer, eight 1-KiB pieces per wave and group; a second sub-layer's
+    // groups follow the first's without a gap (the ring never drains between the two) ---------------------------------------------
     const unsigned voff = (unsigned)(wave * XPPW * XFRAG + lane * 16);
+    const int ngroups = __builtin_amdgcn_readfirstlane(p.nsub * XNG);
     struct Next { uint4_t srd; unsigned so, ldsn; };       // the group XRING - 1 = 3 ahead: its source and its ring slot
-    auto next_of = [&](int h, int j) -> Next {            // (h, j): group j (0, 1: W_q; 2: K | V; 3, 4: W_out) of head h
+    auto next_of = [&](int s) -> Next {                    // s: group index over all sub-layers; inside one: head s / 5, group j = s % 5 (0, 1: W_q; 2: K | V; 3, 4: W_out)
         Next n;
-        const int s = h * XGPH + j;
         n.ldsn = lds0 + (unsigned)((s & (XRING - 1)) * XGROUP + wave * XPPW * XFRAG);
-        if (j < 2) { n.srd = srd_wq; n.so = (unsigned)((h * 2 + j) * XGROUP); }
-        else if (j == 2) { n.srd = srd_kv; n.so = (unsigned)(h * XGROUP); }
-        else { n.srd = srd_wo; n.so = (unsigned)((h * 2 + (j - 3)) * XGROUP); }
+        const int u = s >= XNG ? 1 : 0, r = s - u * XNG;
+        const int h = r / XGPH, j = r - h * XGPH;
+        const XattnSub& S = p.sub[u && p.nsub > 1 ? 1 : 0];
+        if (j < 2) { n.srd = make_srd(S.wq, XHEADS * 2 * XGROUP); n.so = (unsigned)((h * 2 + j) * XGROUP); }
+        else if (j == 2) { n.srd = make_srd(S.kv + (long long)b * XHEADS * XGROUP, XHEADS * XGROUP); n.so = (unsigned)(h * XGROUP); }
+        else { n.srd = make_srd(S.wo, XHEADS * 2 * XGROUP); n.so = (unsigned)((h * 2 + (j - 3)) * XGROUP); }
         // behind the last group of the tile: the same eight pieces with every lane out of the descriptor's range — the hardware fetches
         // nothing and zero-fills a slot nobody reads again, and the vmcnt arithmetic below stays the same for every group
-        if (s >= XNG) n.so = 0x80000000u;
+        if (s >= ngroups) n.so = 0x80000000u;
         return n;
     };
-    auto issue = [&](int h, int j) {                       // prologue: a whole group at once
-        Next n = next_of(h, j);
+    auto issue = [&](int s) {                              // prologue: a whole group at once
+        Next n = next_of(s);
 #pragma unroll
         for (int i = 0; i < XPPW; ++i) dma_piece(n.srd, voff, n.so + i * XFRAG, n.ldsn + i * XFRAG);
     };
-    // before group (h, j) is read: this wave's pieces of it have landed (the two groups issued behind it may still fly: 16 pieces),
+    // before group s is read: this wave's pieces of it have landed (the two groups issued behind it may still fly: 16 pieces),
     // then every wave's have (barrier) — which also says every wave is done with the group before it, whose slot the group three
     // ahead is written into WHILE this group is multiplied (the pieces sit between the MFMAs of the asm walk).
     Next nx;
-    auto group_sync = [&](int h, int j) -> unsigned {
+    auto group_sync = [&](int s) -> unsigned {
         wait_vmcnt<XPPW * (XRING - 2)>();
         __syncthreads();
-        const int jn = j + XRING - 1;                      // (h, j + 3) or (h + 1, j - 2)
-        nx = next_of(jn < XGPH ? h : h + 1, jn < XGPH ? jn : jn - XGPH);
-        return lds0 + (unsigned)(((h * XGPH + j) & (XRING - 1)) * XGROUP) + lane * 16;
+        nx = next_of(s + XRING - 1);
+        return lds0 + (unsigned)((s & (XRING - 1)) * XGROUP) + lane * 16;
     };
 
 #pragma unroll
-    for (int s = 0; s < XRING - 1; ++s) issue(0, s);
+    for (int s = 0; s < XRING - 1; ++s) issue(s);
     // ---- tables -> LDS; LayerNorm statistics of the lane's token ------------------------------------------------------------------
-    if (tid < 128) {
-        *(lds_f4wptr_t)(size_t)(lds0 + XTAB + tid * 16) = ((const float4_t*)p.gamma)[tid];
-        *(lds_f4wptr_t)(size_t)(lds0 + XTAB + 2048 + tid * 16) = ((const float4_t*)p.beta)[tid];
-        *(lds_f4wptr_t)(size_t)(lds0 + XTAB + 4096 + tid * 16) = ((const float4_t*)p.bias)[tid];
+    {
+        const int u = tid >> 7, t7 = tid & 127;             // threads 0 .. 127: first sub-layer, 128 .. 255: second
+        if (u < p.nsub) {
+            const XattnSub& S = p.sub[u];
+            const unsigned tb = lds0 + XTAB + u * XTABS + t7 * 16;
+            *(lds_f4wptr_t)(size_t)tb = ((const float4_t*)S.gamma)[t7];
+            *(lds_f4wptr_t)(size_t)(tb + 2048) = ((const float4_t*)S.beta)[t7];
+            *(lds_f4wptr_t)(size_t)(tb + 4096) = ((const float4_t*)S.bias)[t7];
+        }
     }
     // The lane holds half of its token's row (channels 32 j + 8 q + 4 hi + i), lane ^ 32 the other half.  The row is read TWICE —
     // once for the statistics, once (from L2) for the operand and the residual — because 256 fp32 values + the 128 operand registers
@@ -217,38 +274,67 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
     if (TR) ts[1] = __builtin_amdgcn_s_memtime();           // statistics pass done (first read of the rows)
     const float m1 = s1 * (1.0f / XC);
     const float mean = c0 + m1;
-    const float rstd = rsqrtf(fmaxf(s2 * (1.0f / XC) - m1 * m1, 0.f) + p.eps);
+    const float rstd = rsqrtf(fmaxf(s2 * (1.0f / XC) - m1 * m1, 0.f) + p.sub[0].eps);
     __syncthreads();                                        // tables visible
     // ---- second read: Xn fp16 B fragments (k-step ks = 2 j + qp  <-  values 8 qp .. 8 qp + 7 of tile j) and the accumulators' initial
     // value (x + b_out: the residual) ----------------------------------------------------------------------------------------------
-    float16_t acc[16];
     half8_t xn[32];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
+    static_for<16>([&](auto J) {
+        constexpr int j = J;
+        static_for<4>([&](auto Q) {
+            constexpr int q = Q;
             const float4_t v = *(const float4_t*)(xr + 32 * j + 8 * q);
             const unsigned ta = lds0 + XTAB + (32 * j + 8 * q + 4 * hi) * 4;
             const float4_t g = lds_f4(ta), be = lds_f4(ta + 2048), bo = lds_f4(ta + 4096);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            static_for<4>([&](auto I) {
+                constexpr int i = I;
                 xn[2 * j + (q >> 1)][4 * (q & 1) + i] = (half_t)((v[i] - mean) * rstd * g[i] + be[i]);
-                acc[j][4 * q + i] = v[i] + bo[i];           // out = (x + b_out) + sum over heads
-            }
-        }
-        if (j == 7 || j == 11) __builtin_amdgcn_sched_barrier(0);       // batches of 32, 16, 16 loads: the operand registers fill up as the rows turn into them
-    }
+                acc_set<16 * j + 4 * q + i>(v[i] + bo[i]);  // out = (x + b_out) + sum over heads
+            });
+        });
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);            // batches of 16 loads: the operand registers fill up as the rows turn into them
+    });
 
-    if (TR) ts[2] = __builtin_amdgcn_s_memtime();           // operand fragments and accumulators built (second read)
+    auto mid_layernorm = [&]() {
+        // ---- the NEXT sub-layer of the block on the same tile: its input is what the accumulators hold (the first sub-layer's output —
+        // fp32, exactly the rows the four-launch chain would have written and read back), so its LayerNorm runs on them in place: two
+        // passes like layernorm_kernel, new operand fragments over the old, + its output bias.  One prologue and one epilogue for two
+        // sub-layers, and the stream between them never touches HBM. -----------------------------------------------------------------
+        asm volatile("s_nop 15\ns_nop 15" ::: "memory");    // the last MFMAs of the head loop may still be in flight and the compiler cannot see them
+        float sm = 0.f;
+        static_for<256>([&](auto N) { sm += acc_get<N>(); });
+        sm += swap32(sm);
+        const float mean2 = sm * (1.0f / XC);
+        float sq = 0.f;
+        static_for<256>([&](auto N) { const float d = acc_get<N>() - mean2; sq += d * d; });
+        sq += swap32(sq);
+        const float rstd2 = rsqrtf(sq * (1.0f / XC) + p.sub[1].eps);
+        static_for<16>([&](auto J) {
+            constexpr int j = J;
+            static_for<4>([&](auto Q) {
+                constexpr int q = Q;
+                const unsigned ta = lds0 + XTAB + XTABS + (32 * j + 8 * q + 4 * hi) * 4;
+                const float4_t g = lds_f4(ta), be = lds_f4(ta + 2048), bo = lds_f4(ta + 4096);
+                static_for<4>([&](auto I) {
+                    constexpr int i = I;
+                    const float v = acc_get<16 * j + 4 * q + i>();
+                    xn[2 * j + (q >> 1)][4 * (q & 1) + i] = (half_t)((v - mean2) * rstd2 * g[i] + be[i]);
+                    acc_set<16 * j + 4 * q + i>(v + bo[i]);
+                });
+            });
+        });
+    };
+    auto run_heads = [&](const int sub) {
     // ---- heads ----------------------------------------------------------------------------------------------------------------
 #pragma unroll 1
     for (int h = 0; h < XHEADS; ++h) {
         half8_t t0, t1, t2, t3, t4, t5;
-        if (TR && h == 1) ts[3] = __builtin_amdgcn_s_memtime();    // head 1 is stamped phase by phase (head 0 carries the cold start)
+        const int sg = sub * XNG + h * XGPH;                // first group of this head in the stream
+        if (TR && sub == 0 && h == 1) ts[3] = __builtin_amdgcn_s_memtime();    // head 1 is stamped phase by phase (head 0 carries the cold start)
         // Q_h^T [64 ch][32 tokens] = Wq_h . Xn^T
         float16_t q0, q1;
         {
-            const unsigned st = group_sync(h, 0);
+            const unsigned st = group_sync(sg);
             const int j = 0;
             asm volatile(XG_WQ_FIRST : [q0] "=&v"(q0), [q1] "=&v"(q1), XTMP_OUT
                          : [st] "v"(st), [b0] "v"(xn[16 * j + 0]), [b1] "v"(xn[16 * j + 1]), [b2] "v"(xn[16 * j + 2]), [b3] "v"(xn[16 * j + 3]),
@@ -259,7 +345,7 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
         }
         {
             const int j = 1;
-            const unsigned st = group_sync(h, j);
+            const unsigned st = group_sync(sg + j);
             asm volatile(XG_WQ : [q0] "+v"(q0), [q1] "+v"(q1), XTMP_OUT
                          : [st] "v"(st), [b0] "v"(xn[16 * j + 0]), [b1] "v"(xn[16 * j + 1]), [b2] "v"(xn[16 * j + 2]), [b3] "v"(xn[16 * j + 3]),
                            [b4] "v"(xn[16 * j + 4]), [b5] "v"(xn[16 * j + 5]), [b6] "v"(xn[16 * j + 6]), [b7] "v"(xn[16 * j + 7]),
@@ -267,27 +353,36 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
                            [b12] "v"(xn[16 * j + 12]), [b13] "v"(xn[16 * j + 13]), [b14] "v"(xn[16 * j + 14]), [b15] "v"(xn[16 * j + 15]), XDMA_IN
                          : "memory", "scc");
         }
-        if (TR && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[4] = __builtin_amdgcn_s_memtime(); }     // Q GEMM (64 MFMA)
+        if (TR && sub == 0 && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[4] = __builtin_amdgcn_s_memtime(); }     // Q GEMM (64 MFMA)
         half8_t qf[4];                                      // Q rounded to fp16 like the stored q of the unfused chain
 #pragma unroll
         for (int e = 0; e < 8; ++e) { qf[0][e] = (half_t)q0[e]; qf[1][e] = (half_t)q0[8 + e]; qf[2][e] = (half_t)q1[e]; qf[3][e] = (half_t)q1[8 + e]; }
         // S^T [96 keys][32 tokens] = K_h . Q^T
         float16_t sacc[3];
-        const unsigned stkv = group_sync(h, 2);
+        const unsigned stkv = group_sync(sg + 2);
         asm volatile(XG_K : [c0] "=&v"(sacc[0]), [c1] "=&v"(sacc[1]), [c2] "=&v"(sacc[2]), XTMP_OUT
                      : [st] "v"(stkv), [b0] "v"(qf[0]), [b1] "v"(qf[1]), [b2] "v"(qf[2]), [b3] "v"(qf[3]), XDMA_IN : "memory", "scc");
-        if (TR && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[5] = __builtin_amdgcn_s_memtime(); }     // S = K Q (12 MFMA)
+        if (TR && sub == 0 && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[5] = __builtin_amdgcn_s_memtime(); }     // S = K Q (12 MFMA)
         // softmax over the keys: this lane holds keys 32 t + (r & 3) + 8 (r >> 2) + 4 hi, lane ^ 32 the others
         float mx = -INFINITY;
+        int lk_ = p.lk;
+        asm volatile("" : "+s"(lk_));                        // (re-read per head: hipcc otherwise hoists 48 key compares out of both head loops and
+                                                            //  pays for their 96 mask registers with spills)
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int t = 0; t < 3; ++t) {
+            if (32 * (t + 1) <= lk_) {                      // wave-uniform: a key tile without padding needs no mask
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                float s = sacc[t][r] * p.scale_log2;
-                s = key < p.lk ? s : -INFINITY;
-                sacc[t][r] = s; mx = fmaxf(mx, s);
+                for (int r = 0; r < 16; ++r) { const float s = sacc[t][r] * p.scale_log2; sacc[t][r] = s; mx = fmaxf(mx, s); }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    float s = sacc[t][r] * p.scale_log2;
+                    s = key < lk_ ? s : -INFINITY;
+                    sacc[t][r] = s; mx = fmaxf(mx, s);
+                }
             }
+        }
         mx = fmaxf(mx, swap32(mx));
         float ps = 0.f;
         half8_t pf[6];                                      // P^T B fragments: k-step 2 t + (r >> 3)
@@ -303,30 +398,42 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
         }
         ps += swap32(ps);
         const float inv = 1.0f / ps;
-        if (TR && h == 1) ts[6] = __builtin_amdgcn_s_memtime();                                                          // softmax
+        if (TR && sub == 0 && h == 1) ts[6] = __builtin_amdgcn_s_memtime();                                                          // softmax
         // O^T [64 ch][32 tokens] = V_h^T . P^T (same LDS slot, fragments 12 .. 23)
         float16_t o0, o1;
         asm volatile(XG_V : [c0] "=&v"(o0), [c1] "=&v"(o1), XTMP_OUT
                      : [st] "v"(stkv), [b0] "v"(pf[0]), [b1] "v"(pf[1]), [b2] "v"(pf[2]), [b3] "v"(pf[3]), [b4] "v"(pf[4]), [b5] "v"(pf[5]), XDMA_IN
                      : "memory", "scc");
-        if (TR && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[7] = __builtin_amdgcn_s_memtime(); }     // O = V P (12 MFMA)
+        if (TR && sub == 0 && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[7] = __builtin_amdgcn_s_memtime(); }     // O = V P (12 MFMA)
         half8_t of[4];                                      // O / l rounded to fp16 like the stored attention output
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             of[0][e] = (half_t)(o0[e] * inv); of[1][e] = (half_t)(o0[8 + e] * inv);
             of[2][e] = (half_t)(o1[e] * inv); of[3][e] = (half_t)(o1[8 + e] * inv);
         }
-        // acc [512 ch][32 tokens] += Wout[:, head h] . O^T
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const unsigned st = group_sync(h, 3 + j);
-            asm volatile(XG_WO : [c0] "+a"(acc[8 * j + 0]), [c1] "+a"(acc[8 * j + 1]), [c2] "+a"(acc[8 * j + 2]), [c3] "+a"(acc[8 * j + 3]),
-                           [c4] "+a"(acc[8 * j + 4]), [c5] "+a"(acc[8 * j + 5]), [c6] "+a"(acc[8 * j + 6]), [c7] "+a"(acc[8 * j + 7]), XTMP_OUT
-                         : [st] "v"(st), [b0] "v"(of[0]), [b1] "v"(of[1]), [b2] "v"(of[2]), [b3] "v"(of[3]), XDMA_IN : "memory", "scc");
+        // acc [512 ch][32 tokens] += Wout[:, head h] . O^T (named accumulators: tiles 0 .. 7, then 8 .. 15)
+        {
+            const unsigned st = group_sync(sg + 3);
+            asm volatile(XG_WO0 : XTMP_OUT : [st] "v"(st), [b0] "v"(of[0]), [b1] "v"(of[1]), [b2] "v"(of[2]), [b3] "v"(of[3]), XDMA_IN
+                         : "memory", "scc", XACC_CLOBBERS);
         }
-        if (TR && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[8] = __builtin_amdgcn_s_memtime(); }     // acc += Wout O (64 MFMA)
+        {
+            const unsigned st = group_sync(sg + 4);
+            asm volatile(XG_WO1 : XTMP_OUT : [st] "v"(st), [b0] "v"(of[0]), [b1] "v"(of[1]), [b2] "v"(of[2]), [b3] "v"(of[3]), XDMA_IN
+                         : "memory", "scc", XACC_CLOBBERS);
+        }
+        if (TR && sub == 0 && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[8] = __builtin_amdgcn_s_memtime(); }     // acc += Wout O (64 MFMA)
+    }
+    };
+    // straight-line over the (at most two) sub-layers: a rolled loop carries the accumulators through a phi between the asm walks
+    // (accumulator file) and the LayerNorm in between (VALU), which hipcc resolves by spilling 1 679 registers per lane
+    run_heads(0);
+    if (p.nsub > 1) {
+        mid_layernorm();
+        run_heads(1);
     }
     if (TR) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[9] = __builtin_amdgcn_s_memtime(); }                         // all heads
+    asm volatile("s_nop 15\ns_nop 15" ::: "memory");        // the last MFMAs may still be in flight and the compiler cannot see them
     wait_vmcnt<0>();                                       // the zero-fill pieces behind the last group (LDS-DMA must not outlive the workgroup)
     // ---- store: row-coalesced through the idle ring ---------------------------------------------------------------------------------
     // A lane owns a token: stored from the accumulators' layout a wave-wide 16-B store touches 32 rows x 32 B — quarter cache lines, the
@@ -344,14 +451,14 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
         float* const obase = p.out + (tile0 + wave * 32) * XC + lane * 4;
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float4_t v = {acc[8 * hh + j][4 * q], acc[8 * hh + j][4 * q + 1], acc[8 * hh + j][4 * q + 2], acc[8 * hh + j][4 * q + 3]};
-                    const int pc = 8 * j + 2 * q + hi;
-                    *(lds_f4wptr_t)(size_t)(wbuf + l32 * 1024 + ((pc ^ (l32 & 7)) << 4)) = v;
-                }
+            static_for<32>([&](auto JQ) {
+                constexpr int j = JQ / 4, q = JQ % 4;
+                float4_t v;
+                if (hh == 0) v = float4_t{acc_get<16 * j + 4 * q>(), acc_get<16 * j + 4 * q + 1>(), acc_get<16 * j + 4 * q + 2>(), acc_get<16 * j + 4 * q + 3>()};
+                else v = float4_t{acc_get<128 + 16 * j + 4 * q>(), acc_get<128 + 16 * j + 4 * q + 1>(), acc_get<128 + 16 * j + 4 * q + 2>(), acc_get<128 + 16 * j + 4 * q + 3>()};
+                const int pc = 8 * j + 2 * q + hi;
+                *(lds_f4wptr_t)(size_t)(wbuf + l32 * 1024 + ((pc ^ (l32 & 7)) << 4)) = v;
+            });
             asm volatile("" ::: "memory");                  // (LDS operations of one wave execute in order; the buffer is the wave's own)
 #pragma unroll
             for (int kb = 0; kb < 32; kb += 8) {
@@ -416,31 +523,43 @@ extern "C" int uav_xattn_pack_kv(const void* k, int64_t k_stride, const void* v,
     return uav_launch_status();
 }
 
-extern "C" int uav_xattn_sublayer_f32(const float* x, float* out, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                                      const void* wq_packed, const void* kv_packed, const void* wo_packed, const float* out_bias,
-                                      int64_t rows, int32_t rows_per_kv, int32_t lk, int32_t channels, int32_t heads, float scale,
-                                      void* stream) {
-    if (!x || !out || !ln_gamma || !ln_beta || !wq_packed || !kv_packed || !wo_packed || !out_bias) return UAV_EINVAL;
-    if (channels != XC || heads != XHEADS || lk <= 0 || lk > 96) return UAV_ESHAPE;
+namespace {
+int xattn_fill(XattnArgs& a, const float* x, float* out, const uav_xattn_params* subs, int32_t n_subs, int64_t rows, int32_t rows_per_kv,
+               int32_t lk, int32_t channels, int32_t heads, float scale) {
+    if (!x || !out || !subs) return UAV_EINVAL;
+    if (n_subs < 1 || n_subs > 2 || channels != XC || heads != XHEADS || lk <= 0 || lk > 96) return UAV_ESHAPE;
     if (rows <= 0 || rows_per_kv <= 0 || (rows_per_kv % 128) || (rows % rows_per_kv) || rows / 128 >= (1ll << 31)) return UAV_ESHAPE;
     if (((size_t)x | (size_t)out) & 15) return UAV_EALIGN;
+    a.x = x; a.out = out; a.nsub = n_subs; a.rows = rows; a.rows_per_kv = rows_per_kv; a.lk = lk;
+    a.scale_log2 = scale * 1.44269504088896341f; a.trace = nullptr;
+    for (int i = 0; i < 2; ++i) {
+        const uav_xattn_params& q = subs[i < n_subs ? i : 0];
+        if (!q.ln_gamma || !q.ln_beta || !q.wq_packed || !q.kv_packed || !q.wo_packed || !q.out_bias) return UAV_EINVAL;
+        a.sub[i] = XattnSub{q.ln_gamma, q.ln_beta, q.out_bias, (const char*)q.wq_packed, (const char*)q.kv_packed, (const char*)q.wo_packed, q.ln_eps};
+    }
+    return 0;
+}
+}  // namespace
+
+extern "C" int uav_xattn_sublayers_f32(const float* x, float* out, const uav_xattn_params* subs, int32_t n_subs, int64_t rows,
+                                       int32_t rows_per_kv, int32_t lk, int32_t channels, int32_t heads, float scale, void* stream) {
+    XattnArgs a;
+    if (int rc = xattn_fill(a, x, out, subs, n_subs, rows, rows_per_kv, lk, channels, heads, scale)) return rc;
     static UavDynLds lds;
     if (int rc = uav_set_dyn_lds(lds, (const void*)xattn_sublayer_kernel<0>, XSMEM)) return rc;
-    XattnArgs a{x, out, ln_gamma, ln_beta, out_bias, (const char*)wq_packed, (const char*)kv_packed, (const char*)wo_packed,
-                (long long)rows, rows_per_kv, lk, ln_eps, scale * 1.44269504088896341f, nullptr};
     hipLaunchKernelGGL(xattn_sublayer_kernel<0>, dim3((unsigned)(rows / 128)), dim3(256), XSMEM, (hipStream_t)stream, a);
     return uav_launch_status();
 }
 
 #ifdef UAV_DEV_KERNELS
 // Development build only (tools/ab/build_dev.sh): the stamped instance; trace = 16 x uint64 per workgroup (rows / 128 of them).
-extern "C" int uav_dev_xattn_sublayer_trace(const float* x, float* out, const float* ln_gamma, const float* ln_beta, float ln_eps,
-                                            const void* wq_packed, const void* kv_packed, const void* wo_packed, const float* out_bias,
-                                            int64_t rows, int32_t rows_per_kv, int32_t lk, float scale, void* trace, void* stream) {
+extern "C" int uav_dev_xattn_sublayers_trace(const float* x, float* out, const uav_xattn_params* subs, int32_t n_subs, int64_t rows,
+                                             int32_t rows_per_kv, int32_t lk, float scale, void* trace, void* stream) {
+    XattnArgs a;
+    if (int rc = xattn_fill(a, x, out, subs, n_subs, rows, rows_per_kv, lk, XC, XHEADS, scale)) return rc;
+    a.trace = (unsigned long long*)trace;
     static UavDynLds lds;
     if (int rc = uav_set_dyn_lds(lds, (const void*)xattn_sublayer_kernel<1>, XSMEM)) return rc;
-    XattnArgs a{x, out, ln_gamma, ln_beta, out_bias, (const char*)wq_packed, (const char*)kv_packed, (const char*)wo_packed,
-                (long long)rows, rows_per_kv, lk, ln_eps, scale * 1.44269504088896341f, (unsigned long long*)trace};
     hipLaunchKernelGGL(xattn_sublayer_kernel<1>, dim3((unsigned)(rows / 128)), dim3(256), XSMEM, (hipStream_t)stream, a);
     return uav_launch_status();
 }

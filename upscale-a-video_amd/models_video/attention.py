@@ -99,14 +99,10 @@ class CrossAttention(E.EngineModule):
         if self.is_cross:
             k, v, lk = text[:3]
             kvp = text[3] if len(text) > 3 else None
-            if (kvp is not None and ln is not None and residual is x and E.XATTN_FUSED and not E.LN_FOLD and self.to_q.bias is None
-                    and self.to_out[0].bias is not None and ops.xattn_ok(x, heads=self.heads, head_dim=self.dim_head, lk=lk, rows_per_kv=q_per_kv * lq)):
+            sub = self.fused_params(x, ln, text, rows_per_kv=q_per_kv * lq) if residual is x else None
+            if sub is not None:
                 # the whole sub-layer in one launch (csrc/xattn_fused.hip): the fp32 stream is read once and written once
-                wq = self._cache().get(("xattn", "q"), lambda: ops.pack_xattn_weight(self.to_q.weight, "q", E._dev(self.to_q.weight)), (self.to_q.weight,))
-                wo = self._cache().get(("xattn", "out"), lambda: ops.pack_xattn_weight(self.to_out[0].weight, "out", E._dev(self.to_q.weight)),
-                                       (self.to_out[0].weight,))
-                return ops.xattn_sublayer(x, E.f32_param(self, "xattn.g", ln.weight), E.f32_param(self, "xattn.b", ln.bias), ln.eps, wq, kvp, wo,
-                                          E.f32_param(self, "xattn.ob", self.to_out[0].bias), rows_per_kv=q_per_kv * lq, lk=lk, scale=self.scale)
+                return ops.xattn_sublayers(x, [sub], rows_per_kv=q_per_kv * lq, lk=lk, scale=self.scale)
             q = ops.linear(x, E.packed_conv(self, "q", self.to_q)) if ln is None else E.ln_linear(self, "q", ln, x, [self.to_q])
             o = ops.attention(q, k, v, bq=bq, lq=lq, lk=lk, heads=self.heads, head_dim=self.dim_head, q_per_kv=q_per_kv,
                               scale=self.scale, q_stride=c, k_stride=2 * c, v_stride=2 * c)
@@ -117,6 +113,21 @@ class CrossAttention(E.EngineModule):
                               head_dim=self.dim_head, scale=self.scale, q_stride=3 * c, k_stride=3 * c, v_stride=3 * c)
         s32 = residual.dtype == torch.float32
         return ops.linear(o, E.packed_conv(self, "out", self.to_out[0]), residual=residual, out_f32=s32, ln_produce=s32 and E.LN_FOLD)
+
+    def fused_params(self, x, ln, text, *, rows_per_kv):
+        """(gamma, beta, eps, W_q, K | V, W_out, bias) of this sub-layer for the fused kernel (ops.xattn_sublayers), or None where it does
+        not apply: text cross-attention on an fp32 stream of 512 channels / 8 heads, <= 96 keys, whole 128-row tiles per kv batch."""
+        if not self.is_cross or ln is None or len(text) < 4 or text[3] is None or not E.XATTN_FUSED or E.LN_FOLD:
+            return None
+        if self.to_q.bias is not None or self.to_out[0].bias is None:
+            return None
+        if not ops.xattn_ok(x, heads=self.heads, head_dim=self.dim_head, lk=text[2], rows_per_kv=rows_per_kv):
+            return None
+        wq = self._cache().get(("xattn", "q"), lambda: ops.pack_xattn_weight(self.to_q.weight, "q", E._dev(self.to_q.weight)), (self.to_q.weight,))
+        wo = self._cache().get(("xattn", "out"), lambda: ops.pack_xattn_weight(self.to_out[0].weight, "out", E._dev(self.to_q.weight)),
+                               (self.to_out[0].weight,))
+        return (E.f32_param(self, "xattn.g", ln.weight), E.f32_param(self, "xattn.b", ln.bias), ln.eps, wq, text[3], wo,
+                E.f32_param(self, "xattn.ob", self.to_out[0].bias))
 
     def project_text(self, ehs_rows, n_text=None):
         """K|V of the text tokens: [B*77][2C] (fused GEMM), computed once per prompt tensor — and, where the fused sub-layer kernel
@@ -240,14 +251,30 @@ class BasicTransformerBlock(E.EngineModule):
         bq, lq = g.n_img, g.hw
         # every LayerNorm is handed to its consumer together with the un-normalised stream: engine.ln_linear folds it into
         # the projection when the stream is fp32 and its producer wrote the operand copy, else runs the LayerNorm pass
+        t1 = t2 = None
         if self.only_cross_attention:
             k, v, kvp = self._text_kv(self.attn1, ehs_rows, "a1", n_text)
-            x = self.attn1.run(x, x, bq=bq, lq=lq, text=(k, v, n_text, kvp), q_per_kv=g.t, ln=self.norm1)
-        else:
-            x = self.attn1.run(x, x, bq=bq, lq=lq, ln=self.norm1)
+            t1 = (k, v, n_text, kvp)
         if self.attn2 is not None:
             k, v, kvp = self._text_kv(self.attn2, ehs_rows, "a2", n_text)
-            x = self.attn2.run(x, x, bq=bq, lq=lq, text=(k, v, n_text, kvp), q_per_kv=g.t, ln=self.norm2)
+            t2 = (k, v, n_text, kvp)
+        pair = None
+        if t1 is not None and t2 is not None and E.XATTN_PAIR:
+            # attn1 (only_cross_attention) and attn2 are both text cross-attention: ONE launch for the two sub-layers, the rows between
+            # them never leave the accumulators (csrc/xattn_fused.hip, n_subs = 2)
+            s1 = self.attn1.fused_params(x, self.norm1, t1, rows_per_kv=g.t * lq)
+            s2 = self.attn2.fused_params(x, self.norm2, t2, rows_per_kv=g.t * lq) if s1 is not None else None
+            if s2 is not None and self.attn1.scale == self.attn2.scale:
+                pair = (s1, s2)
+        if pair is not None:
+            x = ops.xattn_sublayers(x, list(pair), rows_per_kv=g.t * lq, lk=n_text, scale=self.attn1.scale)
+        else:
+            if t1 is not None:
+                x = self.attn1.run(x, x, bq=bq, lq=lq, text=t1, q_per_kv=g.t, ln=self.norm1)
+            else:
+                x = self.attn1.run(x, x, bq=bq, lq=lq, ln=self.norm1)
+            if t2 is not None:
+                x = self.attn2.run(x, x, bq=bq, lq=lq, text=t2, q_per_kv=g.t, ln=self.norm2)
         x = self.attn_temporal.run_temporal(x, x, g, ln=self.norm_temporal)
         return self.ff.run(x, x, out_f32, ln=self.norm3, out_hilo=out_hilo)
 

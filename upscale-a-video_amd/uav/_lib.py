@@ -39,6 +39,11 @@ class ConvParams(C.Structure):
     ]
 
 
+class XattnParams(C.Structure):
+    """Mirror of `uav_xattn_params` (include/uav_hip.h): one fused cross-attention sub-layer."""
+    _fields_ = [("ln_gamma", c_p), ("ln_beta", c_p), ("ln_eps", f32), ("wq_packed", c_p), ("kv_packed", c_p), ("wo_packed", c_p), ("out_bias", c_p)]
+
+
 CONV_GEGLU = 1
 CONV_OUT_F32 = 2
 CONV_PERSISTENT = 64
@@ -68,7 +73,7 @@ SIGNATURES = {
     "uav_layernorm_f16": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, f32, c_p]),
     "uav_layernorm_f32in": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, f32, c_p]),
     "uav_attention_f16": (C.c_int, [c_p, i64, c_p, i64, c_p, i64, c_p, i64, i32, i32, i32, i32, i32, i32, f32, i32, c_p, c_p]),
-    "uav_xattn_sublayer_f32": (C.c_int, [c_p, c_p, c_p, c_p, f32, c_p, c_p, c_p, c_p, i64, i32, i32, i32, i32, f32, c_p]),
+    "uav_xattn_sublayers_f32": (C.c_int, [c_p, c_p, c_p, i32, i64, i32, i32, i32, i32, f32, c_p]),
     "uav_xattn_pack_kv": (C.c_int, [c_p, i64, c_p, i64, i32, i32, i32, i32, c_p, c_p]),
     "uav_temporal_attention_f16": (C.c_int, [c_p, c_p, i32, i32, i64, i32, i32, f32, c_p, c_p, i32, c_p, c_p]),
     "uav_linear_small": (C.c_int, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, c_p]),

@@ -99,11 +99,16 @@ def _build_locked(objdir, verbose):
 
 
 def audit_accumulator_file():
-    """attn512w_kernel keeps its 256 O^T accumulators in a[0:255] BY NAME from inline asm (csrc/attention.hip).  That is
-    only sound while hipcc itself never touches the accumulator file in that kernel (it would treat the registers as free
-    between our statements): compile the file to assembly and fail the build if any compiler-generated instruction of the
-    kernel names an AGPR."""
-    src = os.path.join(CSRC, "attention.hip")
+    """attn512w_kernel (csrc/attention.hip) and xattn_sublayer_kernel (csrc/xattn_fused.hip) keep their 256 fp32 accumulators in
+    a[0:255] BY NAME from inline asm.  That is only sound while hipcc itself never touches the accumulator file in those kernels
+    (it would treat the registers as free between our statements): compile the file to assembly and fail the build if any
+    compiler-generated instruction of the kernel names an AGPR."""
+    _audit_named_accumulators("attention.hip", "attn512w_kernel")
+    _audit_named_accumulators("xattn_fused.hip", "xattn_sublayer_kernelILi0E")
+
+
+def _audit_named_accumulators(fname, kernel):
+    src = os.path.join(CSRC, fname)
     r = subprocess.run([HIPCC] + FLAGS + ["-S", "--cuda-device-only", "-o", "-", src], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc -S failed on {src}:\n{r.stderr}")
@@ -112,14 +117,14 @@ def audit_accumulator_file():
     bad = []
     asm_blocks = 0
     for ln in lines:
-        if "attn512w_kernel" in ln and not ln[:1].isspace() and ln.split(";")[0].rstrip().endswith(":"):
+        if kernel in ln and not ln[:1].isspace() and ln.split(";")[0].rstrip().endswith(":"):
             inside = True
             continue
         if not inside:
             continue
         # the function ends at its .Lfunc_end label / .size directive, not at the first s_endpgm (early-exit branches
         # emit several)
-        if ln.startswith(".Lfunc_end") or (ln.lstrip().startswith(".size") and "attn512w_kernel" in ln):
+        if ln.startswith(".Lfunc_end") or (ln.lstrip().startswith(".size") and kernel in ln):
             break
         if "#ASMSTART" in ln:
             in_asm = True
@@ -129,11 +134,11 @@ def audit_accumulator_file():
         elif not in_asm and not ln.lstrip().startswith(";") and ("v_accvgpr" in ln or " a[" in ln or ",a[" in ln):
             bad.append(ln.strip())
     if not inside:
-        raise RuntimeError("audit: attn512w_kernel not found in the assembly of attention.hip")
+        raise RuntimeError(f"audit: {kernel} not found in the assembly of {fname}")
     if asm_blocks == 0:
-        raise RuntimeError("audit: no inline-asm block seen inside attn512w_kernel — the scan did not cover the kernel body")
+        raise RuntimeError(f"audit: no inline-asm block seen inside {kernel} — the scan did not cover the kernel body")
     if bad:
-        raise RuntimeError("audit: hipcc uses the accumulator file inside attn512w_kernel, which names a[0:255] from inline asm:\n  "
+        raise RuntimeError(f"audit: hipcc uses the accumulator file inside {kernel}, which names a[0:255] from inline asm:\n  "
                            + "\n  ".join(bad[:8]))
 
 

@@ -363,6 +363,9 @@ LN_FOLD = _os.environ.get("UAV_LN_FOLD", "0") != "0"
 # launch (csrc/xattn_fused.hip, round 6): the fp32 token stream is read once and written once instead of 24 B per element over four
 # launches.  UAV_XATTN_FUSED=0 keeps the four-launch chain (A/B and the equivalence test).
 XATTN_FUSED = _os.environ.get("UAV_XATTN_FUSED", "1") != "0"
+# ... and attn1 + attn2 of a block with only_cross_attention (both text cross-attention) as ONE launch of that kernel: the second LayerNorm
+# runs on the accumulators.  UAV_XATTN_PAIR=0 keeps one launch per sub-layer.
+XATTN_PAIR = _os.environ.get("UAV_XATTN_PAIR", "1") != "0"
 
 
 def packed_ln_linear(mod: EngineModule, name, ln: nn.LayerNorm, linears, geglu=False):

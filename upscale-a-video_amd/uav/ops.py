@@ -689,18 +689,33 @@ def xattn_ok(x, *, heads, head_dim, lk, rows_per_kv):
             and 0 < lk <= XATTN_MAX_KEYS and rows_per_kv % XATTN_TILE == 0 and x.shape[0] % rows_per_kv == 0)
 
 
-def xattn_sublayer(x, gamma, beta, eps, wq_packed, kv_packed, wo_packed, out_bias, *, rows_per_kv, lk, scale, out=None):
-    """x + to_out(attention(to_q(LayerNorm(x)), K, V)) + bias on fp32 stream rows [M][512] in one launch."""
+def xattn_sublayers(x, subs, *, rows_per_kv, lk, scale, out=None):
+    """One or two consecutive fused cross-attention sub-layers on fp32 stream rows x [M][512] in ONE launch:
+    x <- x + to_out(attention(to_q(LayerNorm(x)), K, V)) + bias, for each entry of `subs` = (gamma, beta, eps, wq_packed, kv_packed,
+    wo_packed, out_bias) in order (two entries: attn1 with only_cross_attention and attn2 of one BasicTransformerBlock — the rows
+    between the two stay in the accumulators)."""
     lib = _lib.load()
     _req(x, torch.float32, "x")
+    if not 1 <= len(subs) <= 2:
+        raise _lib.UavError("xattn_sublayers takes one or two sub-layers")
     m = x.shape[0]
     y = torch.empty_like(x) if out is None else out
+    arr = (_lib.XattnParams * len(subs))()
+    for i, (gamma, beta, eps, wq_packed, kv_packed, wo_packed, out_bias) in enumerate(subs):
+        arr[i].ln_gamma, arr[i].ln_beta, arr[i].ln_eps = _p(gamma), _p(beta), float(eps)
+        arr[i].wq_packed, arr[i].kv_packed, arr[i].wo_packed, arr[i].out_bias = _p(wq_packed), _p(kv_packed), _p(wo_packed), _p(out_bias)
     ev = PROFILER.begin("xattn_sublayer")
-    rc = lib.uav_xattn_sublayer_f32(_p(x), _p(y), _p(gamma), _p(beta), eps, _p(wq_packed), _p(kv_packed), _p(wo_packed), _p(out_bias),
-                                    m, rows_per_kv, lk, XATTN_C, XATTN_HEADS, scale, _stream())
-    _lib.check(rc, "uav_xattn_sublayer_f32")
-    PROFILER.end(ev, "xattn_sublayer", 2.0 * m * (2 * XATTN_C * XATTN_C) + 4.0 * m * lk * XATTN_C, 8.0 * m * XATTN_C)
+    rc = lib.uav_xattn_sublayers_f32(_p(x), _p(y), C.cast(arr, C.c_void_p), len(subs), m, rows_per_kv, lk, XATTN_C, XATTN_HEADS, scale, _stream())
+    _lib.check(rc, "uav_xattn_sublayers_f32")
+    n = len(subs)
+    PROFILER.end(ev, "xattn_sublayer" if not PROFILER.detail else f"xattn_sublayer x{n} M={m}", n * (2.0 * m * (2 * XATTN_C * XATTN_C) + 4.0 * m * lk * XATTN_C),
+                 8.0 * m * XATTN_C)
     return y
+
+
+def xattn_sublayer(x, gamma, beta, eps, wq_packed, kv_packed, wo_packed, out_bias, *, rows_per_kv, lk, scale, out=None):
+    """A single fused sub-layer (see xattn_sublayers)."""
+    return xattn_sublayers(x, [(gamma, beta, eps, wq_packed, kv_packed, wo_packed, out_bias)], rows_per_kv=rows_per_kv, lk=lk, scale=scale, out=out)
 
 
 def temporal_attention(qkv, *, n_batch, t_len, hw, c, heads, scale, rope_cos, rope_sin, rot_dim, bias):
