@@ -253,6 +253,26 @@ typedef struct {
  * for both). */
 int uav_xattn_sublayers_f32(const float* x, float* out, const uav_xattn_params* subs, int32_t n_subs, int64_t rows,
                             int32_t rows_per_kv, int32_t lk, int32_t channels, int32_t heads, float scale, void* stream);
+/* ---- K7b (round 6): fused TEMPORAL attention SUB-LAYER of BasicTransformerBlock ------------------------------------------------
+ * Replaces the four launches of `hidden = attn_temporal(norm_temporal(hidden)) + hidden` (attention.py:555-560; TemporalAttention
+ * :626-733 = to_q | to_k | to_v, RoPE + RelativePositionBias + per-pixel softmax over the T frames, to_out) on fp32 stream rows
+ * [n_batch * t_len * hw][channels] (row (b T + t) hw + pixel): out = x + b_out + W_out . attention, the stream read and written once.
+ * channels == 512, heads == 8, t_len == 8, rot_dim == 32, hw % 16 == 0; else UAV_ESHAPE (the caller keeps the chain).  out may alias x
+ * (a workgroup's 16 pixels x 8 frames are disjoint from every other workgroup's rows and are read before they are written). */
+typedef struct {
+    const float* ln_gamma; const float* ln_beta; float ln_eps;
+    const void*  wq_packed;     /* to_q / to_k / to_v weights, each in the 'q' fragment order of uav.ops.pack_xattn_weight */
+    const void*  wk_packed;
+    const void*  wv_packed;
+    const void*  wo_packed;     /* to_out weights ('out' order) */
+    const float* out_bias;
+    const float* rel_bias;      /* fp32 [heads][t_len][t_len] */
+    const float* rope_cos;      /* fp32 [t_len][rot_dim / 2] */
+    const float* rope_sin;
+    int32_t      rot_dim;
+} uav_tattn_params;
+int uav_tattn_sublayer_f32(const float* x, float* out, const uav_tattn_params* p, int32_t n_batch, int32_t t_len, int64_t hw,
+                           int32_t channels, int32_t heads, float scale, void* stream);
 /* k, v: fp16 rows [n_batch * lk][stride] (head h in columns h*head_dim ..) -> out: n_batch * heads * 32 KiB */
 int uav_xattn_pack_kv(const void* k, int64_t k_stride, const void* v, int64_t v_stride, int32_t n_batch, int32_t lk,
                       int32_t heads, int32_t head_dim, void* out, void* stream);

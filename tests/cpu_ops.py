@@ -251,6 +251,23 @@ def temporal_attention(qkv, *, n_batch, t_len, hw, c, heads, scale, rope_cos, ro
     return _h(o)
 
 
+def tattn_sublayer(x, gamma, beta, eps, wq_packed, wk_packed, wv_packed, wo_packed, out_bias, rel_bias, rope_cos, rope_sin, *,
+                   n_batch, t_len, hw, rot_dim, scale, out=None):
+    """Fused temporal sub-layer (csrc/xattn_fused.hip tattn_sublayer_kernel): the chain LayerNorm -> q | k | v -> temporal attention ->
+    to_out + residual on the decoded fragment streams."""
+    wq, wk, wv = (_unpack_xattn_weight(w, "q") for w in (wq_packed, wk_packed, wv_packed))
+    wo = _unpack_xattn_weight(wo_packed, "out")
+    n = _h(F.layer_norm(x.float(), (512,), gamma.float(), beta.float(), eps)).float()
+    qkv = _h(torch.cat([n @ wq.t(), n @ wk.t(), n @ wv.t()], dim=-1))
+    o = temporal_attention(qkv, n_batch=n_batch, t_len=t_len, hw=hw, c=512, heads=8, scale=scale, rope_cos=rope_cos, rope_sin=rope_sin,
+                           rot_dim=rot_dim, bias=rel_bias)
+    y = x.float() + out_bias.float() + o.float() @ wo.t()
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def linear_small(x, w, b, *, pre_silu=False, post_silu=False):
     x = F.silu(x.float()) if pre_silu else x.float()
@@ -351,7 +368,7 @@ def sft_fuse(dec, scale, shift, w, out_f32=False):
     return y if out_f32 else _h(y)
 
 
-_OPS = ("ln_fold_ok", "resize_area_f32", "cast_f16", "cast_hilo", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "xattn_pack_kv", "xattn_sublayer", "xattn_sublayers", "temporal_attention", "linear_small",
+_OPS = ("ln_fold_ok", "resize_area_f32", "cast_f16", "cast_hilo", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "xattn_pack_kv", "xattn_sublayer", "xattn_sublayers", "tattn_sublayer", "temporal_attention", "linear_small",
         "timestep_embedding", "pack_nhwc", "unpack_ncthw", "axpby", "cfg_ddim_v0", "ddim_vt")
 
 

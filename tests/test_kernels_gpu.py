@@ -1099,3 +1099,66 @@ def test_fused_cross_attention_pair_equals_two_single_launches(ops, dev):
     assert torch.equal(ops.xattn_sublayers(x, subs, **kw), yp)
     xin = x.clone()
     assert ops.xattn_sublayers(xin, subs, out=xin, **kw) is xin and torch.equal(xin, yp)      # in place
+
+
+# ------------------------------------------------------------------------------------------------
+# Fused TEMPORAL attention sub-layer (round 6, tattn_sublayer_kernel): LayerNorm -> to_q | to_k | to_v -> RoPE + relative-position bias +
+# softmax over the 8 frames of a pixel -> to_out -> + residual in one launch — reference attention.py:555-560, TemporalAttention :626-733
+TATTN_CASES = [
+    # name, batches, h, w, row mean / spread
+    ("b2_16x16", 2, 16, 16, 0.3, 1.5),
+    ("b1_4x4_one_tile", 1, 4, 4, 0.0, 1.0),
+    ("b2_40x40", 2, 40, 40, -1.0, 0.8),
+    ("b1_160x160_level", 1, 160, 160, 2.0, 2.0),
+]
+
+
+@pytest.mark.parametrize("case", TATTN_CASES, ids=[c[0] for c in TATTN_CASES])
+def test_fused_temporal_attention_sublayer(ops, dev, case):
+    name, nb, hh, ww, mu, sd = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    C, H, D, T = 512, 8, 64, 8
+    hw = hh * ww
+    M = nb * T * hw
+    x = (torch.randn(M, C, generator=g) * sd + mu + torch.randn(M, 1, generator=g)).to(dev)
+    gamma = (torch.randn(C, generator=g) * 0.2 + 1.0).to(dev); beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+    wq, wk, wv, wo = (h16(C, C, dev=dev, scale=C ** -0.5, gen=g) for _ in range(4))
+    bo = (torch.randn(C, generator=g) * 0.1).to(dev)
+    relb = (torch.randn(H, T, T, generator=g) * 0.5).to(dev).contiguous()
+    fr = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    ang = torch.arange(T).float()[:, None] * fr[None, :]
+    cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
+    scale = D ** -0.5
+    # the four-launch chain
+    n = ops.layernorm(x, gamma, beta, 1e-5)
+    qkv = ops.linear(n, ops.pack_conv(torch.cat([wq, wk, wv], 0), None, device=dev))
+    o = ops.temporal_attention(qkv, n_batch=nb, t_len=T, hw=hw, c=C, heads=H, scale=scale, rope_cos=cos, rope_sin=sin, rot_dim=32, bias=relb)
+    y_chain = ops.linear(o, ops.pack_conv(wo, bo, device=dev), residual=x, out_f32=True)
+    # the fused launch
+    assert ops.tattn_ok(x, heads=H, head_dim=D, t_len=T, hw=hw, rot_dim=32)
+    pk = [ops.pack_xattn_weight(w_, "q", dev) for w_ in (wq, wk, wv)] + [ops.pack_xattn_weight(wo, "out", dev)]
+    kw = dict(n_batch=nb, t_len=T, hw=hw, rot_dim=32, scale=scale)
+    y = ops.tattn_sublayer(x, gamma, beta, 1e-5, *pk, bo, relb, cos, sin, **kw)
+    assert y.dtype == torch.float32 and y.shape == x.shape and bool(torch.isfinite(y).all())
+    # fp32 reference (TemporalAttention.forward on rows (b, t, p))
+    nf = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+
+    def heads_of(t):
+        return t.reshape(nb, T, hw, H, D).permute(0, 2, 3, 1, 4)              # (B, P, H, T, d)
+
+    def rope(t):
+        c_, s_ = cos.reshape(1, 1, 1, T, 16), sin.reshape(1, 1, 1, T, 16)
+        a, b = t[..., 0:32:2], t[..., 1:32:2]
+        r = torch.stack([a * c_ - b * s_, b * c_ + a * s_], dim=-1).reshape(t.shape[:-1] + (32,))
+        return torch.cat([r, t[..., 32:]], dim=-1)
+    qh, kh, vh = rope(heads_of(nf @ wq.t()) * scale), rope(heads_of(nf @ wk.t())), heads_of(nf @ wv.t())
+    att = torch.softmax(qh @ kh.transpose(-1, -2) + relb.reshape(1, 1, H, T, T), dim=-1) @ vh      # (B, P, H, T, d)
+    ref = x + att.permute(0, 3, 1, 2, 4).reshape(M, C) @ wo.t() + bo
+    e_out, e_upd = rel_l2(y, y_chain), rel_l2(y - x, y_chain - x)
+    e_ref, e_ref_chain = rel_l2(y - x, ref - x), rel_l2(y_chain - x, ref - x)
+    assert e_out < 2e-4, (name, e_out, e_upd)
+    assert e_upd < 2.5e-3, (name, e_upd)
+    assert e_ref < 2.5e-3 and e_ref < 1.3 * e_ref_chain + 1e-4, (name, e_ref, e_ref_chain)
+    x2 = x.clone()
+    assert ops.tattn_sublayer(x2, gamma, beta, 1e-5, *pk, bo, relb, cos, sin, out=x2, **kw) is x2 and torch.equal(x2, y)     # in place
+    assert torch.equal(ops.tattn_sublayer(x, gamma, beta, 1e-5, *pk, bo, relb, cos, sin, **kw), y)                             # deterministic

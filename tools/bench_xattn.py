@@ -71,6 +71,55 @@ def case(name, nb, rpk):
     print(json.dumps(d), flush=True)
 
 
+def tcase(name, nb, hh, ww):
+    """The temporal sub-layer: fused launch against LayerNorm -> q|k|v -> temporal attention -> to_out + residual."""
+    T = 8
+    hw = hh * ww
+    m = nb * T * hw
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(m, C, generator=g) * 1.3 + 0.2).to(dev)
+    gamma = (torch.randn(C, generator=g) * 0.2 + 1).to(dev); beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+    ws = [(torch.randn(C, C, generator=g) * C ** -0.5).half().float().to(dev) for _ in range(4)]
+    bo = (torch.randn(C, generator=g) * 0.1).to(dev)
+    relb = (torch.randn(H, T, T, generator=g) * 0.5).to(dev).contiguous()
+    fr = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    ang = torch.arange(T).float()[:, None] * fr[None, :]
+    cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
+    cqkv, co = ops.pack_conv(torch.cat(ws[:3], 0), None, device=dev), ops.pack_conv(ws[3], bo, device=dev)
+    pk = [ops.pack_xattn_weight(w_, "q", dev) for w_ in ws[:3]] + [ops.pack_xattn_weight(ws[3], "out", dev)]
+    scale = D ** -0.5
+    st = {}
+
+    def ln(): st["n"] = ops.layernorm(x, gamma, beta, 1e-5)
+    def qkv(): st["qkv"] = ops.linear(st["n"], cqkv)
+    def att(): st["o"] = ops.temporal_attention(st["qkv"], n_batch=nb, t_len=T, hw=hw, c=C, heads=H, scale=scale, rope_cos=cos, rope_sin=sin, rot_dim=32, bias=relb)
+    def out(): st["y"] = ops.linear(st["o"], co, residual=x, out_f32=True)
+    def chain(): ln(); qkv(); att(); out()
+    def fused(): st["f"] = ops.tattn_sublayer(x, gamma, beta, 1e-5, *pk, bo, relb, cos, sin, n_batch=nb, t_len=T, hw=hw, rot_dim=32, scale=scale)
+
+    fns = {"fused": fused, "chain": chain, "layernorm": ln, "qkv": qkv, "temporal_attention": att, "to_out": out}
+    chain(); fused(); chain(); fused()
+    torch.cuda.synchronize()
+    t = {kk: [] for kk in fns}
+    for _ in range(ROUNDS):
+        for kk, f in fns.items():
+            t[kk].append(time_once(f, PER))
+    fl = 2.0 * m * 4 * C * C + 4.0 * m * T * C
+    d = {"case": name, "rows": m, "max_abs_diff_fused_vs_chain": float((st["f"] - st["y"]).abs().max())}
+    for kk in fns:
+        d[kk + "_ms"] = {"median": round(statistics.median(t[kk]), 4), "min": round(min(t[kk]), 4)}
+    med = d["fused_ms"]["median"]
+    d["fused_tflops"] = round(fl / med / 1e9, 1)
+    d["fused_algorithmic_GBps"] = round(8.0 * m * C / med / 1e6, 0)
+    d["speedup_vs_chain"] = round(d["chain_ms"]["median"] / med, 3)
+    print(json.dumps(d), flush=True)
+
+
 if __name__ == "__main__":
+    if "temporal" in sys.argv[1:] or not sys.argv[1:]:
+        tcase("temporal sub-layer, 160x160 level: 2 x 8 frames x 160 x 160 tokens", 2, 160, 160)
+        tcase("temporal sub-layer, 80x80 level", 2, 80, 80)
+    if sys.argv[1:] == ["temporal"]:
+        sys.exit(0)
     case("160x160 level: 2 x 8 frames x 160 x 160 tokens", 2, 8 * 160 * 160)
     case("80x80 level: 2 x 8 frames x 80 x 80 tokens", 2, 8 * 80 * 80)

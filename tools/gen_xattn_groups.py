@@ -15,7 +15,7 @@ def fmt(name, seq):
     return f"#define {name} \\\n" + " \\\n".join(lines) + "\n"
 
 
-def group(n, base, cb, dma, first=False):
+def group(n, base, cb, dma, first=False, unswapped=False, tail_nop=False):
     """n fragments at slot offsets (base + f) KiB; cb(f) -> (accumulator, B operand); dma: {step: piece} issued behind that step's MFMA;
     first: the group opens its accumulators — the first MFMA on each takes the inline constant 0 as C (no zeroing, no live zero tuple)."""
     out = [f"XRD(t{f}, {(base + f) * 1024})" for f in range(D)]
@@ -32,14 +32,16 @@ def group(n, base, cb, dma, first=False):
             else:
                 out.append(f"XTA({t}, {lo}, {lo + 15}, {b}, {min(D - 1, n - 1 - f)})")
         elif f + D < n:
-            out.append(f"XS{z}({t}, {c}, {b}, {D - 1}, {(base + f + D) * 1024})")
+            out.append(f"XS{'U' if unswapped else ''}{z}({t}, {c}, {b}, {D - 1}, {(base + f + D) * 1024})")
         else:
-            out.append(f"XT{z}({t}, {c}, {b}, {min(D - 1, n - 1 - f)})")
+            out.append(f"XT{'U' if unswapped else ''}{z}({t}, {c}, {b}, {min(D - 1, n - 1 - f)})")
         if f in dma:
             p = dma[f]
             out.append(f"XD({(p & ~3) * 1024}, {(p & 3) * 1024})")       # the instruction offset moves BOTH the global and the LDS address
             if p == 3:
                 out.append("XDADV")
+    if tail_nop:
+        out.append("XNOP")
     return out
 
 
@@ -48,10 +50,14 @@ if __name__ == "__main__":
     dk = {1: 0, 4: 1, 7: 2, 10: 3}                              # K part: pieces 0..3
     dv = {1: 4, 4: 5, 7: 6, 10: 7}                              # V part: pieces 4..7
     txt = fmt("XG_WQ_FIRST", group(32, 0, lambda f: (f"q{f & 1}", f"b{f >> 1}"), d32, first=True)) + "\n"
-    txt += fmt("XG_WQ", group(32, 0, lambda f: (f"q{f & 1}", f"b{f >> 1}"), d32)) + "\n"
+    txt += fmt("XG_WQ", group(32, 0, lambda f: (f"q{f & 1}", f"b{f >> 1}"), d32, tail_nop=True)) + "\n"
+    # temporal sub-layer: V = Xn . Wv^T with the operands the other way round (A = the token fragments in registers, B = the weight fragment):
+    # D[token][channel], lane = channel — the A-operand layout of V^T in O^T = V^T P^T, no transpose
+    txt += fmt("XG_WV_FIRST", group(32, 0, lambda f: (f"q{f & 1}", f"b{f >> 1}"), d32, first=True, unswapped=True)) + "\n"
+    txt += fmt("XG_WV", group(32, 0, lambda f: (f"q{f & 1}", f"b{f >> 1}"), d32, unswapped=True, tail_nop=True)) + "\n"
     # W_out: the 256 accumulators of the tile live in a[0:255] BY NAME (tile nt = a[16 nt : 16 nt + 15]); group j covers tiles 8 j .. 8 j + 7
     for j in range(2):
         txt += fmt(f"XG_WO{j}", group(32, 0, lambda f: (f"A{16 * (8 * j + 2 * (f >> 3) + (f & 1))}", f"b{(f >> 1) & 3}"), d32)) + "\n"
-    txt += fmt("XG_K", group(12, 0, lambda f: (f"c{f % 3}", f"b{f // 3}"), dk, first=True)) + "\n"
-    txt += fmt("XG_V", group(12, 12, lambda f: (f"c{f & 1}", f"b{f >> 1}"), dv, first=True))
+    txt += fmt("XG_K", group(12, 0, lambda f: (f"c{f % 3}", f"b{f // 3}"), dk, first=True, tail_nop=True)) + "\n"
+    txt += fmt("XG_V", group(12, 12, lambda f: (f"c{f & 1}", f"b{f >> 1}"), dv, first=True, tail_nop=True))
     print(txt, end="")

@@ -109,6 +109,16 @@ template <int N, class F> UAV_DEVINL void static_for(F&& f) { static_for_impl(st
 #define XMF(C, A, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #A "], %[" #B "], %[" #C "]\n"
 #define XS(T, C, B, WN, OFF) "s_waitcnt lgkmcnt(" #WN ")\n" XMF(C, T, B) XRD(T, OFF)
 #define XT(T, C, B, WN) "s_waitcnt lgkmcnt(" #WN ")\n" XMF(C, T, B)
+// the operands the other way round (A = the register fragment B, B = the LDS fragment T): D[token][channel]
+#define XMFU(C, T, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #B "], %[" #T "], %[" #C "]\n"
+#define XMFU0(C, T, B) "v_mfma_f32_32x32x16_f16 %[" #C "], %[" #B "], %[" #T "], 0\n"
+#define XSU(T, C, B, WN, OFF) "s_waitcnt lgkmcnt(" #WN ")\n" XMFU(C, T, B) XRD(T, OFF)
+#define XTU(T, C, B, WN) "s_waitcnt lgkmcnt(" #WN ")\n" XMFU(C, T, B)
+#define XSU0(T, C, B, WN, OFF) "s_waitcnt lgkmcnt(" #WN ")\n" XMFU0(C, T, B) XRD(T, OFF)
+#define XTU0(T, C, B, WN) "s_waitcnt lgkmcnt(" #WN ")\n" XMFU0(C, T, B)
+// behind the last MFMA of a group whose accumulators the VALU reads next: the compiler cannot see MFMAs inside an asm statement and
+// inserts none of the wait states their results need
+#define XNOP "s_nop 15\ns_nop 3\n"
 // MFMA on a NAMED accumulator tile a[LO:HI] (the 256 output accumulators, see XACC_CLOBBERS)
 #define XMFA(LO, HI, A, B) "v_mfma_f32_32x32x16_f16 a[" #LO ":" #HI "], %[" #A "], %[" #B "], a[" #LO ":" #HI "]\n"
 #define XSA(T, LO, HI, B, WN, OFF) "s_waitcnt lgkmcnt(" #WN ")\n" XMFA(LO, HI, T, B) XRD(T, OFF)
@@ -146,7 +156,30 @@ template <int N, class F> UAV_DEVINL void static_for(F&& f) { static_for_impl(st
     XS(t5, q1, b8, 5, 23552) XS(t0, q0, b9, 5, 24576) XD(4096, 0) XS(t1, q1, b9, 5, 25600) XS(t2, q0, b10, 5, 26624) \
     XS(t3, q1, b10, 5, 27648) XS(t4, q0, b11, 5, 28672) XD(4096, 1024) XS(t5, q1, b11, 5, 29696) \
     XS(t0, q0, b12, 5, 30720) XS(t1, q1, b12, 5, 31744) XT(t2, q0, b13, 5) XD(4096, 2048) XT(t3, q1, b13, 4) \
-    XT(t4, q0, b14, 3) XT(t5, q1, b14, 2) XT(t0, q0, b15, 1) XD(4096, 3072) XT(t1, q1, b15, 0)
+    XT(t4, q0, b14, 3) XT(t5, q1, b14, 2) XT(t0, q0, b15, 1) XD(4096, 3072) XT(t1, q1, b15, 0) XNOP
+
+#define XG_WV_FIRST \
+    XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XSU0(t0, q0, b0, 5, 6144) \
+    XSU0(t1, q1, b0, 5, 7168) XSU(t2, q0, b1, 5, 8192) XD(0, 0) XSU(t3, q1, b1, 5, 9216) XSU(t4, q0, b2, 5, 10240) \
+    XSU(t5, q1, b2, 5, 11264) XSU(t0, q0, b3, 5, 12288) XD(0, 1024) XSU(t1, q1, b3, 5, 13312) XSU(t2, q0, b4, 5, 14336) \
+    XSU(t3, q1, b4, 5, 15360) XSU(t4, q0, b5, 5, 16384) XD(0, 2048) XSU(t5, q1, b5, 5, 17408) XSU(t0, q0, b6, 5, 18432) \
+    XSU(t1, q1, b6, 5, 19456) XSU(t2, q0, b7, 5, 20480) XD(0, 3072) XDADV XSU(t3, q1, b7, 5, 21504) \
+    XSU(t4, q0, b8, 5, 22528) XSU(t5, q1, b8, 5, 23552) XSU(t0, q0, b9, 5, 24576) XD(4096, 0) XSU(t1, q1, b9, 5, 25600) \
+    XSU(t2, q0, b10, 5, 26624) XSU(t3, q1, b10, 5, 27648) XSU(t4, q0, b11, 5, 28672) XD(4096, 1024) \
+    XSU(t5, q1, b11, 5, 29696) XSU(t0, q0, b12, 5, 30720) XSU(t1, q1, b12, 5, 31744) XTU(t2, q0, b13, 5) XD(4096, 2048) \
+    XTU(t3, q1, b13, 4) XTU(t4, q0, b14, 3) XTU(t5, q1, b14, 2) XTU(t0, q0, b15, 1) XD(4096, 3072) XTU(t1, q1, b15, 0)
+
+#define XG_WV \
+    XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XSU(t0, q0, b0, 5, 6144) \
+    XSU(t1, q1, b0, 5, 7168) XSU(t2, q0, b1, 5, 8192) XD(0, 0) XSU(t3, q1, b1, 5, 9216) XSU(t4, q0, b2, 5, 10240) \
+    XSU(t5, q1, b2, 5, 11264) XSU(t0, q0, b3, 5, 12288) XD(0, 1024) XSU(t1, q1, b3, 5, 13312) XSU(t2, q0, b4, 5, 14336) \
+    XSU(t3, q1, b4, 5, 15360) XSU(t4, q0, b5, 5, 16384) XD(0, 2048) XSU(t5, q1, b5, 5, 17408) XSU(t0, q0, b6, 5, 18432) \
+    XSU(t1, q1, b6, 5, 19456) XSU(t2, q0, b7, 5, 20480) XD(0, 3072) XDADV XSU(t3, q1, b7, 5, 21504) \
+    XSU(t4, q0, b8, 5, 22528) XSU(t5, q1, b8, 5, 23552) XSU(t0, q0, b9, 5, 24576) XD(4096, 0) XSU(t1, q1, b9, 5, 25600) \
+    XSU(t2, q0, b10, 5, 26624) XSU(t3, q1, b10, 5, 27648) XSU(t4, q0, b11, 5, 28672) XD(4096, 1024) \
+    XSU(t5, q1, b11, 5, 29696) XSU(t0, q0, b12, 5, 30720) XSU(t1, q1, b12, 5, 31744) XTU(t2, q0, b13, 5) XD(4096, 2048) \
+    XTU(t3, q1, b13, 4) XTU(t4, q0, b14, 3) XTU(t5, q1, b14, 2) XTU(t0, q0, b15, 1) XD(4096, 3072) XTU(t1, q1, b15, 0) \
+    XNOP
 
 #define XG_WO0 \
     XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XSA(t0, 0, 15, b0, 5, 6144) \
@@ -178,13 +211,13 @@ template <int N, class F> UAV_DEVINL void static_for(F&& f) { static_for_impl(st
     XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XS0(t0, c0, b0, 5, 6144) \
     XS0(t1, c1, b0, 5, 7168) XD(0, 0) XS0(t2, c2, b0, 5, 8192) XS(t3, c0, b1, 5, 9216) XS(t4, c1, b1, 5, 10240) \
     XD(0, 1024) XS(t5, c2, b1, 5, 11264) XT(t0, c0, b2, 5) XT(t1, c1, b2, 4) XD(0, 2048) XT(t2, c2, b2, 3) \
-    XT(t3, c0, b3, 2) XT(t4, c1, b3, 1) XD(0, 3072) XDADV XT(t5, c2, b3, 0)
+    XT(t3, c0, b3, 2) XT(t4, c1, b3, 1) XD(0, 3072) XDADV XT(t5, c2, b3, 0) XNOP
 
 #define XG_V \
     XRD(t0, 12288) XRD(t1, 13312) XRD(t2, 14336) XRD(t3, 15360) XRD(t4, 16384) XRD(t5, 17408) XS0(t0, c0, b0, 5, 18432) \
     XS0(t1, c1, b0, 5, 19456) XD(4096, 0) XS(t2, c0, b1, 5, 20480) XS(t3, c1, b1, 5, 21504) XS(t4, c0, b2, 5, 22528) \
     XD(4096, 1024) XS(t5, c1, b2, 5, 23552) XT(t0, c0, b3, 5) XT(t1, c1, b3, 4) XD(4096, 2048) XT(t2, c0, b4, 3) \
-    XT(t3, c1, b4, 2) XT(t4, c0, b5, 1) XD(4096, 3072) XT(t5, c1, b5, 0)
+    XT(t3, c1, b4, 2) XT(t4, c0, b5, 1) XD(4096, 3072) XT(t5, c1, b5, 0) XNOP
 #define XTMP_OUT [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [so] "+s"(nx.so)
 #define XDMA_IN [ldsn] "s"(nx.ldsn), [srd] "s"(nx.srd), [voff] "v"(voff)
 
@@ -482,6 +515,315 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Fused TEMPORAL attention sub-layer of BasicTransformerBlock (reference attention.py:555-560 `attn_temporal` step, TemporalAttention
+// :626-733, RelativePositionBias :735-772, rotary-embedding-torch RoPE at :709-711) for the same 512-channel levels, T = 8 frames:
+//
+//     out = x + to_out( softmax( RoPE(to_q(n) * scale) . RoPE(to_k(n))^T + bias_h[tq][tk] ) . to_v(n) ) + b_out ,   n = LayerNorm(x)
+//
+// over the 8 tokens of one (batch, pixel).  Same skeleton as the kernel above — lane = token for the whole kernel, A fragments
+// streamed through the LDS ring, named accumulators, row-coalesced stores — with these differences:
+//   * a wave's 32 tokens are 4 neighbouring pixels x 8 frames (lane l32 = 4 t + px): rows (b T + t) hw + pix, i.e. 8 runs of 4 rows;
+//   * three projections per head.  Q^T and K^T = W . Xn^T as above (lane = token); V = Xn . Wv^T with the MFMA operands the OTHER way
+//     round (A = the token fragments in registers, B = the weight fragment): D[token][channel] has lane = CHANNEL and the tokens in
+//     the registers — which is the A-operand layout of V^T in O^T = V^T . P^T, so no transpose exists anywhere;
+//   * S^T[key][query] = K . Q^T is ONE 32 x 32 MFMA tile per head on register operands (K^T's D registers are K's A fragments, same
+//     permuted k order); a query only sees the 8 keys of its own pixel: key row (r & 3) + 8 (r >> 2) + 4 hi has pixel r & 3 and frame
+//     2 (r >> 2) + hi, so register r of lane l32 is live iff (r & 3) == (l32 & 3) — 4 keys in this lane, the other 4 in lane ^ 32; the
+//     rest is masked to -inf (P = 0) and the PV MFMA runs over all 32 keys;
+//   * roundings follow the three-launch chain: q, k, v rounded to fp16 where it stores the fused projection, RoPE in fp32 on the
+//     scaled q / on k and rounded again, O rounded to fp16; P is rounded to fp16 here (the VALU kernel keeps it fp32).
+constexpr int TGPH = 8;                        // groups per head: W_q, W_k, W_v, W_out (2 each)
+constexpr int TNG = XHEADS * TGPH;
+constexpr int TT = 8;                          // frames
+constexpr int TTAB_REL = XTAB + XTABS;         // LDS: relative-position bias [head][tq][hi][m] = bias[head][tq][2 m + hi] (2 KiB)
+constexpr int TTAB_COS = TTAB_REL + 2048;      // RoPE cos [t][hi][2 q + pb] = cos[t][4 q + 2 hi + pb] (512 B), then sin
+constexpr int TSMEM = TTAB_COS + 1024;
+
+struct TattnArgs {
+    const float* x; float* out; const float* gamma; const float* beta; const float* bias; float eps;
+    const char* wq; const char* wk; const char* wv; const char* wo;
+    const float* relbias; const float* rope_cos; const float* rope_sin;
+    int n_batch; long long hw; float scale;
+};
+
+__global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const unsigned tiles_per_b = (unsigned)(p.hw / 16);
+    const unsigned bb = __builtin_amdgcn_readfirstlane(blockIdx.x / tiles_per_b);
+    const unsigned pt = blockIdx.x - bb * tiles_per_b;
+    const long long rowbase = (long long)bb * TT * p.hw + (long long)pt * 16 + wave * 4;      // + t * hw + px
+    const long long row = rowbase + (long long)(l32 >> 2) * p.hw + (l32 & 3);
+
+    const unsigned voff = (unsigned)(wave * XPPW * XFRAG + lane * 16);
+    struct Next { uint4_t srd; unsigned so, ldsn; };
+    auto next_of = [&](int s) -> Next {                    // s = 8 h + j: j 0, 1: W_q; 2, 3: W_k; 4, 5: W_v; 6, 7: W_out
+        Next n;
+        n.ldsn = lds0 + (unsigned)((s & (XRING - 1)) * XGROUP + wave * XPPW * XFRAG);
+        const int h = s >> 3, j = s & 7;
+        const char* base = j < 2 ? p.wq : j < 4 ? p.wk : j < 6 ? p.wv : p.wo;
+        n.srd = make_srd(base, XHEADS * 2 * XGROUP);
+        n.so = (unsigned)((h * 2 + (j & 1)) * XGROUP);
+        if (s >= TNG) n.so = 0x80000000u;                  // zero-fill pieces behind the last group (see the kernel above)
+        return n;
+    };
+    auto issue = [&](int s) {
+        Next n = next_of(s);
+#pragma unroll
+        for (int i = 0; i < XPPW; ++i) dma_piece(n.srd, voff, n.so + i * XFRAG, n.ldsn + i * XFRAG);
+    };
+    Next nx;
+    auto group_sync = [&](int s) -> unsigned {
+        wait_vmcnt<XPPW * (XRING - 2)>();
+        __syncthreads();
+        nx = next_of(s + XRING - 1);
+        return lds0 + (unsigned)((s & (XRING - 1)) * XGROUP) + lane * 16;
+    };
+#pragma unroll
+    for (int s = 0; s < XRING - 1; ++s) issue(s);
+    // ---- tables -> LDS ----------------------------------------------------------------------------------------------------------
+    if (tid < 128) {
+        *(lds_f4wptr_t)(size_t)(lds0 + XTAB + tid * 16) = ((const float4_t*)p.gamma)[tid];
+        *(lds_f4wptr_t)(size_t)(lds0 + XTAB + 2048 + tid * 16) = ((const float4_t*)p.beta)[tid];
+        *(lds_f4wptr_t)(size_t)(lds0 + XTAB + 4096 + tid * 16) = ((const float4_t*)p.bias)[tid];
+    } else {
+        typedef __attribute__((address_space(3))) float* lds_fptr_t;
+        const int u = tid - 128;                            // 128 threads: 512 bias entries (4 each), 128 cos + 128 sin (1 + 1 each)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = u * 4 + k;                        // e = ((h * 8 + tq) * 2 + hi_) * 4 + m
+            const int m = e & 3, hi_ = (e >> 2) & 1, tq = (e >> 3) & 7, h = e >> 6;
+            *(lds_fptr_t)(size_t)(lds0 + TTAB_REL + e * 4) = p.relbias[(h * TT + tq) * TT + 2 * m + hi_];
+        }
+        {
+            const int pb = u & 1, q = (u >> 1) & 3, hi_ = (u >> 3) & 1, t = u >> 4;      // u = ((t * 2 + hi_) * 4 + q) * 2 + pb
+            const int pair = 4 * q + 2 * hi_ + pb;
+            *(lds_fptr_t)(size_t)(lds0 + TTAB_COS + u * 4) = p.rope_cos[t * 16 + pair];
+            *(lds_fptr_t)(size_t)(lds0 + TTAB_COS + 512 + u * 4) = p.rope_sin[t * 16 + pair];
+        }
+    }
+    // ---- LayerNorm statistics (first read), operand fragments + accumulators (second read): as in the kernel above -------------------
+    const float* xr = p.x + row * XC + 4 * hi;
+    const float c0 = p.x[row * XC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < 16; jb += 8) {
+#pragma unroll
+        for (int j = jb; j < jb + 8; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4_t v = *(const float4_t*)(xr + 32 * j + 8 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const float d = v[i] - c0; s1 += d; s2 += d * d; }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    s1 += swap32(s1); s2 += swap32(s2);
+    const float m1 = s1 * (1.0f / XC);
+    const float mean = c0 + m1;
+    const float rstd = rsqrtf(fmaxf(s2 * (1.0f / XC) - m1 * m1, 0.f) + p.eps);
+    __syncthreads();                                        // tables visible
+    half8_t xn[32];
+    static_for<16>([&](auto J) {
+        constexpr int j = J;
+        static_for<4>([&](auto Q) {
+            constexpr int q = Q;
+            const float4_t v = *(const float4_t*)(xr + 32 * j + 8 * q);
+            const unsigned ta = lds0 + XTAB + (32 * j + 8 * q + 4 * hi) * 4;
+            const float4_t g = lds_f4(ta), be = lds_f4(ta + 2048), bo = lds_f4(ta + 4096);
+            static_for<4>([&](auto I) {
+                constexpr int i = I;
+                xn[2 * j + (q >> 1)][4 * (q & 1) + i] = (half_t)((v[i] - mean) * rstd * g[i] + be[i]);
+                acc_set<16 * j + 4 * q + i>(v[i] + bo[i]);
+            });
+        });
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    });
+
+    // (the lane's pixel / frame from a fresh lane id: kept live from the row computation at the top they were spilled across the prologue)
+    int lane2;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\nv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane2));
+    const int px = lane2 & 3, tq = (lane2 & 31) >> 2;
+    // ---- heads ------------------------------------------------------------------------------------------------------------------
+#pragma unroll 1
+    for (int h = 0; h < XHEADS; ++h) {
+        half8_t t0, t1, t2, t3, t4, t5;
+        const int sg = h * TGPH;
+        const unsigned tc = lds0 + TTAB_COS + ((tq * 2 + hi) * 8) * 4;
+        // RoPE on the lane's first 32 head channels (tile 0: registers r <-> channel (r & 3) + 8 (r >> 2) + 4 hi; pairs (4 q, 4 q + 1),
+        // (4 q + 2, 4 q + 3) of the registers are channel pairs (2 i, 2 i + 1), angle index 4 q + 2 hi + pb)
+        auto rope16 = [&](const float (&a)[16], half8_t& f0, half8_t& f1) {
+            const float4_t ca = lds_f4(tc), cb = lds_f4(tc + 16), sa = lds_f4(tc + 512), sb = lds_f4(tc + 528);
+            const float cs[8] = {ca[0], ca[1], ca[2], ca[3], cb[0], cb[1], cb[2], cb[3]};
+            const float sn[8] = {sa[0], sa[1], sa[2], sa[3], sb[0], sb[1], sb[2], sb[3]};
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) {                // pair pr = 2 q + pb <-> registers 4 q + 2 pb, 4 q + 2 pb + 1
+                const int r = 4 * (pr >> 1) + 2 * (pr & 1);
+                const float u = a[r], w = a[r + 1];
+                const half_t e0 = (half_t)(u * cs[pr] - w * sn[pr]), e1 = (half_t)(w * cs[pr] + u * sn[pr]);
+                if (r < 8) { f0[r] = e0; f0[r + 1] = e1; } else { f1[r - 8] = e0; f1[r - 7] = e1; }
+            }
+        };
+        // ---- Q^T = Wq_h . Xn^T -> fp16 (as stored by the chain) -> * scale -> RoPE -> fp16 B fragments ------------------------------
+        half8_t qf[4];
+        {
+            float16_t q0, q1;
+            {
+                const unsigned st = group_sync(sg);
+                asm volatile(XG_WQ_FIRST : [q0] "=&v"(q0), [q1] "=&v"(q1), XTMP_OUT
+                             : [st] "v"(st), [b0] "v"(xn[0]), [b1] "v"(xn[1]), [b2] "v"(xn[2]), [b3] "v"(xn[3]), [b4] "v"(xn[4]), [b5] "v"(xn[5]),
+                               [b6] "v"(xn[6]), [b7] "v"(xn[7]), [b8] "v"(xn[8]), [b9] "v"(xn[9]), [b10] "v"(xn[10]), [b11] "v"(xn[11]),
+                               [b12] "v"(xn[12]), [b13] "v"(xn[13]), [b14] "v"(xn[14]), [b15] "v"(xn[15]), XDMA_IN : "memory", "scc");
+            }
+            {
+                const unsigned st = group_sync(sg + 1);
+                asm volatile(XG_WQ : [q0] "+v"(q0), [q1] "+v"(q1), XTMP_OUT
+                             : [st] "v"(st), [b0] "v"(xn[16]), [b1] "v"(xn[17]), [b2] "v"(xn[18]), [b3] "v"(xn[19]), [b4] "v"(xn[20]), [b5] "v"(xn[21]),
+                               [b6] "v"(xn[22]), [b7] "v"(xn[23]), [b8] "v"(xn[24]), [b9] "v"(xn[25]), [b10] "v"(xn[26]), [b11] "v"(xn[27]),
+                               [b12] "v"(xn[28]), [b13] "v"(xn[29]), [b14] "v"(xn[30]), [b15] "v"(xn[31]), XDMA_IN : "memory", "scc");
+            }
+            float a[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = (float)(half_t)q0[r] * p.scale;
+            rope16(a, qf[0], qf[1]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { qf[2][e] = (half_t)((float)(half_t)q1[e] * p.scale); qf[3][e] = (half_t)((float)(half_t)q1[8 + e] * p.scale); }
+        }
+        // ---- K^T = Wk_h . Xn^T -> fp16 -> RoPE -> fp16: its D registers are the A fragments of K in S^T = K . Q^T ----------------------
+        half8_t kf[4];
+        {
+            float16_t q0, q1;
+            {
+                const unsigned st = group_sync(sg + 2);
+                asm volatile(XG_WQ_FIRST : [q0] "=&v"(q0), [q1] "=&v"(q1), XTMP_OUT
+                             : [st] "v"(st), [b0] "v"(xn[0]), [b1] "v"(xn[1]), [b2] "v"(xn[2]), [b3] "v"(xn[3]), [b4] "v"(xn[4]), [b5] "v"(xn[5]),
+                               [b6] "v"(xn[6]), [b7] "v"(xn[7]), [b8] "v"(xn[8]), [b9] "v"(xn[9]), [b10] "v"(xn[10]), [b11] "v"(xn[11]),
+                               [b12] "v"(xn[12]), [b13] "v"(xn[13]), [b14] "v"(xn[14]), [b15] "v"(xn[15]), XDMA_IN : "memory", "scc");
+            }
+            {
+                const unsigned st = group_sync(sg + 3);
+                asm volatile(XG_WQ : [q0] "+v"(q0), [q1] "+v"(q1), XTMP_OUT
+                             : [st] "v"(st), [b0] "v"(xn[16]), [b1] "v"(xn[17]), [b2] "v"(xn[18]), [b3] "v"(xn[19]), [b4] "v"(xn[20]), [b5] "v"(xn[21]),
+                               [b6] "v"(xn[22]), [b7] "v"(xn[23]), [b8] "v"(xn[24]), [b9] "v"(xn[25]), [b10] "v"(xn[26]), [b11] "v"(xn[27]),
+                               [b12] "v"(xn[28]), [b13] "v"(xn[29]), [b14] "v"(xn[30]), [b15] "v"(xn[31]), XDMA_IN : "memory", "scc");
+            }
+            float a[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = (float)(half_t)q0[r];
+            rope16(a, kf[0], kf[1]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { kf[2][e] = (half_t)q1[e]; kf[3][e] = (half_t)q1[8 + e]; }
+        }
+        // ---- S^T [32 keys][32 queries] on register operands; softmax over the 8 keys of the query's own pixel ------------------------
+        float16_t sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[ks], sacc, 0, 0, 0);
+        const float4_t rb = lds_f4(lds0 + TTAB_REL + (((h * 8 + tq) * 2 + hi) * 4) * 4);        // bias[h][tq][2 m + hi], m = 0 .. 3
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float s = ((r & 3) == px) ? sacc[r] + rb[r >> 2] : -INFINITY;
+            sacc[r] = s; mx = fmaxf(mx, s);
+        }
+        mx = fmaxf(mx, swap32(mx));
+        float ps = 0.f;
+        half8_t pf[2];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f((sacc[r] - mx) * 1.44269504088896341f);
+            ps += e;
+            pf[r >> 3][r & 7] = (half_t)e;
+        }
+        ps += swap32(ps);
+        const float inv = 1.0f / ps;
+        // ---- V = Xn . Wv_h^T (lane = channel, registers = tokens) -> fp16 = the A fragments of V^T ------------------------------------
+        half8_t of[4];
+        {
+            float16_t q0, q1;
+            {
+                const unsigned st = group_sync(sg + 4);
+                asm volatile(XG_WV_FIRST : [q0] "=&v"(q0), [q1] "=&v"(q1), XTMP_OUT
+                             : [st] "v"(st), [b0] "v"(xn[0]), [b1] "v"(xn[1]), [b2] "v"(xn[2]), [b3] "v"(xn[3]), [b4] "v"(xn[4]), [b5] "v"(xn[5]),
+                               [b6] "v"(xn[6]), [b7] "v"(xn[7]), [b8] "v"(xn[8]), [b9] "v"(xn[9]), [b10] "v"(xn[10]), [b11] "v"(xn[11]),
+                               [b12] "v"(xn[12]), [b13] "v"(xn[13]), [b14] "v"(xn[14]), [b15] "v"(xn[15]), XDMA_IN : "memory", "scc");
+            }
+            {
+                const unsigned st = group_sync(sg + 5);
+                asm volatile(XG_WV : [q0] "+v"(q0), [q1] "+v"(q1), XTMP_OUT
+                             : [st] "v"(st), [b0] "v"(xn[16]), [b1] "v"(xn[17]), [b2] "v"(xn[18]), [b3] "v"(xn[19]), [b4] "v"(xn[20]), [b5] "v"(xn[21]),
+                               [b6] "v"(xn[22]), [b7] "v"(xn[23]), [b8] "v"(xn[24]), [b9] "v"(xn[25]), [b10] "v"(xn[26]), [b11] "v"(xn[27]),
+                               [b12] "v"(xn[28]), [b13] "v"(xn[29]), [b14] "v"(xn[30]), [b15] "v"(xn[31]), XDMA_IN : "memory", "scc");
+            }
+            half8_t vf[2][2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { vf[0][0][e] = (half_t)q0[e]; vf[0][1][e] = (half_t)q0[8 + e]; vf[1][0][e] = (half_t)q1[e]; vf[1][1][e] = (half_t)q1[8 + e]; }
+            // O^T [64 ch][32 queries] = V^T . P^T
+            float16_t o0, o1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][ks], pf[ks], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][ks], pf[ks], o1, 0, 0, 0);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                of[0][e] = (half_t)(o0[e] * inv); of[1][e] = (half_t)(o0[8 + e] * inv);
+                of[2][e] = (half_t)(o1[e] * inv); of[3][e] = (half_t)(o1[8 + e] * inv);
+            }
+        }
+        // ---- acc += Wout[:, head h] . O^T ---------------------------------------------------------------------------------------------
+        {
+            const unsigned st = group_sync(sg + 6);
+            asm volatile(XG_WO0 : XTMP_OUT : [st] "v"(st), [b0] "v"(of[0]), [b1] "v"(of[1]), [b2] "v"(of[2]), [b3] "v"(of[3]), XDMA_IN
+                         : "memory", "scc", XACC_CLOBBERS);
+        }
+        {
+            const unsigned st = group_sync(sg + 7);
+            asm volatile(XG_WO1 : XTMP_OUT : [st] "v"(st), [b0] "v"(of[0]), [b1] "v"(of[1]), [b2] "v"(of[2]), [b3] "v"(of[3]), XDMA_IN
+                         : "memory", "scc", XACC_CLOBBERS);
+        }
+    }
+    asm volatile("s_nop 15\ns_nop 15" ::: "memory");
+    wait_vmcnt<0>();
+    __syncthreads();
+    // ---- store: row-coalesced through the idle ring (rows of the wave in lane order: 4 t + px) -----------------------------------------
+    {
+        int lane_;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\nv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
+        const int ln = lane_, l32e = lane_ & 31, hie = lane_ >> 5;
+        const unsigned wbuf = (unsigned)(size_t)(lptr_t)smem + (unsigned)(wave * XGROUP);
+        float* const obase = p.out + rowbase * XC + ln * 4;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            static_for<32>([&](auto JQ) {
+                constexpr int j = JQ / 4, q = JQ % 4;
+                float4_t v;
+                if (hh == 0) v = float4_t{acc_get<16 * j + 4 * q>(), acc_get<16 * j + 4 * q + 1>(), acc_get<16 * j + 4 * q + 2>(), acc_get<16 * j + 4 * q + 3>()};
+                else v = float4_t{acc_get<128 + 16 * j + 4 * q>(), acc_get<128 + 16 * j + 4 * q + 1>(), acc_get<128 + 16 * j + 4 * q + 2>(), acc_get<128 + 16 * j + 4 * q + 3>()};
+                const int pc = 8 * j + 2 * q + hie;
+                *(lds_f4wptr_t)(size_t)(wbuf + l32e * 1024 + ((pc ^ (l32e & 7)) << 4)) = v;
+            });
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int kb = 0; kb < 32; kb += 8) {
+                float4_t r[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) r[k] = lds_f4(wbuf + (kb + k) * 1024 + ((ln ^ ((kb + k) & 7)) << 4));
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    *(float4_t*)(obase + ((long long)((kb + k) >> 2) * p.hw + ((kb + k) & 3)) * XC + hh * 256) = r[k];
+            }
+            asm volatile("" ::: "memory");
+        }
+    }
+}
+
 // Text K | V rows [n_batch * lk][stride] (fp16, head h in columns 64 h ..) -> the fragment stream of the kernel above:
 // [n_batch][8 heads][32 fragments][64 lanes][8 halves]; fragments 0 .. 11 = K_h (key tile f % 3, k-step f / 3), 12 .. 23 = V_h^T
 // (k-step g >> 1, channel tile g & 1, g = f - 12); keys >= lk and the 8 spare fragments are zero.
@@ -548,6 +890,22 @@ extern "C" int uav_xattn_sublayers_f32(const float* x, float* out, const uav_xat
     static UavDynLds lds;
     if (int rc = uav_set_dyn_lds(lds, (const void*)xattn_sublayer_kernel<0>, XSMEM)) return rc;
     hipLaunchKernelGGL(xattn_sublayer_kernel<0>, dim3((unsigned)(rows / 128)), dim3(256), XSMEM, (hipStream_t)stream, a);
+    return uav_launch_status();
+}
+
+extern "C" int uav_tattn_sublayer_f32(const float* x, float* out, const uav_tattn_params* q, int32_t n_batch, int32_t t_len, int64_t hw,
+                                      int32_t channels, int32_t heads, float scale, void* stream) {
+    if (!x || !out || !q || !q->ln_gamma || !q->ln_beta || !q->wq_packed || !q->wk_packed || !q->wv_packed || !q->wo_packed || !q->out_bias ||
+        !q->rel_bias || !q->rope_cos || !q->rope_sin)
+        return UAV_EINVAL;
+    if (channels != XC || heads != XHEADS || t_len != TT || q->rot_dim != 32) return UAV_ESHAPE;
+    if (n_batch <= 0 || hw <= 0 || (hw % 16) || (long long)n_batch * (hw / 16) >= (1ll << 31)) return UAV_ESHAPE;
+    if (((size_t)x | (size_t)out) & 15) return UAV_EALIGN;
+    static UavDynLds lds;
+    if (int rc = uav_set_dyn_lds(lds, (const void*)tattn_sublayer_kernel, TSMEM)) return rc;
+    TattnArgs a{x, out, q->ln_gamma, q->ln_beta, q->out_bias, q->ln_eps, (const char*)q->wq_packed, (const char*)q->wk_packed,
+                (const char*)q->wv_packed, (const char*)q->wo_packed, q->rel_bias, q->rope_cos, q->rope_sin, n_batch, (long long)hw, scale};
+    hipLaunchKernelGGL(tattn_sublayer_kernel, dim3((unsigned)(n_batch * (hw / 16))), dim3(256), TSMEM, (hipStream_t)stream, a);
     return uav_launch_status();
 }
 

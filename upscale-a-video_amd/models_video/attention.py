@@ -171,6 +171,16 @@ class TemporalAttention(CrossAttention):
     def run_temporal(self, x, residual, g: E.Geom, ln=None):
         c = self.heads * self.dim_head
         bias, cos, sin, rot = self._tables(g.t)
+        if (ln is not None and residual is x and E.TATTN_FUSED and not E.LN_FOLD and self.to_q.bias is None and self.to_out[0].bias is not None
+                and cos is not None and ops.tattn_ok(x, heads=self.heads, head_dim=self.dim_head, t_len=g.t, hw=g.hw, rot_dim=rot)):
+            # the whole sub-layer in one launch (csrc/xattn_fused.hip, tattn_sublayer_kernel): LayerNorm -> q | k | v -> RoPE + bias + per-pixel
+            # softmax over the frames -> to_out -> + residual, the fp32 stream read once and written once
+            dev = E._dev(self.to_q.weight)
+            pk = lambda name, lin, kind: self._cache().get(("tattn", name), lambda: ops.pack_xattn_weight(lin.weight, kind, dev), (lin.weight,))
+            return ops.tattn_sublayer(x, E.f32_param(self, "tattn.g", ln.weight), E.f32_param(self, "tattn.b", ln.bias), ln.eps,
+                                      pk("q", self.to_q, "q"), pk("k", self.to_k, "q"), pk("v", self.to_v, "q"), pk("o", self.to_out[0], "out"),
+                                      E.f32_param(self, "tattn.ob", self.to_out[0].bias), bias, cos, sin,
+                                      n_batch=g.b, t_len=g.t, hw=g.hw, rot_dim=rot, scale=self.scale)
         qkv = ops.linear(x, E.packed_cat(self, "qkv", [self.to_q, self.to_k, self.to_v])) if ln is None else \
             E.ln_linear(self, "qkv", ln, x, [self.to_q, self.to_k, self.to_v])
         o = ops.temporal_attention(qkv, n_batch=g.b, t_len=g.t, hw=g.hw, c=c, heads=self.heads, scale=self.scale,

@@ -44,6 +44,12 @@ class XattnParams(C.Structure):
     _fields_ = [("ln_gamma", c_p), ("ln_beta", c_p), ("ln_eps", f32), ("wq_packed", c_p), ("kv_packed", c_p), ("wo_packed", c_p), ("out_bias", c_p)]
 
 
+class TattnParams(C.Structure):
+    """Mirror of `uav_tattn_params` (include/uav_hip.h): the fused temporal attention sub-layer."""
+    _fields_ = [("ln_gamma", c_p), ("ln_beta", c_p), ("ln_eps", f32), ("wq_packed", c_p), ("wk_packed", c_p), ("wv_packed", c_p),
+                ("wo_packed", c_p), ("out_bias", c_p), ("rel_bias", c_p), ("rope_cos", c_p), ("rope_sin", c_p), ("rot_dim", i32)]
+
+
 CONV_GEGLU = 1
 CONV_OUT_F32 = 2
 CONV_PERSISTENT = 64
@@ -74,6 +80,7 @@ SIGNATURES = {
     "uav_layernorm_f32in": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, f32, c_p]),
     "uav_attention_f16": (C.c_int, [c_p, i64, c_p, i64, c_p, i64, c_p, i64, i32, i32, i32, i32, i32, i32, f32, i32, c_p, c_p]),
     "uav_xattn_sublayers_f32": (C.c_int, [c_p, c_p, c_p, i32, i64, i32, i32, i32, i32, f32, c_p]),
+    "uav_tattn_sublayer_f32": (C.c_int, [c_p, c_p, c_p, i32, i32, i64, i32, i32, f32, c_p]),
     "uav_xattn_pack_kv": (C.c_int, [c_p, i64, c_p, i64, i32, i32, i32, i32, c_p, c_p]),
     "uav_temporal_attention_f16": (C.c_int, [c_p, c_p, i32, i32, i64, i32, i32, f32, c_p, c_p, i32, c_p, c_p]),
     "uav_linear_small": (C.c_int, [c_p, c_p, c_p, c_p, i32, i32, i32, i32, i32, c_p]),

@@ -99,12 +99,13 @@ def _build_locked(objdir, verbose):
 
 
 def audit_accumulator_file():
-    """attn512w_kernel (csrc/attention.hip) and xattn_sublayer_kernel (csrc/xattn_fused.hip) keep their 256 fp32 accumulators in
+    """attn512w_kernel (csrc/attention.hip), xattn_sublayer_kernel and tattn_sublayer_kernel (csrc/xattn_fused.hip) keep their 256 fp32 accumulators in
     a[0:255] BY NAME from inline asm.  That is only sound while hipcc itself never touches the accumulator file in those kernels
     (it would treat the registers as free between our statements): compile the file to assembly and fail the build if any
     compiler-generated instruction of the kernel names an AGPR."""
     _audit_named_accumulators("attention.hip", "attn512w_kernel")
     _audit_named_accumulators("xattn_fused.hip", "xattn_sublayer_kernelILi0E")
+    _audit_named_accumulators("xattn_fused.hip", "tattn_sublayer_kernel")
 
 
 def _audit_named_accumulators(fname, kernel):

@@ -366,6 +366,9 @@ XATTN_FUSED = _os.environ.get("UAV_XATTN_FUSED", "1") != "0"
 # ... and attn1 + attn2 of a block with only_cross_attention (both text cross-attention) as ONE launch of that kernel: the second LayerNorm
 # runs on the accumulators.  UAV_XATTN_PAIR=0 keeps one launch per sub-layer.
 XATTN_PAIR = _os.environ.get("UAV_XATTN_PAIR", "1") != "0"
+# ... and the TEMPORAL attention sub-layer of the same blocks (LayerNorm -> q | k | v -> RoPE + relative-position bias + softmax over the 8
+# frames of a pixel -> to_out -> + residual) as one launch (tattn_sublayer_kernel).  UAV_TATTN_FUSED=0 keeps the four-launch chain.
+TATTN_FUSED = _os.environ.get("UAV_TATTN_FUSED", "1") != "0"
 
 
 def packed_ln_linear(mod: EngineModule, name, ln: nn.LayerNorm, linears, geglu=False):

@@ -718,6 +718,31 @@ def xattn_sublayer(x, gamma, beta, eps, wq_packed, kv_packed, wo_packed, out_bia
     return xattn_sublayers(x, [(gamma, beta, eps, wq_packed, kv_packed, wo_packed, out_bias)], rows_per_kv=rows_per_kv, lk=lk, scale=scale, out=out)
 
 
+def tattn_ok(x, *, heads, head_dim, t_len, hw, rot_dim):
+    """Shapes the fused temporal sub-layer kernel takes (csrc/xattn_fused.hip tattn_sublayer_kernel)."""
+    return (x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == XATTN_C and heads == XATTN_HEADS and head_dim == XATTN_D
+            and t_len == 8 and rot_dim == 32 and hw % 16 == 0 and x.shape[0] % (t_len * hw) == 0)
+
+
+def tattn_sublayer(x, gamma, beta, eps, wq_packed, wk_packed, wv_packed, wo_packed, out_bias, rel_bias, rope_cos, rope_sin, *,
+                   n_batch, t_len, hw, rot_dim, scale, out=None):
+    """x + to_out(temporal_attention(to_q | to_k | to_v (LayerNorm(x)))) + bias on fp32 stream rows [B*T*hw][512] in one launch."""
+    lib = _lib.load()
+    _req(x, torch.float32, "x")
+    y = torch.empty_like(x) if out is None else out
+    q = _lib.TattnParams()
+    q.ln_gamma, q.ln_beta, q.ln_eps = _p(gamma), _p(beta), float(eps)
+    q.wq_packed, q.wk_packed, q.wv_packed, q.wo_packed, q.out_bias = _p(wq_packed), _p(wk_packed), _p(wv_packed), _p(wo_packed), _p(out_bias)
+    q.rel_bias, q.rope_cos, q.rope_sin, q.rot_dim = _p(rel_bias), _p(rope_cos), _p(rope_sin), int(rot_dim)
+    m = x.shape[0]
+    ev = PROFILER.begin("tattn_sublayer")
+    rc = lib.uav_tattn_sublayer_f32(_p(x), _p(y), C.byref(q), n_batch, t_len, hw, XATTN_C, XATTN_HEADS, scale, _stream())
+    _lib.check(rc, "uav_tattn_sublayer_f32")
+    PROFILER.end(ev, "tattn_sublayer" if not PROFILER.detail else f"tattn_sublayer M={m}", 2.0 * m * (4 * XATTN_C * XATTN_C) + 4.0 * m * t_len * XATTN_C,
+                 8.0 * m * XATTN_C)
+    return y
+
+
 def temporal_attention(qkv, *, n_batch, t_len, hw, c, heads, scale, rope_cos, rope_sin, rot_dim, bias):
     lib = _lib.load()
     _req(qkv, HALF, "qkv")
