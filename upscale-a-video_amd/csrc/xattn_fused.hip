@@ -576,11 +576,12 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
         for (int i = 0; i < XPPW; ++i) dma_piece(n.srd, voff, n.so + i * XFRAG, n.ldsn + i * XFRAG);
     };
     Next nx;
+    unsigned lane16 = lane * 16;                            // (re-derived from a fresh lane id behind the prologue, see below)
     auto group_sync = [&](int s) -> unsigned {
         wait_vmcnt<XPPW * (XRING - 2)>();
         __syncthreads();
         nx = next_of(s + XRING - 1);
-        return lds0 + (unsigned)((s & (XRING - 1)) * XGROUP) + lane * 16;
+        return lds0 + (unsigned)((s & (XRING - 1)) * XGROUP) + lane16;
     };
 #pragma unroll
     for (int s = 0; s < XRING - 1; ++s) issue(s);
@@ -610,9 +611,9 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
     const float c0 = p.x[row * XC];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int jb = 0; jb < 16; jb += 8) {
+    for (int jb = 0; jb < 16; jb += 4) {
 #pragma unroll
-        for (int j = jb; j < jb + 8; ++j)
+        for (int j = jb; j < jb + 4; ++j)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const float4_t v = *(const float4_t*)(xr + 32 * j + 8 * q);
@@ -640,13 +641,14 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
                 acc_set<16 * j + 4 * q + i>(v[i] + bo[i]);
             });
         });
-        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+        if (j & 1) __builtin_amdgcn_sched_barrier(0);       // batches of 8 loads (this prologue carries the row arithmetic of the frame-strided tile on top)
     });
 
     // (the lane's pixel / frame from a fresh lane id: kept live from the row computation at the top they were spilled across the prologue)
     int lane2;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\nv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane2));
     const int px = lane2 & 3, tq = (lane2 & 31) >> 2;
+    lane16 = (unsigned)lane2 * 16;
     // ---- heads ------------------------------------------------------------------------------------------------------------------
 #pragma unroll 1
     for (int h = 0; h < XHEADS; ++h) {
@@ -718,11 +720,14 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
             for (int e = 0; e < 8; ++e) { kf[2][e] = (half_t)q1[e]; kf[3][e] = (half_t)q1[8 + e]; }
         }
         // ---- S^T [32 keys][32 queries] on register operands; softmax over the 8 keys of the query's own pixel ------------------------
+        // (asm with VGPR results: left to hipcc the MFMA intrinsic takes its result registers from the accumulator file — a[0:15], i.e. the
+        //  NAMED accumulator tile 0 of this kernel, which the compiler cannot know is live; the build audit caught exactly that)
         float16_t sacc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[ks], qf[ks], sacc, 0, 0, 0);
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %5, 0\n"
+                     "v_mfma_f32_32x32x16_f16 %0, %2, %6, %0\n"
+                     "v_mfma_f32_32x32x16_f16 %0, %3, %7, %0\n"
+                     "v_mfma_f32_32x32x16_f16 %0, %4, %8, %0\n" XNOP
+                     : "=&v"(sacc) : "v"(kf[0]), "v"(kf[1]), "v"(kf[2]), "v"(kf[3]), "v"(qf[0]), "v"(qf[1]), "v"(qf[2]), "v"(qf[3]));
         const float4_t rb = lds_f4(lds0 + TTAB_REL + (((h * 8 + tq) * 2 + hi) * 4) * 4);        // bias[h][tq][2 m + hi], m = 0 .. 3
         float mx = -INFINITY;
 #pragma unroll
@@ -764,13 +769,11 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
             for (int e = 0; e < 8; ++e) { vf[0][0][e] = (half_t)q0[e]; vf[0][1][e] = (half_t)q0[8 + e]; vf[1][0][e] = (half_t)q1[e]; vf[1][1][e] = (half_t)q1[8 + e]; }
             // O^T [64 ch][32 queries] = V^T . P^T
             float16_t o0, o1;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-#pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                o0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[0][ks], pf[ks], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[1][ks], pf[ks], o1, 0, 0, 0);
-            }
+            asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %6, 0\n"
+                         "v_mfma_f32_32x32x16_f16 %1, %4, %6, 0\n"
+                         "v_mfma_f32_32x32x16_f16 %0, %3, %7, %0\n"
+                         "v_mfma_f32_32x32x16_f16 %1, %5, %7, %1\n" XNOP
+                         : "=&v"(o0), "=&v"(o1) : "v"(vf[0][0]), "v"(vf[0][1]), "v"(vf[1][0]), "v"(vf[1][1]), "v"(pf[0]), "v"(pf[1]));
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 of[0][e] = (half_t)(o0[e] * inv); of[1][e] = (half_t)(o0[8 + e] * inv);
