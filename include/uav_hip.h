@@ -273,6 +273,13 @@ typedef struct {
 } uav_tattn_params;
 int uav_tattn_sublayer_f32(const float* x, float* out, const uav_tattn_params* p, int32_t n_batch, int32_t t_len, int64_t hw,
                            int32_t channels, int32_t heads, float scale, void* stream);
+/* attn1 -> attn2 -> attn_temporal of one BasicTransformerBlock with only_cross_attention (attention.py:523-564) in ONE launch: `cross`
+ * = the two text cross-attention sub-layers (uav_xattn_params[2], K | V packed per kv batch = per b of n_batch), then the temporal
+ * sub-layer; the rows between the three stay in the accumulators, every LayerNorm but the first runs on them in registers.  Same shape
+ * contract as uav_tattn_sublayer_f32, lk <= 96. */
+int uav_block_attn_sublayers_f32(const float* x, float* out, const uav_xattn_params* cross, int32_t lk, float cross_scale,
+                                 const uav_tattn_params* temporal, int32_t n_batch, int32_t t_len, int64_t hw, int32_t channels,
+                                 int32_t heads, float temporal_scale, void* stream);
 /* k, v: fp16 rows [n_batch * lk][stride] (head h in columns h*head_dim ..) -> out: n_batch * heads * 32 KiB */
 int uav_xattn_pack_kv(const void* k, int64_t k_stride, const void* v, int64_t v_stride, int32_t n_batch, int32_t lk,
                       int32_t heads, int32_t head_dim, void* out, void* stream);

@@ -268,6 +268,15 @@ def tattn_sublayer(x, gamma, beta, eps, wq_packed, wk_packed, wv_packed, wo_pack
     return y
 
 
+def block_attn_sublayers(x, cross, temporal, *, n_batch, t_len, hw, lk, cross_scale, temporal_scale, out=None):
+    y = xattn_sublayers(x, cross, rows_per_kv=t_len * hw, lk=lk, scale=cross_scale)
+    y = tattn_sublayer(y, *temporal[:11], n_batch=n_batch, t_len=t_len, hw=hw, rot_dim=temporal[11], scale=temporal_scale)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def linear_small(x, w, b, *, pre_silu=False, post_silu=False):
     x = F.silu(x.float()) if pre_silu else x.float()
@@ -368,7 +377,7 @@ def sft_fuse(dec, scale, shift, w, out_f32=False):
     return y if out_f32 else _h(y)
 
 
-_OPS = ("ln_fold_ok", "resize_area_f32", "cast_f16", "cast_hilo", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "xattn_pack_kv", "xattn_sublayer", "xattn_sublayers", "tattn_sublayer", "temporal_attention", "linear_small",
+_OPS = ("ln_fold_ok", "resize_area_f32", "cast_f16", "cast_hilo", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "xattn_pack_kv", "xattn_sublayer", "xattn_sublayers", "tattn_sublayer", "block_attn_sublayers", "temporal_attention", "linear_small",
         "timestep_embedding", "pack_nhwc", "unpack_ncthw", "axpby", "cfg_ddim_v0", "ddim_vt")
 
 

@@ -1162,3 +1162,40 @@ def test_fused_temporal_attention_sublayer(ops, dev, case):
     x2 = x.clone()
     assert ops.tattn_sublayer(x2, gamma, beta, 1e-5, *pk, bo, relb, cos, sin, out=x2, **kw) is x2 and torch.equal(x2, y)     # in place
     assert torch.equal(ops.tattn_sublayer(x, gamma, beta, 1e-5, *pk, bo, relb, cos, sin, **kw), y)                             # deterministic
+
+
+def test_fused_block_attention_three_sublayers_equal_pair_then_temporal(ops, dev):
+    """uav_block_attn_sublayers_f32 (attn1 -> attn2 -> attn_temporal of a block with only_cross_attention in one launch, attention.py:523-564)
+    against the cross-attention pair launch followed by the temporal launch on the same rows."""
+    g = torch.Generator().manual_seed(99)
+    C, H, D, T, nb, hh, ww, lk = 512, 8, 64, 8, 2, 24, 16, 77
+    hw = hh * ww
+    M = nb * T * hw
+    x = (torch.randn(M, C, generator=g) * 1.3 + 0.4).to(dev)
+    cross = []
+    for _ in range(2):
+        gamma = (torch.randn(C, generator=g) * 0.2 + 1.0).to(dev); beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+        wq = h16(C, C, dev=dev, scale=C ** -0.5, gen=g); wo = h16(C, C, dev=dev, scale=C ** -0.5, gen=g)
+        bo = (torch.randn(C, generator=g) * 0.1).to(dev)
+        kv = (torch.randn(nb * lk, 2 * C, generator=g) * 1.5).half().to(dev)
+        kvp = ops.xattn_pack_kv(kv[:, :C], kv[:, C:], n_batch=nb, lk=lk, k_stride=2 * C, v_stride=2 * C)
+        cross.append((gamma, beta, 1e-5, ops.pack_xattn_weight(wq, "q", dev), kvp, ops.pack_xattn_weight(wo, "out", dev), bo))
+    gamma = (torch.randn(C, generator=g) * 0.2 + 1.0).to(dev); beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+    ws = [h16(C, C, dev=dev, scale=C ** -0.5, gen=g) for _ in range(4)]
+    bo = (torch.randn(C, generator=g) * 0.1).to(dev)
+    relb = (torch.randn(H, T, T, generator=g) * 0.5).to(dev).contiguous()
+    fr = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    ang = torch.arange(T).float()[:, None] * fr[None, :]
+    cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
+    temporal = (gamma, beta, 1e-5, *[ops.pack_xattn_weight(w_, "q", dev) for w_ in ws[:3]], ops.pack_xattn_weight(ws[3], "out", dev), bo, relb, cos, sin, 32)
+    scale = D ** -0.5
+    y1 = ops.xattn_sublayers(x, cross, rows_per_kv=T * hw, lk=lk, scale=scale)
+    y2 = ops.tattn_sublayer(y1, *temporal[:11], n_batch=nb, t_len=T, hw=hw, rot_dim=32, scale=scale)
+    kw = dict(n_batch=nb, t_len=T, hw=hw, lk=lk, cross_scale=scale, temporal_scale=scale)
+    y3 = ops.block_attn_sublayers(x, cross, temporal, **kw)
+    assert bool(torch.isfinite(y3).all())
+    e, e_upd = rel_l2(y3, y2), rel_l2(y3 - x, y2 - x)
+    assert e < 1e-4 and e_upd < 1.5e-3, (e, e_upd)            # LayerNorm statistics from the accumulators vs from the shifted one-pass first read
+    assert torch.equal(ops.block_attn_sublayers(x, cross, temporal, **kw), y3)
+    xin = x.clone()
+    assert ops.block_attn_sublayers(xin, cross, temporal, out=xin, **kw) is xin and torch.equal(xin, y3)

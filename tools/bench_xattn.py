@@ -97,8 +97,17 @@ def tcase(name, nb, hh, ww):
     def chain(): ln(); qkv(); att(); out()
     def fused(): st["f"] = ops.tattn_sublayer(x, gamma, beta, 1e-5, *pk, bo, relb, cos, sin, n_batch=nb, t_len=T, hw=hw, rot_dim=32, scale=scale)
 
-    fns = {"fused": fused, "chain": chain, "layernorm": ln, "qkv": qkv, "temporal_attention": att, "to_out": out}
-    chain(); fused(); chain(); fused()
+    # the block launch: two cross-attention sub-layers (synthetic weights) + this temporal sub-layer in one kernel, against pair + temporal
+    LK = 77
+    kvx = torch.randn(nb * LK, 2 * C, generator=g).half().to(dev)
+    kvp = ops.xattn_pack_kv(kvx[:, :C], kvx[:, C:], n_batch=nb, lk=LK, k_stride=2 * C, v_stride=2 * C)
+    xs = (gamma, beta, 1e-5, pk[0], kvp, pk[3], bo)
+    tp = (gamma, beta, 1e-5, *pk, bo, relb, cos, sin, 32)
+    def pair(): st["p"] = ops.xattn_sublayers(x, [xs, xs], rows_per_kv=T * hw, lk=LK, scale=scale)
+    def block(): st["b"] = ops.block_attn_sublayers(x, [xs, xs], tp, n_batch=nb, t_len=T, hw=hw, lk=LK, cross_scale=scale, temporal_scale=scale)
+
+    fns = {"fused": fused, "cross_pair": pair, "block_of_three": block, "chain": chain, "layernorm": ln, "qkv": qkv, "temporal_attention": att, "to_out": out}
+    chain(); fused(); pair(); block(); chain(); fused()
     torch.cuda.synchronize()
     t = {kk: [] for kk in fns}
     for _ in range(ROUNDS):

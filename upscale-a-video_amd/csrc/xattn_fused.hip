@@ -221,6 +221,143 @@ template <int N, class F> UAV_DEVINL void static_for(F&& f) { static_for_impl(st
 #define XTMP_OUT [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [so] "+s"(nx.so)
 #define XDMA_IN [ldsn] "s"(nx.ldsn), [srd] "s"(nx.srd), [voff] "v"(voff)
 
+// ---- the head loop of ONE text cross-attention sub-layer on the wave's 32 tokens (shared by the cross-attention kernel and the block
+// kernel below): groups sg0 .. sg0 + 39 of the stream ----------------------------------------------------------------------------------
+struct XNext { uint4_t srd; unsigned so, ldsn; };         // the group XRING - 1 = 3 ahead: its source and its ring slot
+template <int TR, class GS>
+UAV_DEVINL void xattn_heads(const int sg0, half8_t (&xn)[32], GS&& group_sync, XNext& nx, const unsigned voff, const int hi, const int lk,
+                            const float scale_log2, unsigned long long (&ts)[12], const bool stamp) {
+#pragma unroll 1
+    for (int h = 0; h < XHEADS; ++h) {
+        half8_t t0, t1, t2, t3, t4, t5;
+        const int sg = sg0 + h * XGPH;                // first group of this head in the stream
+        if (TR && stamp && h == 1) ts[3] = __builtin_amdgcn_s_memtime();    // head 1 is stamped phase by phase (head 0 carries the cold start)
+        // Q_h^T [64 ch][32 tokens] = Wq_h . Xn^T
+        float16_t q0, q1;
+        {
+            const unsigned st = group_sync(sg);
+            const int j = 0;
+            asm volatile(XG_WQ_FIRST : [q0] "=&v"(q0), [q1] "=&v"(q1), XTMP_OUT
+                         : [st] "v"(st), [b0] "v"(xn[16 * j + 0]), [b1] "v"(xn[16 * j + 1]), [b2] "v"(xn[16 * j + 2]), [b3] "v"(xn[16 * j + 3]),
+                           [b4] "v"(xn[16 * j + 4]), [b5] "v"(xn[16 * j + 5]), [b6] "v"(xn[16 * j + 6]), [b7] "v"(xn[16 * j + 7]),
+                           [b8] "v"(xn[16 * j + 8]), [b9] "v"(xn[16 * j + 9]), [b10] "v"(xn[16 * j + 10]), [b11] "v"(xn[16 * j + 11]),
+                           [b12] "v"(xn[16 * j + 12]), [b13] "v"(xn[16 * j + 13]), [b14] "v"(xn[16 * j + 14]), [b15] "v"(xn[16 * j + 15]), XDMA_IN
+                         : "memory", "scc");
+        }
+        {
+            const int j = 1;
+            const unsigned st = group_sync(sg + j);
+            asm volatile(XG_WQ : [q0] "+v"(q0), [q1] "+v"(q1), XTMP_OUT
+                         : [st] "v"(st), [b0] "v"(xn[16 * j + 0]), [b1] "v"(xn[16 * j + 1]), [b2] "v"(xn[16 * j + 2]), [b3] "v"(xn[16 * j + 3]),
+                           [b4] "v"(xn[16 * j + 4]), [b5] "v"(xn[16 * j + 5]), [b6] "v"(xn[16 * j + 6]), [b7] "v"(xn[16 * j + 7]),
+                           [b8] "v"(xn[16 * j + 8]), [b9] "v"(xn[16 * j + 9]), [b10] "v"(xn[16 * j + 10]), [b11] "v"(xn[16 * j + 11]),
+                           [b12] "v"(xn[16 * j + 12]), [b13] "v"(xn[16 * j + 13]), [b14] "v"(xn[16 * j + 14]), [b15] "v"(xn[16 * j + 15]), XDMA_IN
+                         : "memory", "scc");
+        }
+        if (TR && stamp && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[4] = __builtin_amdgcn_s_memtime(); }     // Q GEMM (64 MFMA)
+        half8_t qf[4];                                      // Q rounded to fp16 like the stored q of the unfused chain
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { qf[0][e] = (half_t)q0[e]; qf[1][e] = (half_t)q0[8 + e]; qf[2][e] = (half_t)q1[e]; qf[3][e] = (half_t)q1[8 + e]; }
+        // S^T [96 keys][32 tokens] = K_h . Q^T
+        float16_t sacc[3];
+        const unsigned stkv = group_sync(sg + 2);
+        asm volatile(XG_K : [c0] "=&v"(sacc[0]), [c1] "=&v"(sacc[1]), [c2] "=&v"(sacc[2]), XTMP_OUT
+                     : [st] "v"(stkv), [b0] "v"(qf[0]), [b1] "v"(qf[1]), [b2] "v"(qf[2]), [b3] "v"(qf[3]), XDMA_IN : "memory", "scc");
+        if (TR && stamp && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[5] = __builtin_amdgcn_s_memtime(); }     // S = K Q (12 MFMA)
+        // softmax over the keys: this lane holds keys 32 t + (r & 3) + 8 (r >> 2) + 4 hi, lane ^ 32 the others
+        float mx = -INFINITY;
+        int lk_ = lk;
+        asm volatile("" : "+s"(lk_));                        // (re-read per head: hipcc otherwise hoists 48 key compares out of both head loops and
+                                                            //  pays for their 96 mask registers with spills)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            if (32 * (t + 1) <= lk_) {                      // wave-uniform: a key tile without padding needs no mask
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float s = sacc[t][r] * scale_log2; sacc[t][r] = s; mx = fmaxf(mx, s); }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    float s = sacc[t][r] * scale_log2;
+                    s = key < lk_ ? s : -INFINITY;
+                    sacc[t][r] = s; mx = fmaxf(mx, s);
+                }
+            }
+        }
+        mx = fmaxf(mx, swap32(mx));
+        float ps = 0.f;
+        half8_t pf[6];                                      // P^T B fragments: k-step 2 t + (r >> 3)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __builtin_amdgcn_exp2f(sacc[t][r] - mx);
+                ps += e;
+                pf[2 * t + (r >> 3)][r & 7] = (half_t)e;
+            }
+            __builtin_amdgcn_sched_barrier(0);              // one key tile at a time: hipcc otherwise keeps all 48 exponentials in fp32 beside S and P
+        }
+        ps += swap32(ps);
+        const float inv = 1.0f / ps;
+        if (TR && stamp && h == 1) ts[6] = __builtin_amdgcn_s_memtime();                                                          // softmax
+        // O^T [64 ch][32 tokens] = V_h^T . P^T (same LDS slot, fragments 12 .. 23)
+        float16_t o0, o1;
+        asm volatile(XG_V : [c0] "=&v"(o0), [c1] "=&v"(o1), XTMP_OUT
+                     : [st] "v"(stkv), [b0] "v"(pf[0]), [b1] "v"(pf[1]), [b2] "v"(pf[2]), [b3] "v"(pf[3]), [b4] "v"(pf[4]), [b5] "v"(pf[5]), XDMA_IN
+                     : "memory", "scc");
+        if (TR && stamp && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[7] = __builtin_amdgcn_s_memtime(); }     // O = V P (12 MFMA)
+        half8_t of[4];                                      // O / l rounded to fp16 like the stored attention output
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            of[0][e] = (half_t)(o0[e] * inv); of[1][e] = (half_t)(o0[8 + e] * inv);
+            of[2][e] = (half_t)(o1[e] * inv); of[3][e] = (half_t)(o1[8 + e] * inv);
+        }
+        // acc [512 ch][32 tokens] += Wout[:, head h] . O^T (named accumulators: tiles 0 .. 7, then 8 .. 15)
+        {
+            const unsigned st = group_sync(sg + 3);
+            asm volatile(XG_WO0 : XTMP_OUT : [st] "v"(st), [b0] "v"(of[0]), [b1] "v"(of[1]), [b2] "v"(of[2]), [b3] "v"(of[3]), XDMA_IN
+                         : "memory", "scc", XACC_CLOBBERS);
+        }
+        {
+            const unsigned st = group_sync(sg + 4);
+            asm volatile(XG_WO1 : XTMP_OUT : [st] "v"(st), [b0] "v"(of[0]), [b1] "v"(of[1]), [b2] "v"(of[2]), [b3] "v"(of[3]), XDMA_IN
+                         : "memory", "scc", XACC_CLOBBERS);
+        }
+        if (TR && stamp && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[8] = __builtin_amdgcn_s_memtime(); }     // acc += Wout O (64 MFMA)
+    }
+}
+
+// ---- LayerNorm of the NEXT sub-layer on the rows the accumulators hold (ltab: LDS address of its gamma | beta | bias tables) -------------
+UAV_DEVINL void mid_layernorm(half8_t (&xn)[32], const unsigned ltab, const float eps, const int hi) {
+        // ---- the NEXT sub-layer of the block on the same tile: its input is what the accumulators hold (the first sub-layer's output —
+        // fp32, exactly the rows the four-launch chain would have written and read back), so its LayerNorm runs on them in place: two
+        // passes like layernorm_kernel, new operand fragments over the old, + its output bias.  One prologue and one epilogue for two
+        // sub-layers, and the stream between them never touches HBM. -----------------------------------------------------------------
+        asm volatile("s_nop 15\ns_nop 15" ::: "memory");    // the last MFMAs of the head loop may still be in flight and the compiler cannot see them
+        float sm = 0.f;
+        static_for<256>([&](auto N) { sm += acc_get<N>(); });
+        sm += swap32(sm);
+        const float mean2 = sm * (1.0f / XC);
+        float sq = 0.f;
+        static_for<256>([&](auto N) { const float d = acc_get<N>() - mean2; sq += d * d; });
+        sq += swap32(sq);
+        const float rstd2 = rsqrtf(sq * (1.0f / XC) + eps);
+        static_for<16>([&](auto J) {
+            constexpr int j = J;
+            static_for<4>([&](auto Q) {
+                constexpr int q = Q;
+                const unsigned ta = ltab + (32 * j + 8 * q + 4 * hi) * 4;
+                const float4_t g = lds_f4(ta), be = lds_f4(ta + 2048), bo = lds_f4(ta + 4096);
+                static_for<4>([&](auto I) {
+                    constexpr int i = I;
+                    const float v = acc_get<16 * j + 4 * q + i>();
+                    xn[2 * j + (q >> 1)][4 * (q & 1) + i] = (half_t)((v - mean2) * rstd2 * g[i] + be[i]);
+                    acc_set<16 * j + 4 * q + i>(v + bo[i]);
+                });
+            });
+        });
+}
+
 // TR = 1: development instance that stamps s_memtime at the phase boundaries (tools/trace_xattn.py); the product is TR = 0
 template <int TR>
 __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
@@ -238,9 +375,8 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
     // groups follow the first's without a gap (the ring never drains between the two) ---------------------------------------------
     const unsigned voff = (unsigned)(wave * XPPW * XFRAG + lane * 16);
     const int ngroups = __builtin_amdgcn_readfirstlane(p.nsub * XNG);
-    struct Next { uint4_t srd; unsigned so, ldsn; };       // the group XRING - 1 = 3 ahead: its source and its ring slot
-    auto next_of = [&](int s) -> Next {                    // s: group index over all sub-layers; inside one: head s / 5, group j = s % 5 (0, 1: W_q; 2: K | V; 3, 4: W_out)
-        Next n;
+    auto next_of = [&](int s) -> XNext {                    // s: group index over all sub-layers; inside one: head s / 5, group j = s % 5 (0, 1: W_q; 2: K | V; 3, 4: W_out)
+        XNext n;
         n.ldsn = lds0 + (unsigned)((s & (XRING - 1)) * XGROUP + wave * XPPW * XFRAG);
         const int u = s >= XNG ? 1 : 0, r = s - u * XNG;
         const int h = r / XGPH, j = r - h * XGPH;
@@ -254,14 +390,14 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
         return n;
     };
     auto issue = [&](int s) {                              // prologue: a whole group at once
-        Next n = next_of(s);
+        XNext n = next_of(s);
 #pragma unroll
         for (int i = 0; i < XPPW; ++i) dma_piece(n.srd, voff, n.so + i * XFRAG, n.ldsn + i * XFRAG);
     };
     // before group s is read: this wave's pieces of it have landed (the two groups issued behind it may still fly: 16 pieces),
     // then every wave's have (barrier) — which also says every wave is done with the group before it, whose slot the group three
     // ahead is written into WHILE this group is multiplied (the pieces sit between the MFMAs of the asm walk).
-    Next nx;
+    XNext nx;
     auto group_sync = [&](int s) -> unsigned {
         wait_vmcnt<XPPW * (XRING - 2)>();
         __syncthreads();
@@ -328,142 +464,12 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
         if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);            // batches of 16 loads: the operand registers fill up as the rows turn into them
     });
 
-    auto mid_layernorm = [&]() {
-        // ---- the NEXT sub-layer of the block on the same tile: its input is what the accumulators hold (the first sub-layer's output —
-        // fp32, exactly the rows the four-launch chain would have written and read back), so its LayerNorm runs on them in place: two
-        // passes like layernorm_kernel, new operand fragments over the old, + its output bias.  One prologue and one epilogue for two
-        // sub-layers, and the stream between them never touches HBM. -----------------------------------------------------------------
-        asm volatile("s_nop 15\ns_nop 15" ::: "memory");    // the last MFMAs of the head loop may still be in flight and the compiler cannot see them
-        float sm = 0.f;
-        static_for<256>([&](auto N) { sm += acc_get<N>(); });
-        sm += swap32(sm);
-        const float mean2 = sm * (1.0f / XC);
-        float sq = 0.f;
-        static_for<256>([&](auto N) { const float d = acc_get<N>() - mean2; sq += d * d; });
-        sq += swap32(sq);
-        const float rstd2 = rsqrtf(sq * (1.0f / XC) + p.sub[1].eps);
-        static_for<16>([&](auto J) {
-            constexpr int j = J;
-            static_for<4>([&](auto Q) {
-                constexpr int q = Q;
-                const unsigned ta = lds0 + XTAB + XTABS + (32 * j + 8 * q + 4 * hi) * 4;
-                const float4_t g = lds_f4(ta), be = lds_f4(ta + 2048), bo = lds_f4(ta + 4096);
-                static_for<4>([&](auto I) {
-                    constexpr int i = I;
-                    const float v = acc_get<16 * j + 4 * q + i>();
-                    xn[2 * j + (q >> 1)][4 * (q & 1) + i] = (half_t)((v - mean2) * rstd2 * g[i] + be[i]);
-                    acc_set<16 * j + 4 * q + i>(v + bo[i]);
-                });
-            });
-        });
-    };
-    auto run_heads = [&](const int sub) {
-    // ---- heads ----------------------------------------------------------------------------------------------------------------
-#pragma unroll 1
-    for (int h = 0; h < XHEADS; ++h) {
-        half8_t t0, t1, t2, t3, t4, t5;
-        const int sg = sub * XNG + h * XGPH;                // first group of this head in the stream
-        if (TR && sub == 0 && h == 1) ts[3] = __builtin_amdgcn_s_memtime();    // head 1 is stamped phase by phase (head 0 carries the cold start)
-        // Q_h^T [64 ch][32 tokens] = Wq_h . Xn^T
-        float16_t q0, q1;
-        {
-            const unsigned st = group_sync(sg);
-            const int j = 0;
-            asm volatile(XG_WQ_FIRST : [q0] "=&v"(q0), [q1] "=&v"(q1), XTMP_OUT
-                         : [st] "v"(st), [b0] "v"(xn[16 * j + 0]), [b1] "v"(xn[16 * j + 1]), [b2] "v"(xn[16 * j + 2]), [b3] "v"(xn[16 * j + 3]),
-                           [b4] "v"(xn[16 * j + 4]), [b5] "v"(xn[16 * j + 5]), [b6] "v"(xn[16 * j + 6]), [b7] "v"(xn[16 * j + 7]),
-                           [b8] "v"(xn[16 * j + 8]), [b9] "v"(xn[16 * j + 9]), [b10] "v"(xn[16 * j + 10]), [b11] "v"(xn[16 * j + 11]),
-                           [b12] "v"(xn[16 * j + 12]), [b13] "v"(xn[16 * j + 13]), [b14] "v"(xn[16 * j + 14]), [b15] "v"(xn[16 * j + 15]), XDMA_IN
-                         : "memory", "scc");
-        }
-        {
-            const int j = 1;
-            const unsigned st = group_sync(sg + j);
-            asm volatile(XG_WQ : [q0] "+v"(q0), [q1] "+v"(q1), XTMP_OUT
-                         : [st] "v"(st), [b0] "v"(xn[16 * j + 0]), [b1] "v"(xn[16 * j + 1]), [b2] "v"(xn[16 * j + 2]), [b3] "v"(xn[16 * j + 3]),
-                           [b4] "v"(xn[16 * j + 4]), [b5] "v"(xn[16 * j + 5]), [b6] "v"(xn[16 * j + 6]), [b7] "v"(xn[16 * j + 7]),
-                           [b8] "v"(xn[16 * j + 8]), [b9] "v"(xn[16 * j + 9]), [b10] "v"(xn[16 * j + 10]), [b11] "v"(xn[16 * j + 11]),
-                           [b12] "v"(xn[16 * j + 12]), [b13] "v"(xn[16 * j + 13]), [b14] "v"(xn[16 * j + 14]), [b15] "v"(xn[16 * j + 15]), XDMA_IN
-                         : "memory", "scc");
-        }
-        if (TR && sub == 0 && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[4] = __builtin_amdgcn_s_memtime(); }     // Q GEMM (64 MFMA)
-        half8_t qf[4];                                      // Q rounded to fp16 like the stored q of the unfused chain
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { qf[0][e] = (half_t)q0[e]; qf[1][e] = (half_t)q0[8 + e]; qf[2][e] = (half_t)q1[e]; qf[3][e] = (half_t)q1[8 + e]; }
-        // S^T [96 keys][32 tokens] = K_h . Q^T
-        float16_t sacc[3];
-        const unsigned stkv = group_sync(sg + 2);
-        asm volatile(XG_K : [c0] "=&v"(sacc[0]), [c1] "=&v"(sacc[1]), [c2] "=&v"(sacc[2]), XTMP_OUT
-                     : [st] "v"(stkv), [b0] "v"(qf[0]), [b1] "v"(qf[1]), [b2] "v"(qf[2]), [b3] "v"(qf[3]), XDMA_IN : "memory", "scc");
-        if (TR && sub == 0 && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[5] = __builtin_amdgcn_s_memtime(); }     // S = K Q (12 MFMA)
-        // softmax over the keys: this lane holds keys 32 t + (r & 3) + 8 (r >> 2) + 4 hi, lane ^ 32 the others
-        float mx = -INFINITY;
-        int lk_ = p.lk;
-        asm volatile("" : "+s"(lk_));                        // (re-read per head: hipcc otherwise hoists 48 key compares out of both head loops and
-                                                            //  pays for their 96 mask registers with spills)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            if (32 * (t + 1) <= lk_) {                      // wave-uniform: a key tile without padding needs no mask
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { const float s = sacc[t][r] * p.scale_log2; sacc[t][r] = s; mx = fmaxf(mx, s); }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    float s = sacc[t][r] * p.scale_log2;
-                    s = key < lk_ ? s : -INFINITY;
-                    sacc[t][r] = s; mx = fmaxf(mx, s);
-                }
-            }
-        }
-        mx = fmaxf(mx, swap32(mx));
-        float ps = 0.f;
-        half8_t pf[6];                                      // P^T B fragments: k-step 2 t + (r >> 3)
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(sacc[t][r] - mx);
-                ps += e;
-                pf[2 * t + (r >> 3)][r & 7] = (half_t)e;
-            }
-            __builtin_amdgcn_sched_barrier(0);              // one key tile at a time: hipcc otherwise keeps all 48 exponentials in fp32 beside S and P
-        }
-        ps += swap32(ps);
-        const float inv = 1.0f / ps;
-        if (TR && sub == 0 && h == 1) ts[6] = __builtin_amdgcn_s_memtime();                                                          // softmax
-        // O^T [64 ch][32 tokens] = V_h^T . P^T (same LDS slot, fragments 12 .. 23)
-        float16_t o0, o1;
-        asm volatile(XG_V : [c0] "=&v"(o0), [c1] "=&v"(o1), XTMP_OUT
-                     : [st] "v"(stkv), [b0] "v"(pf[0]), [b1] "v"(pf[1]), [b2] "v"(pf[2]), [b3] "v"(pf[3]), [b4] "v"(pf[4]), [b5] "v"(pf[5]), XDMA_IN
-                     : "memory", "scc");
-        if (TR && sub == 0 && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[7] = __builtin_amdgcn_s_memtime(); }     // O = V P (12 MFMA)
-        half8_t of[4];                                      // O / l rounded to fp16 like the stored attention output
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            of[0][e] = (half_t)(o0[e] * inv); of[1][e] = (half_t)(o0[8 + e] * inv);
-            of[2][e] = (half_t)(o1[e] * inv); of[3][e] = (half_t)(o1[8 + e] * inv);
-        }
-        // acc [512 ch][32 tokens] += Wout[:, head h] . O^T (named accumulators: tiles 0 .. 7, then 8 .. 15)
-        {
-            const unsigned st = group_sync(sg + 3);
-            asm volatile(XG_WO0 : XTMP_OUT : [st] "v"(st), [b0] "v"(of[0]), [b1] "v"(of[1]), [b2] "v"(of[2]), [b3] "v"(of[3]), XDMA_IN
-                         : "memory", "scc", XACC_CLOBBERS);
-        }
-        {
-            const unsigned st = group_sync(sg + 4);
-            asm volatile(XG_WO1 : XTMP_OUT : [st] "v"(st), [b0] "v"(of[0]), [b1] "v"(of[1]), [b2] "v"(of[2]), [b3] "v"(of[3]), XDMA_IN
-                         : "memory", "scc", XACC_CLOBBERS);
-        }
-        if (TR && sub == 0 && h == 1) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[8] = __builtin_amdgcn_s_memtime(); }     // acc += Wout O (64 MFMA)
-    }
-    };
     // straight-line over the (at most two) sub-layers: a rolled loop carries the accumulators through a phi between the asm walks
     // (accumulator file) and the LayerNorm in between (VALU), which hipcc resolves by spilling 1 679 registers per lane
-    run_heads(0);
+    xattn_heads<TR>(0, xn, group_sync, nx, voff, hi, p.lk, p.scale_log2, ts, true);
     if (p.nsub > 1) {
-        mid_layernorm();
-        run_heads(1);
+        mid_layernorm(xn, lds0 + XTAB + XTABS, p.sub[1].eps, hi);
+        xattn_heads<TR>(XNG, xn, group_sync, nx, voff, hi, p.lk, p.scale_log2, ts, false);
     }
     if (TR) { asm volatile("s_nop 15\ns_nop 15" ::: "memory"); ts[9] = __builtin_amdgcn_s_memtime(); }                         // all heads
     asm volatile("s_nop 15\ns_nop 15" ::: "memory");        // the last MFMAs may still be in flight and the compiler cannot see them
@@ -536,7 +542,7 @@ __global__ __launch_bounds__(256, 1) void xattn_sublayer_kernel(XattnArgs p) {
 constexpr int TGPH = 8;                        // groups per head: W_q, W_k, W_v, W_out (2 each)
 constexpr int TNG = XHEADS * TGPH;
 constexpr int TT = 8;                          // frames
-constexpr int TTAB_REL = XTAB + XTABS;         // LDS: relative-position bias [head][tq][hi][m] = bias[head][tq][2 m + hi] (2 KiB)
+constexpr int TTAB_REL = XTAB + 3 * XTABS;     // LDS behind the LayerNorm / bias tables of up to three sub-layers: relative-position bias [head][tq][hi][m] = bias[head][tq][2 m + hi] (2 KiB)
 constexpr int TTAB_COS = TTAB_REL + 2048;      // RoPE cos [t][hi][2 q + pb] = cos[t][4 q + 2 hi + pb] (512 B), then sin
 constexpr int TSMEM = TTAB_COS + 1024;
 
@@ -545,8 +551,14 @@ struct TattnArgs {
     const char* wq; const char* wk; const char* wv; const char* wo;
     const float* relbias; const float* rope_cos; const float* rope_sin;
     int n_batch; long long hw; float scale;
+    XattnSub xs[2]; int lk; float xscale_log2;   // NX = 2: the block's two text cross-attention sub-layers in front (attn1, attn2)
 };
 
+// NX = 0: the temporal sub-layer alone.  NX = 2: attn1 -> attn2 -> attn_temporal of one BasicTransformerBlock (only_cross_attention) in ONE
+// launch on the temporal tiling — a workgroup's 16 pixels x 8 frames lie inside one batch entry, which is all the cross-attention head
+// loop asks of its 32 tokens —: the stream is read once and written once for three sub-layers, the rows between them stay in the
+// accumulators and every LayerNorm but the first runs on them in registers.
+template <int NX>
 __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
@@ -559,23 +571,33 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
     const long long row = rowbase + (long long)(l32 >> 2) * p.hw + (l32 & 3);
 
     const unsigned voff = (unsigned)(wave * XPPW * XFRAG + lane * 16);
-    struct Next { uint4_t srd; unsigned so, ldsn; };
-    auto next_of = [&](int s) -> Next {                    // s = 8 h + j: j 0, 1: W_q; 2, 3: W_k; 4, 5: W_v; 6, 7: W_out
-        Next n;
+    constexpr int SG_T = NX * XNG;                         // first group of the temporal sub-layer in the stream
+    auto next_of = [&](int s) -> XNext {
+        XNext n;
         n.ldsn = lds0 + (unsigned)((s & (XRING - 1)) * XGROUP + wave * XPPW * XFRAG);
-        const int h = s >> 3, j = s & 7;
+        if (NX > 0 && s < SG_T) {                          // a cross-attention sub-layer: head r / 5, group j = r % 5 (0, 1: W_q; 2: K | V; 3, 4: W_out)
+            const int u = s >= XNG ? 1 : 0, r = s - u * XNG;
+            const int h = r / XGPH, j = r - h * XGPH;
+            const XattnSub& S = p.xs[u];
+            if (j < 2) { n.srd = make_srd(S.wq, XHEADS * 2 * XGROUP); n.so = (unsigned)((h * 2 + j) * XGROUP); }
+            else if (j == 2) { n.srd = make_srd(S.kv + (long long)bb * XHEADS * XGROUP, XHEADS * XGROUP); n.so = (unsigned)(h * XGROUP); }
+            else { n.srd = make_srd(S.wo, XHEADS * 2 * XGROUP); n.so = (unsigned)((h * 2 + (j - 3)) * XGROUP); }
+            return n;
+        }
+        const int st = s - SG_T;                           // temporal: st = 8 h + j: j 0, 1: W_q; 2, 3: W_k; 4, 5: W_v; 6, 7: W_out
+        const int h = st >> 3, j = st & 7;
         const char* base = j < 2 ? p.wq : j < 4 ? p.wk : j < 6 ? p.wv : p.wo;
         n.srd = make_srd(base, XHEADS * 2 * XGROUP);
         n.so = (unsigned)((h * 2 + (j & 1)) * XGROUP);
-        if (s >= TNG) n.so = 0x80000000u;                  // zero-fill pieces behind the last group (see the kernel above)
+        if (st >= TNG) n.so = 0x80000000u;                 // zero-fill pieces behind the last group (see the kernel above)
         return n;
     };
     auto issue = [&](int s) {
-        Next n = next_of(s);
+        XNext n = next_of(s);
 #pragma unroll
         for (int i = 0; i < XPPW; ++i) dma_piece(n.srd, voff, n.so + i * XFRAG, n.ldsn + i * XFRAG);
     };
-    Next nx;
+    XNext nx;
     unsigned lane16 = lane * 16;                            // (re-derived from a fresh lane id behind the prologue, see below)
     auto group_sync = [&](int s) -> unsigned {
         wait_vmcnt<XPPW * (XRING - 2)>();
@@ -586,10 +608,18 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
 #pragma unroll
     for (int s = 0; s < XRING - 1; ++s) issue(s);
     // ---- tables -> LDS ----------------------------------------------------------------------------------------------------------
+    constexpr int TT_LN = XTAB + NX * XTABS;                // the temporal sub-layer's gamma | beta | bias behind the cross sub-layers'
     if (tid < 128) {
-        *(lds_f4wptr_t)(size_t)(lds0 + XTAB + tid * 16) = ((const float4_t*)p.gamma)[tid];
-        *(lds_f4wptr_t)(size_t)(lds0 + XTAB + 2048 + tid * 16) = ((const float4_t*)p.beta)[tid];
-        *(lds_f4wptr_t)(size_t)(lds0 + XTAB + 4096 + tid * 16) = ((const float4_t*)p.bias)[tid];
+#pragma unroll
+        for (int u = 0; u < NX; ++u) {
+            const unsigned tb = lds0 + XTAB + u * XTABS + tid * 16;
+            *(lds_f4wptr_t)(size_t)tb = ((const float4_t*)p.xs[u].gamma)[tid];
+            *(lds_f4wptr_t)(size_t)(tb + 2048) = ((const float4_t*)p.xs[u].beta)[tid];
+            *(lds_f4wptr_t)(size_t)(tb + 4096) = ((const float4_t*)p.xs[u].bias)[tid];
+        }
+        *(lds_f4wptr_t)(size_t)(lds0 + TT_LN + tid * 16) = ((const float4_t*)p.gamma)[tid];
+        *(lds_f4wptr_t)(size_t)(lds0 + TT_LN + 2048 + tid * 16) = ((const float4_t*)p.beta)[tid];
+        *(lds_f4wptr_t)(size_t)(lds0 + TT_LN + 4096 + tid * 16) = ((const float4_t*)p.bias)[tid];
     } else {
         typedef __attribute__((address_space(3))) float* lds_fptr_t;
         const int u = tid - 128;                            // 128 threads: 512 bias entries (4 each), 128 cos + 128 sin (1 + 1 each)
@@ -625,7 +655,7 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
     s1 += swap32(s1); s2 += swap32(s2);
     const float m1 = s1 * (1.0f / XC);
     const float mean = c0 + m1;
-    const float rstd = rsqrtf(fmaxf(s2 * (1.0f / XC) - m1 * m1, 0.f) + p.eps);
+    const float rstd = rsqrtf(fmaxf(s2 * (1.0f / XC) - m1 * m1, 0.f) + (NX > 0 ? p.xs[0].eps : p.eps));      // (the tables at XTAB are the first sub-layer's)
     __syncthreads();                                        // tables visible
     half8_t xn[32];
     static_for<16>([&](auto J) {
@@ -644,16 +674,17 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
         if (j & 1) __builtin_amdgcn_sched_barrier(0);       // batches of 8 loads (this prologue carries the row arithmetic of the frame-strided tile on top)
     });
 
+    auto temporal_heads = [&](half8_t (&xn)[32]) {
     // (the lane's pixel / frame from a fresh lane id: kept live from the row computation at the top they were spilled across the prologue)
     int lane2;
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\nv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane2));
-    const int px = lane2 & 3, tq = (lane2 & 31) >> 2;
+    const int px = lane2 & 3, tq = (lane2 & 31) >> 2, hi = lane2 >> 5;
     lane16 = (unsigned)lane2 * 16;
     // ---- heads ------------------------------------------------------------------------------------------------------------------
 #pragma unroll 1
     for (int h = 0; h < XHEADS; ++h) {
         half8_t t0, t1, t2, t3, t4, t5;
-        const int sg = h * TGPH;
+        const int sg = SG_T + h * TGPH;
         const unsigned tc = lds0 + TTAB_COS + ((tq * 2 + hi) * 8) * 4;
         // RoPE on the lane's first 32 head channels (tile 0: registers r <-> channel (r & 3) + 8 (r >> 2) + 4 hi; pairs (4 q, 4 q + 1),
         // (4 q + 2, 4 q + 3) of the registers are channel pairs (2 i, 2 i + 1), angle index 4 q + 2 hi + pb)
@@ -792,6 +823,20 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
                          : "memory", "scc", XACC_CLOBBERS);
         }
     }
+    };
+    if constexpr (NX > 0) {
+        // ---- attn1, attn2 (text cross-attention) on the same tile, then the temporal sub-layer's LayerNorm on their output ---------------
+        unsigned long long ts_[12];
+        xattn_heads<0>(0, xn, group_sync, nx, voff, hi, p.lk, p.xscale_log2, ts_, false);
+        mid_layernorm(xn, lds0 + XTAB + XTABS, p.xs[1].eps, hi);
+        xattn_heads<0>(XNG, xn, group_sync, nx, voff, hi, p.lk, p.xscale_log2, ts_, false);
+        // (a second fragment array: hipcc gives the temporal loop's fragments other registers than the cross loops', and moving one set
+        //  onto the other through the full register file went through scratch — 33 spilled fragments)
+        half8_t xt[32];
+        mid_layernorm(xt, lds0 + TT_LN, p.eps, hi);
+        temporal_heads(xt);
+    }
+    if constexpr (NX == 0) temporal_heads(xn);
     asm volatile("s_nop 15\ns_nop 15" ::: "memory");
     wait_vmcnt<0>();
     __syncthreads();
@@ -896,20 +941,48 @@ extern "C" int uav_xattn_sublayers_f32(const float* x, float* out, const uav_xat
     return uav_launch_status();
 }
 
-extern "C" int uav_tattn_sublayer_f32(const float* x, float* out, const uav_tattn_params* q, int32_t n_batch, int32_t t_len, int64_t hw,
-                                      int32_t channels, int32_t heads, float scale, void* stream) {
+namespace {
+int tattn_launch(const float* x, float* out, const uav_xattn_params* xs, int32_t n_xs, int32_t lk, float xscale, const uav_tattn_params* q,
+                 int32_t n_batch, int32_t t_len, int64_t hw, int32_t channels, int32_t heads, float scale, void* stream) {
     if (!x || !out || !q || !q->ln_gamma || !q->ln_beta || !q->wq_packed || !q->wk_packed || !q->wv_packed || !q->wo_packed || !q->out_bias ||
         !q->rel_bias || !q->rope_cos || !q->rope_sin)
         return UAV_EINVAL;
     if (channels != XC || heads != XHEADS || t_len != TT || q->rot_dim != 32) return UAV_ESHAPE;
     if (n_batch <= 0 || hw <= 0 || (hw % 16) || (long long)n_batch * (hw / 16) >= (1ll << 31)) return UAV_ESHAPE;
+    if (n_xs != 0 && n_xs != 2) return UAV_ESHAPE;
+    if (n_xs && (!xs || lk <= 0 || lk > 96)) return UAV_ESHAPE;
     if (((size_t)x | (size_t)out) & 15) return UAV_EALIGN;
-    static UavDynLds lds;
-    if (int rc = uav_set_dyn_lds(lds, (const void*)tattn_sublayer_kernel, TSMEM)) return rc;
     TattnArgs a{x, out, q->ln_gamma, q->ln_beta, q->out_bias, q->ln_eps, (const char*)q->wq_packed, (const char*)q->wk_packed,
-                (const char*)q->wv_packed, (const char*)q->wo_packed, q->rel_bias, q->rope_cos, q->rope_sin, n_batch, (long long)hw, scale};
-    hipLaunchKernelGGL(tattn_sublayer_kernel, dim3((unsigned)(n_batch * (hw / 16))), dim3(256), TSMEM, (hipStream_t)stream, a);
+                (const char*)q->wv_packed, (const char*)q->wo_packed, q->rel_bias, q->rope_cos, q->rope_sin, n_batch, (long long)hw, scale,
+                {}, lk, xscale * 1.44269504088896341f};
+    for (int i = 0; i < n_xs; ++i) {
+        const uav_xattn_params& c = xs[i];
+        if (!c.ln_gamma || !c.ln_beta || !c.wq_packed || !c.kv_packed || !c.wo_packed || !c.out_bias) return UAV_EINVAL;
+        a.xs[i] = XattnSub{c.ln_gamma, c.ln_beta, c.out_bias, (const char*)c.wq_packed, (const char*)c.kv_packed, (const char*)c.wo_packed, c.ln_eps};
+    }
+    const dim3 grid((unsigned)(n_batch * (hw / 16)));
+    if (n_xs) {
+        static UavDynLds lds2;
+        if (int rc = uav_set_dyn_lds(lds2, (const void*)tattn_sublayer_kernel<2>, TSMEM)) return rc;
+        hipLaunchKernelGGL(tattn_sublayer_kernel<2>, grid, dim3(256), TSMEM, (hipStream_t)stream, a);
+    } else {
+        static UavDynLds lds0;
+        if (int rc = uav_set_dyn_lds(lds0, (const void*)tattn_sublayer_kernel<0>, TSMEM)) return rc;
+        hipLaunchKernelGGL(tattn_sublayer_kernel<0>, grid, dim3(256), TSMEM, (hipStream_t)stream, a);
+    }
     return uav_launch_status();
+}
+}  // namespace
+
+extern "C" int uav_tattn_sublayer_f32(const float* x, float* out, const uav_tattn_params* q, int32_t n_batch, int32_t t_len, int64_t hw,
+                                      int32_t channels, int32_t heads, float scale, void* stream) {
+    return tattn_launch(x, out, nullptr, 0, 0, 0.f, q, n_batch, t_len, hw, channels, heads, scale, stream);
+}
+
+extern "C" int uav_block_attn_sublayers_f32(const float* x, float* out, const uav_xattn_params* cross, int32_t lk, float cross_scale,
+                                            const uav_tattn_params* temporal, int32_t n_batch, int32_t t_len, int64_t hw, int32_t channels,
+                                            int32_t heads, float temporal_scale, void* stream) {
+    return tattn_launch(x, out, cross, 2, lk, cross_scale, temporal, n_batch, t_len, hw, channels, heads, temporal_scale, stream);
 }
 
 #ifdef UAV_DEV_KERNELS

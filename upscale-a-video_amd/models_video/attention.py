@@ -168,19 +168,28 @@ class TemporalAttention(CrossAttention):
         return self._cache().get(("ttab", t_len), build, (self.time_rel_pos_bias.relative_attention_bias.weight,
                                                           None if self.rotary_emb is None else self.rotary_emb.freqs))
 
+    def fused_temporal_params(self, x, ln, g: E.Geom):
+        """(gamma, beta, eps, W_q, W_k, W_v, W_out packed, bias, rel-pos bias, RoPE cos, sin, rot_dim) for the fused temporal sub-layer kernel
+        (ops.tattn_sublayer / ops.block_attn_sublayers), or None where it does not apply (fp32 stream of 512 channels / 8 heads, T = 8,
+        rot_dim 32, whole 16-pixel tiles)."""
+        bias, cos, sin, rot = self._tables(g.t)
+        if (ln is None or not E.TATTN_FUSED or E.LN_FOLD or self.to_q.bias is not None or self.to_out[0].bias is None or cos is None
+                or not ops.tattn_ok(x, heads=self.heads, head_dim=self.dim_head, t_len=g.t, hw=g.hw, rot_dim=rot)):
+            return None
+        dev = E._dev(self.to_q.weight)
+        pk = lambda name, lin, kind: self._cache().get(("tattn", name), lambda: ops.pack_xattn_weight(lin.weight, kind, dev), (lin.weight,))
+        return (E.f32_param(self, "tattn.g", ln.weight), E.f32_param(self, "tattn.b", ln.bias), ln.eps,
+                pk("q", self.to_q, "q"), pk("k", self.to_k, "q"), pk("v", self.to_v, "q"), pk("o", self.to_out[0], "out"),
+                E.f32_param(self, "tattn.ob", self.to_out[0].bias), bias, cos, sin, rot)
+
     def run_temporal(self, x, residual, g: E.Geom, ln=None):
         c = self.heads * self.dim_head
         bias, cos, sin, rot = self._tables(g.t)
-        if (ln is not None and residual is x and E.TATTN_FUSED and not E.LN_FOLD and self.to_q.bias is None and self.to_out[0].bias is not None
-                and cos is not None and ops.tattn_ok(x, heads=self.heads, head_dim=self.dim_head, t_len=g.t, hw=g.hw, rot_dim=rot)):
+        tp = self.fused_temporal_params(x, ln, g) if residual is x else None
+        if tp is not None:
             # the whole sub-layer in one launch (csrc/xattn_fused.hip, tattn_sublayer_kernel): LayerNorm -> q | k | v -> RoPE + bias + per-pixel
             # softmax over the frames -> to_out -> + residual, the fp32 stream read once and written once
-            dev = E._dev(self.to_q.weight)
-            pk = lambda name, lin, kind: self._cache().get(("tattn", name), lambda: ops.pack_xattn_weight(lin.weight, kind, dev), (lin.weight,))
-            return ops.tattn_sublayer(x, E.f32_param(self, "tattn.g", ln.weight), E.f32_param(self, "tattn.b", ln.bias), ln.eps,
-                                      pk("q", self.to_q, "q"), pk("k", self.to_k, "q"), pk("v", self.to_v, "q"), pk("o", self.to_out[0], "out"),
-                                      E.f32_param(self, "tattn.ob", self.to_out[0].bias), bias, cos, sin,
-                                      n_batch=g.b, t_len=g.t, hw=g.hw, rot_dim=rot, scale=self.scale)
+            return ops.tattn_sublayer(x, *tp[:11], n_batch=g.b, t_len=g.t, hw=g.hw, rot_dim=tp[11], scale=self.scale)
         qkv = ops.linear(x, E.packed_cat(self, "qkv", [self.to_q, self.to_k, self.to_v])) if ln is None else \
             E.ln_linear(self, "qkv", ln, x, [self.to_q, self.to_k, self.to_v])
         o = ops.temporal_attention(qkv, n_batch=g.b, t_len=g.t, hw=g.hw, c=c, heads=self.heads, scale=self.scale,
@@ -276,6 +285,14 @@ class BasicTransformerBlock(E.EngineModule):
             s2 = self.attn2.fused_params(x, self.norm2, t2, rows_per_kv=g.t * lq) if s1 is not None else None
             if s2 is not None and self.attn1.scale == self.attn2.scale:
                 pair = (s1, s2)
+        if pair is not None and E.BLOCK_ATTN_FUSED:
+            # ... and the temporal sub-layer behind them in the same launch (tattn_sublayer_kernel<2>): x is read once and written once for
+            # the three attention sub-layers of the block
+            tp = self.attn_temporal.fused_temporal_params(x, self.norm_temporal, g)
+            if tp is not None:
+                x = ops.block_attn_sublayers(x, list(pair), tp, n_batch=g.b, t_len=g.t, hw=g.hw, lk=n_text, cross_scale=self.attn1.scale,
+                                             temporal_scale=self.attn_temporal.scale)
+                return self.ff.run(x, x, out_f32, ln=self.norm3, out_hilo=out_hilo)
         if pair is not None:
             x = ops.xattn_sublayers(x, list(pair), rows_per_kv=g.t * lq, lk=n_text, scale=self.attn1.scale)
         else:

@@ -105,7 +105,8 @@ def audit_accumulator_file():
     compiler-generated instruction of the kernel names an AGPR."""
     _audit_named_accumulators("attention.hip", "attn512w_kernel")
     _audit_named_accumulators("xattn_fused.hip", "xattn_sublayer_kernelILi0E")
-    _audit_named_accumulators("xattn_fused.hip", "tattn_sublayer_kernel")
+    _audit_named_accumulators("xattn_fused.hip", "tattn_sublayer_kernelILi0E")
+    _audit_named_accumulators("xattn_fused.hip", "tattn_sublayer_kernelILi2E")
 
 
 def _audit_named_accumulators(fname, kernel):

@@ -369,6 +369,9 @@ XATTN_PAIR = _os.environ.get("UAV_XATTN_PAIR", "1") != "0"
 # ... and the TEMPORAL attention sub-layer of the same blocks (LayerNorm -> q | k | v -> RoPE + relative-position bias + softmax over the 8
 # frames of a pixel -> to_out -> + residual) as one launch (tattn_sublayer_kernel).  UAV_TATTN_FUSED=0 keeps the four-launch chain.
 TATTN_FUSED = _os.environ.get("UAV_TATTN_FUSED", "1") != "0"
+# ... and all three (attn1 -> attn2 -> attn_temporal) as ONE launch where both of the above apply (tattn_sublayer_kernel<2>).
+# UAV_BLOCK_ATTN_FUSED=0 keeps the pair launch + the temporal launch.
+BLOCK_ATTN_FUSED = _os.environ.get("UAV_BLOCK_ATTN_FUSED", "1") != "0"
 
 
 def packed_ln_linear(mod: EngineModule, name, ln: nn.LayerNorm, linears, geglu=False):

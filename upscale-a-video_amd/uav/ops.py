@@ -743,6 +743,39 @@ def tattn_sublayer(x, gamma, beta, eps, wq_packed, wk_packed, wv_packed, wo_pack
     return y
 
 
+def _tattn_params(t):
+    gamma, beta, eps, wq_packed, wk_packed, wv_packed, wo_packed, out_bias, rel_bias, rope_cos, rope_sin, rot_dim = t
+    q = _lib.TattnParams()
+    q.ln_gamma, q.ln_beta, q.ln_eps = _p(gamma), _p(beta), float(eps)
+    q.wq_packed, q.wk_packed, q.wv_packed, q.wo_packed, q.out_bias = _p(wq_packed), _p(wk_packed), _p(wv_packed), _p(wo_packed), _p(out_bias)
+    q.rel_bias, q.rope_cos, q.rope_sin, q.rot_dim = _p(rel_bias), _p(rope_cos), _p(rope_sin), int(rot_dim)
+    return q
+
+
+def block_attn_sublayers(x, cross, temporal, *, n_batch, t_len, hw, lk, cross_scale, temporal_scale, out=None):
+    """attn1 -> attn2 -> attn_temporal of one BasicTransformerBlock (only_cross_attention) on fp32 stream rows [B*T*hw][512] in ONE
+    launch: `cross` = two (gamma, beta, eps, wq_packed, kv_packed, wo_packed, out_bias) tuples as for xattn_sublayers, `temporal` =
+    (gamma, beta, eps, wq, wk, wv, wo packed, out_bias, rel_bias, rope_cos, rope_sin, rot_dim) as for tattn_sublayer."""
+    lib = _lib.load()
+    _req(x, torch.float32, "x")
+    if len(cross) != 2:
+        raise _lib.UavError("block_attn_sublayers takes the two cross-attention sub-layers of a block")
+    y = torch.empty_like(x) if out is None else out
+    arr = (_lib.XattnParams * 2)()
+    for i, (gamma, beta, eps, wq_packed, kv_packed, wo_packed, out_bias) in enumerate(cross):
+        arr[i].ln_gamma, arr[i].ln_beta, arr[i].ln_eps = _p(gamma), _p(beta), float(eps)
+        arr[i].wq_packed, arr[i].kv_packed, arr[i].wo_packed, arr[i].out_bias = _p(wq_packed), _p(kv_packed), _p(wo_packed), _p(out_bias)
+    q = _tattn_params(temporal)
+    m = x.shape[0]
+    ev = PROFILER.begin("block_attn_sublayers")
+    rc = lib.uav_block_attn_sublayers_f32(_p(x), _p(y), C.cast(arr, C.c_void_p), lk, cross_scale, C.byref(q), n_batch, t_len, hw, XATTN_C, XATTN_HEADS,
+                                          temporal_scale, _stream())
+    _lib.check(rc, "uav_block_attn_sublayers_f32")
+    PROFILER.end(ev, "block_attn_sublayers" if not PROFILER.detail else f"block_attn_sublayers M={m}",
+                 2.0 * m * (8 * XATTN_C * XATTN_C) + 2 * 4.0 * m * lk * XATTN_C + 4.0 * m * t_len * XATTN_C, 8.0 * m * XATTN_C)
+    return y
+
+
 def temporal_attention(qkv, *, n_batch, t_len, hw, c, heads, scale, rope_cos, rope_sin, rot_dim, bias):
     lib = _lib.load()
     _req(qkv, HALF, "qkv")
