@@ -270,6 +270,12 @@ typedef struct {
     const float* rope_cos;      /* fp32 [t_len][rot_dim / 2] */
     const float* rope_sin;
     int32_t      rot_dim;
+    /* optional (next_ln_out != NULL): the LayerNorm that FOLLOWS the sub-layer in the block (norm3, in front of the feed-forward) applied
+     * to the rows written to `out`, as fp16 operand rows [rows][channels] — saves that LayerNorm launch (attention.py:562-564) */
+    void*        next_ln_out;
+    const float* next_ln_gamma;
+    const float* next_ln_beta;
+    float        next_ln_eps;
 } uav_tattn_params;
 int uav_tattn_sublayer_f32(const float* x, float* out, const uav_tattn_params* p, int32_t n_batch, int32_t t_len, int64_t hw,
                            int32_t channels, int32_t heads, float scale, void* stream);

@@ -251,8 +251,19 @@ def temporal_attention(qkv, *, n_batch, t_len, hw, c, heads, scale, rope_cos, ro
     return _h(o)
 
 
+def _attach_next_ln(y, next_ln):
+    if next_ln is None:
+        return y
+    from uav import ops as _ops
+    gamma, beta, eps = next_ln
+    nl = _ops.NextLn(_h(F.layer_norm(y.float(), (y.shape[-1],), gamma.float(), beta.float(), eps)), gamma, beta, eps)
+    nl.version = y._version
+    y._uav_next_ln = nl
+    return y
+
+
 def tattn_sublayer(x, gamma, beta, eps, wq_packed, wk_packed, wv_packed, wo_packed, out_bias, rel_bias, rope_cos, rope_sin, *,
-                   n_batch, t_len, hw, rot_dim, scale, out=None):
+                   n_batch, t_len, hw, rot_dim, scale, out=None, next_ln=None):
     """Fused temporal sub-layer (csrc/xattn_fused.hip tattn_sublayer_kernel): the chain LayerNorm -> q | k | v -> temporal attention ->
     to_out + residual on the decoded fragment streams."""
     wq, wk, wv = (_unpack_xattn_weight(w, "q") for w in (wq_packed, wk_packed, wv_packed))
@@ -264,17 +275,17 @@ def tattn_sublayer(x, gamma, beta, eps, wq_packed, wk_packed, wv_packed, wo_pack
     y = x.float() + out_bias.float() + o.float() @ wo.t()
     if out is not None:
         out.copy_(y)
-        return out
-    return y
+        return _attach_next_ln(out, next_ln)
+    return _attach_next_ln(y, next_ln)
 
 
-def block_attn_sublayers(x, cross, temporal, *, n_batch, t_len, hw, lk, cross_scale, temporal_scale, out=None):
+def block_attn_sublayers(x, cross, temporal, *, n_batch, t_len, hw, lk, cross_scale, temporal_scale, out=None, next_ln=None):
     y = xattn_sublayers(x, cross, rows_per_kv=t_len * hw, lk=lk, scale=cross_scale)
     y = tattn_sublayer(y, *temporal[:11], n_batch=n_batch, t_len=t_len, hw=hw, rot_dim=temporal[11], scale=temporal_scale)
     if out is not None:
         out.copy_(y)
-        return out
-    return y
+        return _attach_next_ln(out, next_ln)
+    return _attach_next_ln(y, next_ln)
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -1199,3 +1199,33 @@ def test_fused_block_attention_three_sublayers_equal_pair_then_temporal(ops, dev
     assert torch.equal(ops.block_attn_sublayers(x, cross, temporal, **kw), y3)
     xin = x.clone()
     assert ops.block_attn_sublayers(xin, cross, temporal, out=xin, **kw) is xin and torch.equal(xin, y3)
+
+
+def test_fused_sublayer_kernels_emit_the_next_layernorm(ops, dev):
+    """`next_ln`: the temporal / block kernels also write fp16 LayerNorm(y) of the rows they store (the block's norm3, attention.py:562-564), so
+    the feed-forward's LayerNorm launch disappears — against the LayerNorm kernel on the same rows."""
+    g = torch.Generator().manual_seed(4242)
+    C, H, D, T, nb, hh, ww = 512, 8, 64, 8, 2, 16, 16
+    hw = hh * ww
+    M = nb * T * hw
+    x = (torch.randn(M, C, generator=g) * 1.3 + 0.4).to(dev)
+    gamma = (torch.randn(C, generator=g) * 0.2 + 1.0).to(dev); beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+    ws = [h16(C, C, dev=dev, scale=C ** -0.5, gen=g) for _ in range(4)]
+    bo = (torch.randn(C, generator=g) * 0.1).to(dev)
+    relb = (torch.randn(H, T, T, generator=g) * 0.5).to(dev).contiguous()
+    fr = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    ang = torch.arange(T).float()[:, None] * fr[None, :]
+    cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
+    pk = [ops.pack_xattn_weight(w_, "q", dev) for w_ in ws[:3]] + [ops.pack_xattn_weight(ws[3], "out", dev)]
+    g3 = (torch.randn(C, generator=g) * 0.2 + 1.0).to(dev); b3 = (torch.randn(C, generator=g) * 0.1).to(dev)
+    kw = dict(n_batch=nb, t_len=T, hw=hw, rot_dim=32, scale=D ** -0.5)
+    y0 = ops.tattn_sublayer(x, gamma, beta, 1e-5, *pk, bo, relb, cos, sin, **kw)
+    y = ops.tattn_sublayer(x, gamma, beta, 1e-5, *pk, bo, relb, cos, sin, next_ln=(g3, b3, 1e-5), **kw)
+    assert torch.equal(y, y0)                                        # the fp32 rows themselves are unchanged
+    n = ops.next_ln_of(y, g3, b3, 1e-5)
+    assert n is not None and n.dtype == torch.float16 and n.shape == y.shape
+    ref = ops.layernorm(y, g3, b3, 1e-5)
+    assert rel_l2(n, ref) < 1e-4 and (n.float() - ref.float()).abs().max().item() < 4e-3      # same two-pass arithmetic, fp32 summation order apart
+    assert ops.next_ln_of(y, b3, g3, 1e-5) is None and ops.next_ln_of(y, g3, b3, 1e-6) is None   # other parameters: not this LayerNorm
+    y.add_(1.0)
+    assert ops.next_ln_of(y, g3, b3, 1e-5) is None                   # rows changed since: stale

@@ -1,0 +1,57 @@
+"""Round-6 documentation filler: writes the round-6 blocks of DESIGN.md from one table of measured numbers (the placeholders @@ROUND6_*@@
+are replaced in place; run once — kept for the record of where every number in those paragraphs comes from)."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+N = dict(
+    fps_driver="1.2xx", fps_default="1.2xx", ms_clip="6 6xx", two_clips="1.2x", conv_frac="0.37x", conv_tflops="9xx", n_tests="2xx",
+    traffic="1.2xx GB", traffic_ratio="1.3x",
+)
+
+
+def main():
+    N.update(dict(a.split("=", 1) for a in sys.argv[1:]))
+    p = os.path.join(ROOT, "DESIGN.md")
+    s = open(p).read()
+    summary = f"""**Round 6 in one paragraph** (details in §3, §4, §6; rounds 1-5: `profiles/HISTORY.md`).  The round-5 verdict: parity green on the headline by 5 %
+on one metric only, throughput back where round 2 had it (driver: 1.105 → 1.019 → 0.996 → 1.104 frames/s), and what is left is "bytes and idle tile
+phases, not the k-step": the K = 512 linears at 0.21 of the MFMA peak, every transformer sub-layer round-tripping the fp32 stream 3–4 times.  This
+round (i) **closed the parity evidence**: the tiled video-VAE fixture at its own 30-step schedule (`pipe_tiled_full_videovae_30`: 1.12e-3 — outside 1e-3 on
+3-frame 68 × 160 tiles and reported as such), a direct fp32 `F.conv3d` / GEMM reference for every case of the four-wave conv kernel, configs[3] at its
+real length (T = 32, 320×320, 30 steps vs the GPU oracle: latents 7.0e-4, `.images` 8.5e-4; windows on two streams bit-identical to serial), a
+full-width forward at the stated 1e-3 inside `smoke()` (6.2e-4); (ii) **bought the margin**: block tails leave their producer as the hi | lo operand
+pair (`UAV_CONV_OUT_HILO`, written by the row-coalesced epilogue of the four-wave kernel: no cast pass) and that mode is the default — headline
+latents 8.2e-4 → **7.3e-4**, `.images` 9.5e-4 → **8.7e-4** over all pixels / 1.23e-3 → 1.12e-3 unclamped for −1.2 % frames/s, the two headline tests
+now assert 8.0e-4 / 9.2e-4; (iii) built the **fused transformer sub-layer kernels** the verdict named (`csrc/xattn_fused.hip`): LayerNorm → projection(s) →
+attention → `to_out` → + residual in ONE launch that reads and writes the fp32 stream once, lane = token from the first load to the last store —
+text cross-attention (LayerNorm → to_q → 77-key softmax → to_out: 0.87 ms against 1.25 ms for the four launches at M = 409 600), two of them back to
+back (attn1 + attn2 of a block: the second LayerNorm runs on the accumulators, 1.40 ms against 2.44), the temporal sub-layer (q | k | v, RoPE,
+relative-position bias, per-pixel softmax over the 8 frames: 1.14 ms against 1.85), and finally **all three attention sub-layers of a block in one
+launch**; 900 LayerNorm + 900 projection + 750 attention launches per clip disappear and the K ≤ 1 024 linear class loses its worst members; (iv) took
+the HIP events out of the timed region (same-box A/B: +0.63 %; `roofline` and the per-kernel table come from one instrumented clip behind it);
+(v) **pruned the library**: one translation unit per conv kernel family, the legacy / ablation / trace instances behind `-DUAV_DEV_KERNELS` in a side
+library, 115 → 9x kernels, 5.4 → 2.7 MB, build 3 min → 1 min, and a build audit that fails on ANY scratch in a shipped kernel; (vi) measured and
+recorded what lost: the two guidance branches of one clip on two streams (−3.4 %, again).  Serial headline, final tree, the way the driver runs it:
+**{N['fps_driver']} frames/s** ({N['ms_clip']} ms per clip; two clips per GPU {N['two_clips']}), conv **{N['conv_tflops']} TFLOP/s = {N['conv_frac']}** of the dense
+peak, {N['n_tests']} GPU tests + smoke green.
+"""
+    s = s.replace("@@ROUND6_SUMMARY@@", summary)
+    ledger = f"""### Round 6 — measurements in the order they were taken (one `gpurun` call each, `tools/run.sh`; boxes differ by ±3 %)
+
+| run | what | result |
+|---|---|---|
+| 1 | first version of the fused cross-attention sub-layer kernel (weights as LDS-DMA bursts behind each barrier), full suite, `--overlap-split-cfg` (`r06_xattn_fused_vs_four_launch_chain_run1_first_version.jsonl`, `r06_bench1_run1_*.json`, `r06_bench1_cfg_branches_on_two_streams_run1.json`) | every kernel test green on the first run; 0.98 ms against 1.27 ms (chain) at M = 409 600, 0.31 / 0.37 at 102 400; clip 1.103 → **1.122** frames/s same box; the two guidance branches of ONE clip on two streams: **1.084 (−3.4 %)** — half-size launches and the CFG-shared head given up cost more than the overlap gives: recorded, not pursued (VERDICT r5 next #6) |
+| 2 | DMA pieces between the MFMAs + first MFMA on C = 0 | NaN: the 12-bit instruction offset of `buffer_load … lds` moves BOTH the global and the LDS address (the pieces landed 1–3 KiB too far) — fixed in run 3 |
+| 3, 4 | phase trace of the kernel (`tools/trace_xattn.py`, the `-DUAV_DEV_KERNELS` side library; `r06_xattn_fused_phase_trace_run3/4.jsonl`), bigger load batches, row-coalesced stores through the idle ring | per 128-token tile (ticks): first read of x (LayerNorm statistics) 30 k, second read (operands + accumulators) 20 k, head 0 (cold ring) 8.7 k, then **7.9 k per head** — Q GEMM 2.5 k (64 MFMA: 39 cycles each), S 0.8 k, softmax 1.7 k, PV 0.8 k, Wout 2.9 k — and 13 k for the stores: 129 k per tile, of which the 8 heads' 65 k are 60 % MFMA time.  0.98 → 0.87 ms; event-overhead A/B twice interleaved: 1.1420 / 1.1414 with conv events in the timed region, **1.1493 / 1.1486 without (+0.63 %)** (`r06_event_overhead_ab_*_run4.jsonl`) |
+| 4, 5 | block tails as hi \\| lo pairs from the producer's epilogue (`UAV_CONV_OUT_HILO`), default on; T = 32 parity (`r06_parity_headline_tail_hilo_on_run4.jsonl`, `r06_parity_configs3_t32_320x320_30steps_vs_gpu_oracle_run5.jsonl`, `r06_parity_full_suite_run5_*.jsonl`, `r06_bench1_run5_*.json`) | bit-identical to fp32 result + cast pass (after keeping hipcc from contracting `v·scale − hi` into one fma); headline 8.2e-4 / 9.5e-4 / 1.23e-3 → **7.3e-4 / 8.7e-4 / 1.12e-3**, full-width forward 8.5e-4 → 6.5e-4, configs[0] 1.55e-3 → 1.25e-3, tiled 30-step fixture 1.25e-3 → 1.12e-3; 1.1484 → 1.1352 frames/s (−1.2 %) same box; **T = 32 at 320²: latents 7.0e-4, `.images` 8.5e-4 / 1.09e-3**, 35.3 s serial, 34.2 s with the windows on two streams (bit-identical) |
+| 6 | two cross-attention sub-layers in one launch: accumulators by NAME in the accumulator file, second LayerNorm on them (`r06_bench1_run6_cross_pair_fused.json`) | pair 1.40 ms against 2 × 0.90 single / 2 × 1.22 chain at M = 409 600; clip **1.158**; as C++ tuples that asm statements hold as `"+a"` AND the VALU reads, the accumulators cost 34 … 1 679 spilled registers per lane — by name, 0 |
+| 7 | temporal sub-layer kernel (`r06_fused_sublayers_vs_chains_run7_cross_pair_and_temporal.jsonl`, `r06_bench1_run7_*.json`, `r06_tests_gpu_suite_and_smoke_run7.log`) | all four cases green on the first run; **1.14 ms against 1.85 ms** (LayerNorm 0.23 + q\\|k\\|v 0.83 + attention 0.34 + to_out 0.45) at M = 409 600, 0.35 / 0.53 at 102 400; clip **1.193 frames/s**, conv 0.371; 214 GPU tests + smoke |
+"""
+    s = s.replace("@@ROUND6_LEDGER@@", ledger)
+    open(p, "w").write(s)
+
+
+if __name__ == "__main__":
+    main()

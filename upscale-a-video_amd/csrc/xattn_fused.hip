@@ -75,6 +75,10 @@ UAV_DEVINL void dma_piece(uint4_t srd, unsigned voff, unsigned soff, unsigned ld
 }
 template <int N> UAV_DEVINL void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 UAV_DEVINL float swap32(float v) { return __shfl_xor(v, 32, 64); }
+UAV_DEVINL uint32_t pack_h2f(float x, float y) {
+    half2_t h = {(half_t)x, (half_t)y};
+    return __builtin_bit_cast(uint32_t, h);
+}
 
 // The 256 fp32 accumulators of a wave's 32 tokens x 512 channels live in the accumulator half of the register file BY NAME — channel
 // tile nt in a[16 nt : 16 nt + 15] — like the O^T tile of attn512w_kernel (attention.hip): as C++ tuples that asm statements take as
@@ -544,7 +548,8 @@ constexpr int TNG = XHEADS * TGPH;
 constexpr int TT = 8;                          // frames
 constexpr int TTAB_REL = XTAB + 3 * XTABS;     // LDS behind the LayerNorm / bias tables of up to three sub-layers: relative-position bias [head][tq][hi][m] = bias[head][tq][2 m + hi] (2 KiB)
 constexpr int TTAB_COS = TTAB_REL + 2048;      // RoPE cos [t][hi][2 q + pb] = cos[t][4 q + 2 hi + pb] (512 B), then sin
-constexpr int TSMEM = TTAB_COS + 1024;
+constexpr int TTAB_LN3 = TTAB_COS + 1024;      // gamma | beta of the LayerNorm BEHIND the sub-layer(s) (the block's norm3), when its output is asked for (4 KiB)
+constexpr int TSMEM = TTAB_LN3 + 4096;
 
 struct TattnArgs {
     const float* x; float* out; const float* gamma; const float* beta; const float* bias; float eps;
@@ -552,6 +557,9 @@ struct TattnArgs {
     const float* relbias; const float* rope_cos; const float* rope_sin;
     int n_batch; long long hw; float scale;
     XattnSub xs[2]; int lk; float xscale_log2;   // NX = 2: the block's two text cross-attention sub-layers in front (attn1, attn2)
+    // optional: the NEXT LayerNorm of the block (norm3, in front of the feed-forward) applied to the rows this kernel writes, as fp16 operand
+    // rows [M][512] — the rows are in the accumulators anyway, and the LayerNorm launch (4 B read + 2 B written per element) disappears
+    half_t* ln_out; const float* ln_gamma; const float* ln_beta; float ln_eps;
 };
 
 // NX = 0: the temporal sub-layer alone.  NX = 2: attn1 -> attn2 -> attn_temporal of one BasicTransformerBlock (only_cross_attention) in ONE
@@ -620,6 +628,10 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
         *(lds_f4wptr_t)(size_t)(lds0 + TT_LN + tid * 16) = ((const float4_t*)p.gamma)[tid];
         *(lds_f4wptr_t)(size_t)(lds0 + TT_LN + 2048 + tid * 16) = ((const float4_t*)p.beta)[tid];
         *(lds_f4wptr_t)(size_t)(lds0 + TT_LN + 4096 + tid * 16) = ((const float4_t*)p.bias)[tid];
+        if (p.ln_out) {
+            *(lds_f4wptr_t)(size_t)(lds0 + TTAB_LN3 + tid * 16) = ((const float4_t*)p.ln_gamma)[tid];
+            *(lds_f4wptr_t)(size_t)(lds0 + TTAB_LN3 + 2048 + tid * 16) = ((const float4_t*)p.ln_beta)[tid];
+        }
     } else {
         typedef __attribute__((address_space(3))) float* lds_fptr_t;
         const int u = tid - 128;                            // 128 threads: 512 bias entries (4 each), 128 cos + 128 sin (1 + 1 each)
@@ -847,6 +859,41 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
         const int ln = lane_, l32e = lane_ & 31, hie = lane_ >> 5;
         const unsigned wbuf = (unsigned)(size_t)(lptr_t)smem + (unsigned)(wave * XGROUP);
         float* const obase = p.out + rowbase * XC + ln * 4;
+        if (p.ln_out) {
+            // ---- the block's next LayerNorm on the finished rows (two passes over the accumulators like layernorm_kernel), fp16 rows out: the
+            // lane's 8-B pieces (4 channels) into the wave's ring quarter — 32 rows x 1 KiB, 16-B block pb of row r at pb ^ (r & 7) —, whole rows back
+            typedef __attribute__((address_space(3))) uint2_t* lds_u2wptr_t;
+            float sm = 0.f;
+            static_for<256>([&](auto N) { sm += acc_get<N>(); });
+            sm += swap32(sm);
+            const float mean3 = sm * (1.0f / XC);
+            float sq = 0.f;
+            static_for<256>([&](auto N) { const float d = acc_get<N>() - mean3; sq += d * d; });
+            sq += swap32(sq);
+            const float rstd3 = rsqrtf(sq * (1.0f / XC) + p.ln_eps);
+            static_for<64>([&](auto JQ) {
+                constexpr int j = JQ / 4, q = JQ % 4;
+                const unsigned ta = (unsigned)(size_t)(lptr_t)smem + TTAB_LN3 + (32 * j + 8 * q + 4 * hie) * 4;
+                const float4_t g = lds_f4(ta), be = lds_f4(ta + 2048);
+                const float v0 = acc_get<16 * j + 4 * q>(), v1 = acc_get<16 * j + 4 * q + 1>(), v2 = acc_get<16 * j + 4 * q + 2>(), v3 = acc_get<16 * j + 4 * q + 3>();
+                const uint2_t h = {pack_h2f((v0 - mean3) * rstd3 * g[0] + be[0], (v1 - mean3) * rstd3 * g[1] + be[1]),
+                                   pack_h2f((v2 - mean3) * rstd3 * g[2] + be[2], (v3 - mean3) * rstd3 * g[3] + be[3])};
+                const int pc8 = 8 * j + 2 * q + hie;        // 8-B piece of the 1-KiB row; 16-B block pc8 >> 1
+                *(lds_u2wptr_t)(size_t)(wbuf + l32e * 1024 + ((((pc8 >> 1) ^ (l32e & 7)) << 4) | ((pc8 & 1) << 3))) = h;
+            });
+            asm volatile("" ::: "memory");
+            half_t* const nbase = p.ln_out + rowbase * XC + ln * 8;
+#pragma unroll
+            for (int kb = 0; kb < 32; kb += 8) {
+                float4_t r[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) r[k] = lds_f4(wbuf + (kb + k) * 1024 + ((ln ^ ((kb + k) & 7)) << 4));
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    *(float4_t*)(nbase + ((long long)((kb + k) >> 2) * p.hw + ((kb + k) & 3)) * XC) = r[k];
+            }
+            asm volatile("" ::: "memory");
+        }
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
             static_for<32>([&](auto JQ) {
@@ -954,7 +1001,8 @@ int tattn_launch(const float* x, float* out, const uav_xattn_params* xs, int32_t
     if (((size_t)x | (size_t)out) & 15) return UAV_EALIGN;
     TattnArgs a{x, out, q->ln_gamma, q->ln_beta, q->out_bias, q->ln_eps, (const char*)q->wq_packed, (const char*)q->wk_packed,
                 (const char*)q->wv_packed, (const char*)q->wo_packed, q->rel_bias, q->rope_cos, q->rope_sin, n_batch, (long long)hw, scale,
-                {}, lk, xscale * 1.44269504088896341f};
+                {}, lk, xscale * 1.44269504088896341f, (half_t*)q->next_ln_out, q->next_ln_gamma, q->next_ln_beta, q->next_ln_eps};
+    if (q->next_ln_out && (!q->next_ln_gamma || !q->next_ln_beta || ((size_t)q->next_ln_out & 15))) return UAV_EINVAL;
     for (int i = 0; i < n_xs; ++i) {
         const uav_xattn_params& c = xs[i];
         if (!c.ln_gamma || !c.ln_beta || !c.wq_packed || !c.kv_packed || !c.wo_packed || !c.out_bias) return UAV_EINVAL;

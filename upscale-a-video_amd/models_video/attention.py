@@ -182,14 +182,14 @@ class TemporalAttention(CrossAttention):
                 pk("q", self.to_q, "q"), pk("k", self.to_k, "q"), pk("v", self.to_v, "q"), pk("o", self.to_out[0], "out"),
                 E.f32_param(self, "tattn.ob", self.to_out[0].bias), bias, cos, sin, rot)
 
-    def run_temporal(self, x, residual, g: E.Geom, ln=None):
+    def run_temporal(self, x, residual, g: E.Geom, ln=None, next_ln=None):
         c = self.heads * self.dim_head
         bias, cos, sin, rot = self._tables(g.t)
         tp = self.fused_temporal_params(x, ln, g) if residual is x else None
         if tp is not None:
             # the whole sub-layer in one launch (csrc/xattn_fused.hip, tattn_sublayer_kernel): LayerNorm -> q | k | v -> RoPE + bias + per-pixel
             # softmax over the frames -> to_out -> + residual, the fp32 stream read once and written once
-            return ops.tattn_sublayer(x, *tp[:11], n_batch=g.b, t_len=g.t, hw=g.hw, rot_dim=tp[11], scale=self.scale)
+            return ops.tattn_sublayer(x, *tp[:11], n_batch=g.b, t_len=g.t, hw=g.hw, rot_dim=tp[11], scale=self.scale, next_ln=next_ln)
         qkv = ops.linear(x, E.packed_cat(self, "qkv", [self.to_q, self.to_k, self.to_v])) if ln is None else \
             E.ln_linear(self, "qkv", ln, x, [self.to_q, self.to_k, self.to_v])
         o = ops.temporal_attention(qkv, n_batch=g.b, t_len=g.t, hw=g.hw, c=c, heads=self.heads, scale=self.scale,
@@ -290,8 +290,11 @@ class BasicTransformerBlock(E.EngineModule):
             # the three attention sub-layers of the block
             tp = self.attn_temporal.fused_temporal_params(x, self.norm_temporal, g)
             if tp is not None:
+                # (+ norm3 of the finished rows for the feed-forward: the same parameter tensors FeedForward.run -> engine.ln_linear looks up)
+                nxt = (E.f32_param(self.ff, "up.ln.g", self.norm3.weight), E.f32_param(self.ff, "up.ln.b", self.norm3.bias), self.norm3.eps) \
+                    if E.NEXT_LN else None
                 x = ops.block_attn_sublayers(x, list(pair), tp, n_batch=g.b, t_len=g.t, hw=g.hw, lk=n_text, cross_scale=self.attn1.scale,
-                                             temporal_scale=self.attn_temporal.scale)
+                                             temporal_scale=self.attn_temporal.scale, next_ln=nxt)
                 return self.ff.run(x, x, out_f32, ln=self.norm3, out_hilo=out_hilo)
         if pair is not None:
             x = ops.xattn_sublayers(x, list(pair), rows_per_kv=g.t * lq, lk=n_text, scale=self.attn1.scale)
@@ -302,7 +305,8 @@ class BasicTransformerBlock(E.EngineModule):
                 x = self.attn1.run(x, x, bq=bq, lq=lq, ln=self.norm1)
             if t2 is not None:
                 x = self.attn2.run(x, x, bq=bq, lq=lq, text=t2, q_per_kv=g.t, ln=self.norm2)
-        x = self.attn_temporal.run_temporal(x, x, g, ln=self.norm_temporal)
+        nxt = (E.f32_param(self.ff, "up.ln.g", self.norm3.weight), E.f32_param(self.ff, "up.ln.b", self.norm3.bias), self.norm3.eps) if E.NEXT_LN else None
+        x = self.attn_temporal.run_temporal(x, x, g, ln=self.norm_temporal, next_ln=nxt)
         return self.ff.run(x, x, out_f32, ln=self.norm3, out_hilo=out_hilo)
 
 

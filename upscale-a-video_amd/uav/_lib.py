@@ -47,7 +47,8 @@ class XattnParams(C.Structure):
 class TattnParams(C.Structure):
     """Mirror of `uav_tattn_params` (include/uav_hip.h): the fused temporal attention sub-layer."""
     _fields_ = [("ln_gamma", c_p), ("ln_beta", c_p), ("ln_eps", f32), ("wq_packed", c_p), ("wk_packed", c_p), ("wv_packed", c_p),
-                ("wo_packed", c_p), ("out_bias", c_p), ("rel_bias", c_p), ("rope_cos", c_p), ("rope_sin", c_p), ("rot_dim", i32)]
+                ("wo_packed", c_p), ("out_bias", c_p), ("rel_bias", c_p), ("rope_cos", c_p), ("rope_sin", c_p), ("rot_dim", i32),
+                ("next_ln_out", c_p), ("next_ln_gamma", c_p), ("next_ln_beta", c_p), ("next_ln_eps", f32)]
 
 
 CONV_GEGLU = 1

@@ -374,6 +374,11 @@ TATTN_FUSED = _os.environ.get("UAV_TATTN_FUSED", "1") != "0"
 BLOCK_ATTN_FUSED = _os.environ.get("UAV_BLOCK_ATTN_FUSED", "1") != "0"
 
 
+# ... and the LayerNorm in front of the feed-forward (norm3) written by that launch's epilogue (fp16 rows beside the fp32 ones): the
+# LayerNorm pass of the block's last sub-layer disappears.  UAV_NEXT_LN=0 keeps the pass.
+NEXT_LN = _os.environ.get("UAV_NEXT_LN", "1") != "0"
+
+
 def packed_ln_linear(mod: EngineModule, name, ln: nn.LayerNorm, linears, geglu=False):
     """(ConvW of fp16(W o gamma) with bias W.beta + b, colsum[n_pad] fp32) for the row-concatenated `linears` behind `ln`."""
     def build():
@@ -398,7 +403,11 @@ def ln_linear(mod: EngineModule, name, ln: nn.LayerNorm, x, linears, geglu=False
         cw, colsum = packed_ln_linear(mod, name, ln, linears, geglu)
         if ops.ln_fold_ok(x.shape[0], x.shape[-1], cw):
             return ops.linear(op.raw, cw, ln_consume=(op, colsum, ln.eps))
-    n = layer_norm(mod, name + ".ln", ln, x)
+    n = None
+    if NEXT_LN and x.dtype == torch.float32:       # the kernel that wrote x also wrote LayerNorm(x) for THIS LayerNorm (ops.NextLn)?
+        n = ops.next_ln_of(x, f32_param(mod, name + ".ln.g", ln.weight), f32_param(mod, name + ".ln.b", ln.bias), ln.eps)
+    if n is None:
+        n = layer_norm(mod, name + ".ln", ln, x)
     if len(linears) == 1:
         return ops.linear(n, packed_conv(mod, name, linears[0], geglu=geglu))
     return ops.linear(n, packed_cat(mod, name, linears))

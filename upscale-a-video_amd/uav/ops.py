@@ -725,22 +725,52 @@ def tattn_ok(x, *, heads, head_dim, t_len, hw, rot_dim):
 
 
 def tattn_sublayer(x, gamma, beta, eps, wq_packed, wk_packed, wv_packed, wo_packed, out_bias, rel_bias, rope_cos, rope_sin, *,
-                   n_batch, t_len, hw, rot_dim, scale, out=None):
-    """x + to_out(temporal_attention(to_q | to_k | to_v (LayerNorm(x)))) + bias on fp32 stream rows [B*T*hw][512] in one launch."""
+                   n_batch, t_len, hw, rot_dim, scale, out=None, next_ln=None):
+    """x + to_out(temporal_attention(to_q | to_k | to_v (LayerNorm(x)))) + bias on fp32 stream rows [B*T*hw][512] in one launch.
+    next_ln = (gamma, beta, eps): also write fp16 LayerNorm(y) of the result rows (attached to y, see NextLn)."""
     lib = _lib.load()
     _req(x, torch.float32, "x")
     y = torch.empty_like(x) if out is None else out
-    q = _lib.TattnParams()
-    q.ln_gamma, q.ln_beta, q.ln_eps = _p(gamma), _p(beta), float(eps)
-    q.wq_packed, q.wk_packed, q.wv_packed, q.wo_packed, q.out_bias = _p(wq_packed), _p(wk_packed), _p(wv_packed), _p(wo_packed), _p(out_bias)
-    q.rel_bias, q.rope_cos, q.rope_sin, q.rot_dim = _p(rel_bias), _p(rope_cos), _p(rope_sin), int(rot_dim)
+    q = _tattn_params((gamma, beta, eps, wq_packed, wk_packed, wv_packed, wo_packed, out_bias, rel_bias, rope_cos, rope_sin, rot_dim))
+    nl = _attach_next_ln(y, q, next_ln)
     m = x.shape[0]
     ev = PROFILER.begin("tattn_sublayer")
     rc = lib.uav_tattn_sublayer_f32(_p(x), _p(y), C.byref(q), n_batch, t_len, hw, XATTN_C, XATTN_HEADS, scale, _stream())
     _lib.check(rc, "uav_tattn_sublayer_f32")
     PROFILER.end(ev, "tattn_sublayer" if not PROFILER.detail else f"tattn_sublayer M={m}", 2.0 * m * (4 * XATTN_C * XATTN_C) + 4.0 * m * t_len * XATTN_C,
                  8.0 * m * XATTN_C)
+    if nl is not None:
+        nl.version = y._version
+        y._uav_next_ln = nl
+    elif getattr(y, "_uav_next_ln", None) is not None:
+        y._uav_next_ln = None
     return y
+
+
+class NextLn:
+    """fp16 rows n = LayerNorm(y) that the kernel which produced y wrote beside it (`next_ln` of tattn_sublayer / block_attn_sublayers):
+    attached to y as `_uav_next_ln`; engine.ln_linear uses it instead of a LayerNorm launch when it was made with the same parameters."""
+    __slots__ = ("rows", "gamma", "beta", "eps", "version")
+
+    def __init__(self, rows, gamma, beta, eps):
+        self.rows, self.gamma, self.beta, self.eps, self.version = rows, gamma, beta, float(eps), None
+
+
+def next_ln_of(x, gamma, beta, eps):
+    nl = getattr(x, "_uav_next_ln", None)
+    if nl is None or nl.version != x._version or nl.gamma is not gamma or nl.beta is not beta or nl.eps != float(eps) or nl.rows.shape != x.shape:
+        return None
+    return nl.rows
+
+
+def _attach_next_ln(y, q, next_ln):
+    """Fill the next-LayerNorm fields of TattnParams `q` for output rows y; returns the NextLn to attach after the launch."""
+    if next_ln is None:
+        return None
+    gamma, beta, eps = next_ln
+    nl = NextLn(torch.empty(y.shape, dtype=HALF, device=y.device), gamma, beta, eps)
+    q.next_ln_out, q.next_ln_gamma, q.next_ln_beta, q.next_ln_eps = _p(nl.rows), _p(gamma), _p(beta), float(eps)
+    return nl
 
 
 def _tattn_params(t):
@@ -752,7 +782,7 @@ def _tattn_params(t):
     return q
 
 
-def block_attn_sublayers(x, cross, temporal, *, n_batch, t_len, hw, lk, cross_scale, temporal_scale, out=None):
+def block_attn_sublayers(x, cross, temporal, *, n_batch, t_len, hw, lk, cross_scale, temporal_scale, out=None, next_ln=None):
     """attn1 -> attn2 -> attn_temporal of one BasicTransformerBlock (only_cross_attention) on fp32 stream rows [B*T*hw][512] in ONE
     launch: `cross` = two (gamma, beta, eps, wq_packed, kv_packed, wo_packed, out_bias) tuples as for xattn_sublayers, `temporal` =
     (gamma, beta, eps, wq, wk, wv, wo packed, out_bias, rel_bias, rope_cos, rope_sin, rot_dim) as for tattn_sublayer."""
@@ -766,11 +796,17 @@ def block_attn_sublayers(x, cross, temporal, *, n_batch, t_len, hw, lk, cross_sc
         arr[i].ln_gamma, arr[i].ln_beta, arr[i].ln_eps = _p(gamma), _p(beta), float(eps)
         arr[i].wq_packed, arr[i].kv_packed, arr[i].wo_packed, arr[i].out_bias = _p(wq_packed), _p(kv_packed), _p(wo_packed), _p(out_bias)
     q = _tattn_params(temporal)
+    nl = _attach_next_ln(y, q, next_ln)         # next_ln = (gamma, beta, eps) of the LayerNorm behind the three sub-layers (the block's norm3)
     m = x.shape[0]
     ev = PROFILER.begin("block_attn_sublayers")
     rc = lib.uav_block_attn_sublayers_f32(_p(x), _p(y), C.cast(arr, C.c_void_p), lk, cross_scale, C.byref(q), n_batch, t_len, hw, XATTN_C, XATTN_HEADS,
                                           temporal_scale, _stream())
     _lib.check(rc, "uav_block_attn_sublayers_f32")
+    if nl is not None:
+        nl.version = y._version
+        y._uav_next_ln = nl
+    elif getattr(y, "_uav_next_ln", None) is not None:
+        y._uav_next_ln = None
     PROFILER.end(ev, "block_attn_sublayers" if not PROFILER.detail else f"block_attn_sublayers M={m}",
                  2.0 * m * (8 * XATTN_C * XATTN_C) + 2 * 4.0 * m * lk * XATTN_C + 4.0 * m * t_len * XATTN_C, 8.0 * m * XATTN_C)
     return y
