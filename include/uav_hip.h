@@ -286,6 +286,23 @@ int uav_tattn_sublayer_f32(const float* x, float* out, const uav_tattn_params* p
 int uav_block_attn_sublayers_f32(const float* x, float* out, const uav_xattn_params* cross, int32_t lk, float cross_scale,
                                  const uav_tattn_params* temporal, int32_t n_batch, int32_t t_len, int64_t hw, int32_t channels,
                                  int32_t heads, float temporal_scale, void* stream);
+/* The feed-forward sub-layer of the same block (reference attention.py:562-564 `ff(norm3(x)) + x`: LayerNorm -> GEGLU 512 -> 2 x 2048
+ * -> Linear 2048 -> 512 -> + residual; diffusers_attention.py:735-823) in ONE launch: the hidden activations never leave the registers.
+ *   x: fp32 rows [rows][512], rows % 128 == 0; out: fp32 rows (may be NULL) and / or out_hilo: fp16 rows [rows][1024] = fp16(y) |
+ *   fp16(y - fp16(y)), the operand pair of proj_out (uav_cast_f32_hilo's layout, bit-identical to it on the fp32 result).
+ *   w_packed: 6 MiB fragment stream = per slice c of 32 hidden channels: 64 KiB of fragments of W_up (k-step, tile: tile 0 = value rows
+ *   32c.., tile 1 = gate rows 2048 + 32c..) then 32 KiB of fragments of columns 32c.. of W_down — uav.ops.pack_ff_weights.
+ *   up_bias: fp32 [4096] (value | gate), down_bias: fp32 [512].  channels must be 512, inner 2048 (UAV_ESHAPE otherwise). */
+typedef struct uav_ff_params {
+    const float* ln_gamma;
+    const float* ln_beta;
+    float        ln_eps;
+    const void*  w_packed;
+    const float* up_bias;
+    const float* down_bias;
+} uav_ff_params;
+int uav_ff_sublayer_f32(const float* x, float* out, void* out_hilo, const uav_ff_params* p, int64_t rows, int32_t channels,
+                        int32_t inner, void* stream);
 /* k, v: fp16 rows [n_batch * lk][stride] (head h in columns h*head_dim ..) -> out: n_batch * heads * 32 KiB */
 int uav_xattn_pack_kv(const void* k, int64_t k_stride, const void* v, int64_t v_stride, int32_t n_batch, int32_t lk,
                       int32_t heads, int32_t head_dim, void* out, void* stream);

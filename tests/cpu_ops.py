@@ -372,6 +372,27 @@ def resize_area_f32(x, ho, wo, mul=1.0):
     return (F.interpolate(x.reshape((-1, 1) + tuple(x.shape[-2:])).float(), (ho, wo), mode="area") * mul).reshape(tuple(lead) + (ho, wo))
 
 
+def _unpack_ff_weights(w_packed):
+    """Inverse of uav.ops.pack_ff_weights: -> (w_up [4096][512], w_down [512][2048])."""
+    f = w_packed.float().reshape(64, 3 * 32 * 512)
+    # [c][ks][vg][hi][l32][e2][e1] -> rows (vg, c, l32) x k (ks, e2, hi, e1)
+    wu = f[:, :2 * 32 * 512].reshape(64, 32, 2, 2, 32, 2, 4).permute(2, 0, 4, 1, 5, 3, 6).reshape(4096, 512)
+    # [c][npair][ks][par][hi][l32][e2][e1] -> rows (npair, par, l32) x k (c, ks, e2, hi, e1)
+    wd = f[:, 2 * 32 * 512:].reshape(64, 8, 2, 2, 2, 32, 2, 4).permute(1, 3, 5, 0, 2, 6, 4, 7).reshape(512, 2048)
+    return wu, wd
+
+
+def ff_sublayer(x, gamma, beta, eps, w_packed, up_bias, down_bias, *, out_f32=True, out_hilo=False):
+    wu, wd = _unpack_ff_weights(w_packed)
+    n = _h(F.layer_norm(x.float(), (x.shape[-1],), gamma.float(), beta.float(), eps)).float()
+    u = n @ wu.t() + up_bias.float()
+    hdn = _h(u[:, :2048] * F.gelu(u[:, 2048:])).float()
+    y = x.float() + down_bias.float() + hdn @ wd.t()
+    if out_f32 and out_hilo:
+        return y, cast_hilo(y)
+    return y if out_f32 else cast_hilo(y)
+
+
 def cast_f16(x):
     return x if x.dtype == HALF else _h(x)
 
@@ -388,7 +409,7 @@ def sft_fuse(dec, scale, shift, w, out_f32=False):
     return y if out_f32 else _h(y)
 
 
-_OPS = ("ln_fold_ok", "resize_area_f32", "cast_f16", "cast_hilo", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "xattn_pack_kv", "xattn_sublayer", "xattn_sublayers", "tattn_sublayer", "block_attn_sublayers", "temporal_attention", "linear_small",
+_OPS = ("ln_fold_ok", "resize_area_f32", "cast_f16", "cast_hilo", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "xattn_pack_kv", "xattn_sublayer", "xattn_sublayers", "tattn_sublayer", "block_attn_sublayers", "ff_sublayer", "temporal_attention", "linear_small",
         "timestep_embedding", "pack_nhwc", "unpack_ncthw", "axpby", "cfg_ddim_v0", "ddim_vt")
 
 

@@ -426,3 +426,41 @@ def test_pipeline_overlap_units_host_side(cpu_engine, unet_and_sd, monkeypatch):
     got8 = run(8, True, split=True)
     assert calls == [[((0, 8), 0), ((0, 8), 1)]] * 2 + [[0, 3, 6]]
     assert rel_l2(got8[1], ref8[1]) < 5e-3          # batch-1 units vs the batch-2 evaluation: ATen's CPU convs block differently (see above)
+
+
+def test_transformer_block_fused_feed_forward_host_side(cpu_engine):
+    """BasicTransformerBlock at the 512-channel width with the feed-forward as ONE launch (ops.ff_sublayer; weights re-packed into the
+    kernel's fragment stream by ops.pack_ff_weights) against LayerNorm + the two GEMM launches: the host side — which blocks qualify, the
+    stream layout (the stand-in un-packs it), norm3 not asked of the attention launch, the hi | lo pair for proj_out."""
+    from uav import engine as E, ops
+    from models_video.attention import BasicTransformerBlock
+    g = torch.Generator().manual_seed(5)
+    blk = BasicTransformerBlock(512, 8, 64, cross_attention_dim=64, only_cross_attention=True)
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.05 if p_.dim() > 1 else 0.2))
+        for ln in (blk.norm1, blk.norm2, blk.norm_temporal, blk.norm3):
+            ln.weight.add_(1.0)
+    blk = blk.half().eval()
+    geom = E.Geom(1, 8, 4, 4)                                   # 128 rows: one tile of every fused kernel
+    x = torch.randn(geom.rows, 512, generator=g) * 1.2
+    ehs = torch.randn(7, 64, generator=g).half()
+    assert blk.ff.fused_params(x, blk.norm3) is not None and blk.ff.fused_params(x.half(), blk.norm3) is None
+    assert blk.ff.fused_params(x[:100], blk.norm3) is None      # not whole 128-row tiles
+    old = E.FF_FUSED
+    res = {}
+    try:
+        for on in (True, False):
+            E.FF_FUSED = on
+            E.invalidate_packed(blk)
+            with torch.no_grad():
+                res[on] = (blk.run(x.clone(), geom, ehs, 7), blk.run(x.clone(), geom, ehs, 7, out_hilo=True))
+            if on:
+                assert ops.next_ln_of(res[on][0], blk.norm3.weight, blk.norm3.bias, blk.norm3.eps) is None
+    finally:
+        E.FF_FUSED = old
+        E.invalidate_packed(blk)
+    (y1, h1), (y0, h0) = res[True], res[False]
+    assert y1.dtype == y0.dtype == torch.float32 and h1.dtype == h0.dtype == torch.float16 and h1.shape == (geom.rows, 1024)
+    assert rel_l2(y1, y0) < 2e-4                                # the two forms on the CPU: fp32 summation order only
+    assert torch.equal(h1, ops.cast_hilo(y1))

@@ -1229,3 +1229,78 @@ def test_fused_sublayer_kernels_emit_the_next_layernorm(ops, dev):
     assert ops.next_ln_of(y, b3, g3, 1e-5) is None and ops.next_ln_of(y, g3, b3, 1e-6) is None   # other parameters: not this LayerNorm
     y.add_(1.0)
     assert ops.next_ln_of(y, g3, b3, 1e-5) is None                   # rows changed since: stale
+
+
+@pytest.mark.parametrize("m,mode", [(128, "f32"), (4096, "f32"), (2048, "hilo"), (1024, "both")])
+def test_fused_feed_forward_sublayer(ops, dev, m, mode):
+    """uav_ff_sublayer_f32 (reference attention.py:562-564 `ff(norm3(x)) + x`, GEGLU feed-forward of diffusers) against the three launches it
+    replaces (LayerNorm, 512 -> 4096 GEMM with the GEGLU epilogue, 2048 -> 512 GEMM + residual) — same roundings, fp32 summation order
+    apart — and against fp32 torch; the hi | lo pair is cast_hilo of the fp32 rows, bit for bit."""
+    g = torch.Generator().manual_seed(77 + m)
+    C, I = 512, 2048
+    x = (torch.randn(m, C, generator=g) * 1.3 + 0.4).to(dev)
+    gamma = (torch.randn(C, generator=g) * 0.2 + 1.0).to(dev); beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+    wu = h16(2 * I, C, dev=dev, scale=C ** -0.5, gen=g); wd = h16(C, I, dev=dev, scale=I ** -0.5, gen=g)
+    bu = (torch.randn(2 * I, generator=g) * 0.2).to(dev); bd = (torch.randn(C, generator=g) * 0.1).to(dev)
+    wp = ops.pack_ff_weights(wu, wd, dev)
+    assert ops.ff_ok(x, inner=I)
+    r = ops.ff_sublayer(x, gamma, beta, 1e-5, wp, bu, bd, out_f32=mode != "hilo", out_hilo=mode != "f32")
+    y, yh = (r, None) if mode == "f32" else (None, r) if mode == "hilo" else r
+    # the chain
+    n = ops.layernorm(x, gamma, beta, 1e-5)
+    hdn = ops.linear(n, ops.pack_conv(wu, bu, geglu=True, device=dev))
+    yc = ops.linear(hdn, ops.pack_conv(wd, bd, device=dev), residual=x, out_f32=True)
+    # fp32 torch on the same fp16-representable weights
+    nf = torch.nn.functional.layer_norm(x, (C,), gamma, beta, 1e-5)
+    u = nf @ wu.float().t() + bu
+    yf = x + bd + (u[:, :I] * torch.nn.functional.gelu(u[:, I:])) @ wd.float().t()
+    if y is not None:
+        assert rel_l2(y - x, yc - x) < 3e-4, rel_l2(y - x, yc - x)      # the branch alone (the residual would hide it)
+        assert rel_l2(y - x, yf - x) < 2e-3
+        assert torch.isfinite(y).all()
+    if yh is not None:
+        assert yh.shape == (m, 2 * C) and yh.dtype == torch.float16
+        if y is not None:
+            assert torch.equal(yh, ops.cast_hilo(y))
+        else:
+            yy = yh[:, :C].float() + yh[:, C:].float()
+            assert rel_l2(yy - x, yc - x) < 3e-4
+    # determinism
+    r2 = ops.ff_sublayer(x, gamma, beta, 1e-5, wp, bu, bd, out_f32=mode != "hilo", out_hilo=mode != "f32")
+    assert all(torch.equal(a, b) for a, b in zip(r if isinstance(r, tuple) else (r,), r2 if isinstance(r2, tuple) else (r2,)))
+    with pytest.raises(Exception):
+        ops.ff_sublayer(x[:100], gamma, beta, 1e-5, wp, bu, bd)           # not a whole 128-row tile
+
+
+def test_transformer_block_with_fused_feed_forward_matches_three_launch_chain(ops, dev):
+    """BasicTransformerBlock (T = 8: the block kernel in front) with the feed-forward as one launch on and off — same module, same weights —,
+    as fp32 rows and as the hi | lo pair of proj_out."""
+    from uav import engine as E
+    from models_video.attention import BasicTransformerBlock
+    g = torch.Generator().manual_seed(78)
+    blk = BasicTransformerBlock(512, 8, 64, cross_attention_dim=1024, only_cross_attention=True)
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.05 if p_.dim() > 1 else 0.2))
+        for ln in (blk.norm1, blk.norm2, blk.norm_temporal, blk.norm3):
+            ln.weight.add_(1.0)
+    blk = blk.half().to(dev).eval()
+    geom = E.Geom(2, 8, 16, 16)
+    x = (torch.randn(geom.rows, 512, generator=g) * 1.2).to(dev)
+    ehs = (torch.randn(2 * 77, 1024, generator=g)).half().to(dev)
+    old = E.FF_FUSED
+    res = {}
+    try:
+        for on in (True, False):
+            E.FF_FUSED = on
+            E.invalidate_packed(blk)
+            with torch.no_grad():
+                res[on] = (blk.run(x.clone(), geom, ehs, 77), blk.run(x.clone(), geom, ehs, 77, out_hilo=True))
+    finally:
+        E.FF_FUSED = old
+        E.invalidate_packed(blk)
+    (y1, h1), (y0, h0) = res[True], res[False]
+    assert y1.dtype == y0.dtype == torch.float32 and h1.dtype == h0.dtype == torch.float16
+    e = rel_l2(y1, y0)
+    assert e < 5e-4, e
+    assert torch.equal(h1, ops.cast_hilo(y1)) and torch.equal(h0, ops.cast_hilo(y0))

@@ -124,7 +124,51 @@ def tcase(name, nb, hh, ww):
     print(json.dumps(d), flush=True)
 
 
+def fcase(name, m):
+    """The feed-forward sub-layer: fused launch against LayerNorm -> 512 -> 4096 GEGLU GEMM -> 2048 -> 512 GEMM + residual."""
+    I = 2048
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(m, C, generator=g) * 1.3 + 0.2).to(dev)
+    gamma = (torch.randn(C, generator=g) * 0.2 + 1).to(dev); beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+    wu = (torch.randn(2 * I, C, generator=g) * C ** -0.5).half().float().to(dev); wd = (torch.randn(C, I, generator=g) * I ** -0.5).half().float().to(dev)
+    bu = (torch.randn(2 * I, generator=g) * 0.2).to(dev); bd = (torch.randn(C, generator=g) * 0.1).to(dev)
+    cu, cd = ops.pack_conv(wu, bu, geglu=True, device=dev), ops.pack_conv(wd, bd, device=dev)
+    wp = ops.pack_ff_weights(wu, wd, dev)
+    st = {}
+
+    def ln(): st["n"] = ops.layernorm(x, gamma, beta, 1e-5)
+    def up(): st["h"] = ops.linear(st["n"], cu)
+    def down(): st["y"] = ops.linear(st["h"], cd, residual=x, out_f32=True)
+    def down_hilo(): st["yh"] = ops.linear(st["h"], cd, residual=x, out_f32=True, out_hilo=True)
+    def chain(): ln(); up(); down()
+    def fused(): st["f"] = ops.ff_sublayer(x, gamma, beta, 1e-5, wp, bu, bd)
+    def fused_hilo(): st["fh"] = ops.ff_sublayer(x, gamma, beta, 1e-5, wp, bu, bd, out_f32=False, out_hilo=True)
+
+    fns = {"fused": fused, "fused_hilo_out": fused_hilo, "chain": chain, "layernorm": ln, "up_geglu": up, "down": down, "down_hilo_out": down_hilo}
+    chain(); fused(); fused_hilo(); down_hilo(); chain(); fused()
+    torch.cuda.synchronize()
+    t = {kk: [] for kk in fns}
+    for _ in range(ROUNDS):
+        for kk, f in fns.items():
+            t[kk].append(time_once(f, PER))
+    fl = 2.0 * m * C * 3 * I
+    d = {"case": name, "rows": m, "max_abs_diff_fused_vs_chain": float((st["f"] - st["y"]).abs().max()),
+         "hilo_pair_bit_identical_to_chain": bool(torch.equal(st["fh"], ops.cast_hilo(st["f"])))}
+    for kk in fns:
+        d[kk + "_ms"] = {"median": round(statistics.median(t[kk]), 4), "min": round(min(t[kk]), 4)}
+    med = d["fused_ms"]["median"]
+    d["fused_tflops"] = round(fl / med / 1e9, 1)
+    d["chain_tflops"] = round(fl / d["chain_ms"]["median"] / 1e9, 1)
+    d["speedup_vs_chain"] = round(d["chain_ms"]["median"] / med, 3)
+    print(json.dumps(d), flush=True)
+
+
 if __name__ == "__main__":
+    if "ff" in sys.argv[1:] or not sys.argv[1:]:
+        fcase("feed-forward sub-layer, 160x160 level: 409 600 tokens", 2 * 8 * 160 * 160)
+        fcase("feed-forward sub-layer, 80x80 level: 102 400 tokens", 2 * 8 * 80 * 80)
+    if sys.argv[1:] == ["ff"]:
+        sys.exit(0)
     if "temporal" in sys.argv[1:] or not sys.argv[1:]:
         tcase("temporal sub-layer, 160x160 level: 2 x 8 frames x 160 x 160 tokens", 2, 160, 160)
         tcase("temporal sub-layer, 80x80 level", 2, 80, 80)

@@ -59,5 +59,8 @@ if __name__ == "__main__":
     for j in range(2):
         txt += fmt(f"XG_WO{j}", group(32, 0, lambda f: (f"A{16 * (8 * j + 2 * (f >> 3) + (f & 1))}", f"b{(f >> 1) & 3}"), d32)) + "\n"
     txt += fmt("XG_K", group(12, 0, lambda f: (f"c{f % 3}", f"b{f // 3}"), dk, first=True, tail_nop=True)) + "\n"
-    txt += fmt("XG_V", group(12, 12, lambda f: (f"c{f & 1}", f"b{f >> 1}"), dv, first=True, tail_nop=True))
+    txt += fmt("XG_V", group(12, 12, lambda f: (f"c{f & 1}", f"b{f >> 1}"), dv, first=True, tail_nop=True)) + "\n"
+    # feed-forward kernel, W_down over ONE 32-wide k slice (half a chunk: two k-steps) onto all 16 accumulator tiles: fragment
+    # f = (channel tile 2 (f >> 2) + (f & 1), k-step (f >> 1) & 1)
+    txt += fmt("XG_WD32", group(32, 0, lambda f: (f"A{16 * (2 * (f >> 2) + (f & 1))}", f"b{(f >> 1) & 1}"), d32))
     print(txt, end="")

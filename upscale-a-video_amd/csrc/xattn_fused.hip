@@ -222,6 +222,19 @@ template <int N, class F> UAV_DEVINL void static_for(F&& f) { static_for_impl(st
     XS0(t1, c1, b0, 5, 19456) XD(4096, 0) XS(t2, c0, b1, 5, 20480) XS(t3, c1, b1, 5, 21504) XS(t4, c0, b2, 5, 22528) \
     XD(4096, 1024) XS(t5, c1, b2, 5, 23552) XT(t0, c0, b3, 5) XT(t1, c1, b3, 4) XD(4096, 2048) XT(t2, c0, b4, 3) \
     XT(t3, c1, b4, 2) XT(t4, c0, b5, 1) XD(4096, 3072) XT(t5, c1, b5, 0) XNOP
+#define XG_WD32 \
+    XRD(t0, 0) XRD(t1, 1024) XRD(t2, 2048) XRD(t3, 3072) XRD(t4, 4096) XRD(t5, 5120) XSA(t0, 0, 15, b0, 5, 6144) \
+    XSA(t1, 16, 31, b0, 5, 7168) XSA(t2, 0, 15, b1, 5, 8192) XD(0, 0) XSA(t3, 16, 31, b1, 5, 9216) \
+    XSA(t4, 32, 47, b0, 5, 10240) XSA(t5, 48, 63, b0, 5, 11264) XSA(t0, 32, 47, b1, 5, 12288) XD(0, 1024) \
+    XSA(t1, 48, 63, b1, 5, 13312) XSA(t2, 64, 79, b0, 5, 14336) XSA(t3, 80, 95, b0, 5, 15360) \
+    XSA(t4, 64, 79, b1, 5, 16384) XD(0, 2048) XSA(t5, 80, 95, b1, 5, 17408) XSA(t0, 96, 111, b0, 5, 18432) \
+    XSA(t1, 112, 127, b0, 5, 19456) XSA(t2, 96, 111, b1, 5, 20480) XD(0, 3072) XDADV XSA(t3, 112, 127, b1, 5, 21504) \
+    XSA(t4, 128, 143, b0, 5, 22528) XSA(t5, 144, 159, b0, 5, 23552) XSA(t0, 128, 143, b1, 5, 24576) XD(4096, 0) \
+    XSA(t1, 144, 159, b1, 5, 25600) XSA(t2, 160, 175, b0, 5, 26624) XSA(t3, 176, 191, b0, 5, 27648) \
+    XSA(t4, 160, 175, b1, 5, 28672) XD(4096, 1024) XSA(t5, 176, 191, b1, 5, 29696) XSA(t0, 192, 207, b0, 5, 30720) \
+    XSA(t1, 208, 223, b0, 5, 31744) XTA(t2, 192, 207, b1, 5) XD(4096, 2048) XTA(t3, 208, 223, b1, 4) \
+    XTA(t4, 224, 239, b0, 3) XTA(t5, 240, 255, b0, 2) XTA(t0, 224, 239, b1, 1) XD(4096, 3072) XTA(t1, 240, 255, b1, 0)
+
 #define XTMP_OUT [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4), [t5] "=&v"(t5), [so] "+s"(nx.so)
 #define XDMA_IN [ldsn] "s"(nx.ldsn), [srd] "s"(nx.srd), [voff] "v"(voff)
 
@@ -919,6 +932,222 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Fused FEED-FORWARD sub-layer of BasicTransformerBlock (reference attention.py:562-564 `ff(norm3(x)) + x`; FeedForward / GEGLU of
+// diffusers: proj 512 -> 2 x 2048, value * gelu(gate), Linear 2048 -> 512) on the same skeleton:
+//
+//     out = x + W_down ( (W_v n + b_v) * gelu(W_g n + b_g) ) + b_down ,   n = LayerNorm(x)
+//
+// The 2 048 hidden channels never exist as a tensor: they are walked in 64 slices of 32, and a slice is shaped like an attention head —
+// the "Q" step on W_up rows (value rows of the slice as channel tile 0, gate rows as tile 1: 64 MFMA over k = 512 on the Xn fragments,
+// two groups), GEGLU in registers on the D layout (value and gate of one hidden channel sit in the same lane and register), rounded to
+// fp16 = the two B fragments of the "to_out" step (W_down[:, slice]: 32 MFMA onto the 256 named accumulators, one group).  Three 32-KiB
+// groups per slice, 192 per tile (6 MiB of fragments from L2), one linear stream.  (Slices of 64 — value and gate as two "Q" steps — keep
+// 64 fp32 results live beside the 128 operand registers: 4 spilled registers and a 12-minute build.)  Against the two conv-GEMM launches
+// it replaces (512 -> 4 096 with the GEGLU epilogue at 0.28 of the MFMA peak: eight k-steps per 256 x 256 tile; 2 048 -> 512): no
+// [M][2048] fp16 tensor written and read back, no LayerNorm rows, no tile prologue / epilogue per 512 of k.  Roundings are the chain's:
+// LayerNorm rows and the hidden activations fp16, the rest fp32; gelu is uav_gelu_erf of the conv epilogue.  Optionally the result leaves
+// as the fp16 hi | lo operand pair of proj_out (cast_f32_hilo_kernel's [M][2 C] rows, bit-identical) instead of / beside the fp32 rows.
+constexpr int FSLICES = 64;                    // hidden channels in slices of 32
+constexpr int FGPS = 3;                        // groups per slice: W_up value | gate rows (2), W_down columns (1)
+constexpr int FNG = FSLICES * FGPS;
+constexpr int FINNER = FSLICES * 32;
+constexpr int FTAB_UP = XTAB + XTABS;          // LDS behind gamma | beta | b_down: b_up (value 0 .. 2047 | gate 2048 .. 4095), 16 KiB
+constexpr int FSMEM = FTAB_UP + 2 * FINNER * 4;
+
+struct FfArgs {
+    const float* x; float* out; half_t* out_hilo;
+    const float* gamma; const float* beta; const float* down_bias; const float* up_bias; const char* w; float eps;
+};
+
+__global__ __launch_bounds__(256, 1) void ff_sublayer_kernel(FfArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(lptr_t)smem;
+    const long long tile0 = (long long)blockIdx.x * 128;
+    const long long row = tile0 + wave * 32 + l32;
+
+    const unsigned voff = (unsigned)(wave * XPPW * XFRAG + lane * 16);
+    const uint4_t wsrd = make_srd(p.w, FNG * XGROUP);
+    auto next_of = [&](int s) -> XNext {
+        XNext n;
+        n.ldsn = lds0 + (unsigned)((s & (XRING - 1)) * XGROUP + wave * XPPW * XFRAG);
+        n.srd = wsrd;
+        n.so = s < FNG ? (unsigned)s * XGROUP : 0x80000000u;                 // zero-fill pieces behind the last group (see the kernels above)
+        return n;
+    };
+    auto issue = [&](int s) {
+        XNext n = next_of(s);
+#pragma unroll
+        for (int i = 0; i < XPPW; ++i) dma_piece(n.srd, voff, n.so + i * XFRAG, n.ldsn + i * XFRAG);
+    };
+    XNext nx;
+    unsigned lane16 = lane * 16;
+    auto group_sync = [&](int s) -> unsigned {
+        wait_vmcnt<XPPW * (XRING - 2)>();
+        __syncthreads();
+        nx = next_of(s + XRING - 1);
+        return lds0 + (unsigned)((s & (XRING - 1)) * XGROUP) + lane16;
+    };
+#pragma unroll
+    for (int s = 0; s < XRING - 1; ++s) issue(s);
+    // ---- tables -> LDS ----------------------------------------------------------------------------------------------------------
+    if (tid < 128) {
+        *(lds_f4wptr_t)(size_t)(lds0 + XTAB + tid * 16) = ((const float4_t*)p.gamma)[tid];
+        *(lds_f4wptr_t)(size_t)(lds0 + XTAB + 2048 + tid * 16) = ((const float4_t*)p.beta)[tid];
+        *(lds_f4wptr_t)(size_t)(lds0 + XTAB + 4096 + tid * 16) = ((const float4_t*)p.down_bias)[tid];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) *(lds_f4wptr_t)(size_t)(lds0 + FTAB_UP + (k * 256 + tid) * 16) = ((const float4_t*)p.up_bias)[k * 256 + tid];
+    // ---- LayerNorm statistics (first read), operand fragments + accumulators (second read): as in the kernels above -------------------
+    const float* xr = p.x + row * XC + 4 * hi;
+    const float c0 = p.x[row * XC];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int jb = 0; jb < 16; jb += 8) {
+#pragma unroll
+        for (int j = jb; j < jb + 8; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4_t v = *(const float4_t*)(xr + 32 * j + 8 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const float d = v[i] - c0; s1 += d; s2 += d * d; }
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    s1 += swap32(s1); s2 += swap32(s2);
+    const float m1 = s1 * (1.0f / XC);
+    const float mean = c0 + m1;
+    const float rstd = rsqrtf(fmaxf(s2 * (1.0f / XC) - m1 * m1, 0.f) + p.eps);
+    __syncthreads();                                        // tables visible
+    half8_t xn[32];
+    static_for<16>([&](auto J) {
+        constexpr int j = J;
+        static_for<4>([&](auto Q) {
+            constexpr int q = Q;
+            const float4_t v = *(const float4_t*)(xr + 32 * j + 8 * q);
+            const unsigned ta = lds0 + XTAB + (32 * j + 8 * q + 4 * hi) * 4;
+            const float4_t g = lds_f4(ta), be = lds_f4(ta + 2048), bo = lds_f4(ta + 4096);
+            static_for<4>([&](auto I) {
+                constexpr int i = I;
+                xn[2 * j + (q >> 1)][4 * (q & 1) + i] = (half_t)((v[i] - mean) * rstd * g[i] + be[i]);
+                acc_set<16 * j + 4 * q + i>(v[i] + bo[i]);  // out = (x + b_down) + sum over slices
+            });
+        });
+        if ((j & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+    });
+
+    // ---- slices ------------------------------------------------------------------------------------------------------------------
+    {
+        int lane2;                                          // (fresh lane id: see the kernels above)
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\nv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane2));
+        const int hi2 = lane2 >> 5;
+        lane16 = (unsigned)lane2 * 16;
+#pragma unroll 1
+        for (int c = 0; c < FSLICES; ++c) {
+            half8_t t0, t1, t2, t3, t4, t5;
+            const int sg = c * FGPS;
+            // value^T (q0), gate^T (q1) [32 ch][32 tokens] = W_up[value / gate rows of the slice] . Xn^T
+            float16_t q0, q1;
+            {
+                const unsigned st = group_sync(sg);
+                asm volatile(XG_WQ_FIRST : [q0] "=&v"(q0), [q1] "=&v"(q1), XTMP_OUT
+                             : [st] "v"(st), [b0] "v"(xn[0]), [b1] "v"(xn[1]), [b2] "v"(xn[2]), [b3] "v"(xn[3]), [b4] "v"(xn[4]), [b5] "v"(xn[5]),
+                               [b6] "v"(xn[6]), [b7] "v"(xn[7]), [b8] "v"(xn[8]), [b9] "v"(xn[9]), [b10] "v"(xn[10]), [b11] "v"(xn[11]),
+                               [b12] "v"(xn[12]), [b13] "v"(xn[13]), [b14] "v"(xn[14]), [b15] "v"(xn[15]), XDMA_IN : "memory", "scc");
+            }
+            {
+                const unsigned st = group_sync(sg + 1);
+                asm volatile(XG_WQ : [q0] "+v"(q0), [q1] "+v"(q1), XTMP_OUT
+                             : [st] "v"(st), [b0] "v"(xn[16]), [b1] "v"(xn[17]), [b2] "v"(xn[18]), [b3] "v"(xn[19]), [b4] "v"(xn[20]), [b5] "v"(xn[21]),
+                               [b6] "v"(xn[22]), [b7] "v"(xn[23]), [b8] "v"(xn[24]), [b9] "v"(xn[25]), [b10] "v"(xn[26]), [b11] "v"(xn[27]),
+                               [b12] "v"(xn[28]), [b13] "v"(xn[29]), [b14] "v"(xn[30]), [b15] "v"(xn[31]), XDMA_IN : "memory", "scc");
+            }
+            // GEGLU on the D layout: register r <-> hidden channel 32 c + (r & 3) + 8 (r >> 2) + 4 hi; fp16 = the B fragments of the down
+            // step (k-step r >> 3)
+            half8_t of[2];
+            const unsigned ub = lds0 + FTAB_UP + (32 * c + 4 * hi2) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4_t bv = lds_f4(ub + 32 * q), bg = lds_f4(ub + FINNER * 4 + 32 * q);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int r = 4 * q + i;
+                    of[q >> 1][4 * (q & 1) + i] = (half_t)((q0[r] + bv[i]) * uav_gelu_erf(q1[r] + bg[i]));
+                }
+            }
+            // acc [512 ch][32 tokens] += W_down[:, slice c] . H^T
+            {
+                const unsigned st = group_sync(sg + 2);
+                asm volatile(XG_WD32 : XTMP_OUT : [st] "v"(st), [b0] "v"(of[0]), [b1] "v"(of[1]), XDMA_IN : "memory", "scc", XACC_CLOBBERS);
+            }
+        }
+    }
+    asm volatile("s_nop 15\ns_nop 15" ::: "memory");
+    wait_vmcnt<0>();
+    __syncthreads();                                        // every wave is done reading fragments: the ring is free
+    // ---- store: row-coalesced through the idle ring (see xattn_sublayer_kernel); the hi | lo pair the same way, 8-B pieces ---------------
+    {
+        int lane_;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\nv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane_));
+        const int ln = lane_, l32e = lane_ & 31, hie = lane_ >> 5;
+        const unsigned wbuf = (unsigned)(size_t)(lptr_t)smem + (unsigned)(wave * XGROUP);
+        if (p.out_hilo) {
+            typedef __attribute__((address_space(3))) uint2_t* lds_u2wptr_t;
+#pragma unroll
+            for (int part = 0; part < 2; ++part) {          // hi = fp16(v), then lo = fp16(v - hi): each 32 rows x 1 KiB in the wave's ring quarter
+                static_for<64>([&](auto JQ) {
+                    constexpr int j = JQ / 4, q = JQ % 4;
+                    float v[4] = {acc_get<16 * j + 4 * q>(), acc_get<16 * j + 4 * q + 1>(), acc_get<16 * j + 4 * q + 2>(), acc_get<16 * j + 4 * q + 3>()};
+                    if (part) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) v[i] = v[i] - (float)(half_t)v[i];
+                    }
+                    const uint2_t h = {pack_h2f(v[0], v[1]), pack_h2f(v[2], v[3])};
+                    const int pc8 = 8 * j + 2 * q + hie;
+                    *(lds_u2wptr_t)(size_t)(wbuf + l32e * 1024 + ((((pc8 >> 1) ^ (l32e & 7)) << 4) | ((pc8 & 1) << 3))) = h;
+                });
+                asm volatile("" ::: "memory");
+                half_t* const nbase = p.out_hilo + (tile0 + wave * 32) * (2 * XC) + part * XC + ln * 8;
+#pragma unroll
+                for (int kb = 0; kb < 32; kb += 8) {
+                    float4_t r[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) r[k] = lds_f4(wbuf + (kb + k) * 1024 + ((ln ^ ((kb + k) & 7)) << 4));
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) *(float4_t*)(nbase + (long long)(kb + k) * (2 * XC)) = r[k];
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+        if (p.out) {
+            float* const obase = p.out + (tile0 + wave * 32) * XC + ln * 4;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                static_for<32>([&](auto JQ) {
+                    constexpr int j = JQ / 4, q = JQ % 4;
+                    float4_t v;
+                    if (hh == 0) v = float4_t{acc_get<16 * j + 4 * q>(), acc_get<16 * j + 4 * q + 1>(), acc_get<16 * j + 4 * q + 2>(), acc_get<16 * j + 4 * q + 3>()};
+                    else v = float4_t{acc_get<128 + 16 * j + 4 * q>(), acc_get<128 + 16 * j + 4 * q + 1>(), acc_get<128 + 16 * j + 4 * q + 2>(), acc_get<128 + 16 * j + 4 * q + 3>()};
+                    const int pc = 8 * j + 2 * q + hie;
+                    *(lds_f4wptr_t)(size_t)(wbuf + l32e * 1024 + ((pc ^ (l32e & 7)) << 4)) = v;
+                });
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int kb = 0; kb < 32; kb += 8) {
+                    float4_t r[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) r[k] = lds_f4(wbuf + (kb + k) * 1024 + ((ln ^ ((kb + k) & 7)) << 4));
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) *(float4_t*)(obase + (long long)(kb + k) * XC + hh * 256) = r[k];
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
+}
+
 // Text K | V rows [n_batch * lk][stride] (fp16, head h in columns 64 h ..) -> the fragment stream of the kernel above:
 // [n_batch][8 heads][32 fragments][64 lanes][8 halves]; fragments 0 .. 11 = K_h (key tile f % 3, k-step f / 3), 12 .. 23 = V_h^T
 // (k-step g >> 1, channel tile g & 1, g = f - 12); keys >= lk and the 8 spare fragments are zero.
@@ -1031,6 +1260,18 @@ extern "C" int uav_block_attn_sublayers_f32(const float* x, float* out, const ua
                                             const uav_tattn_params* temporal, int32_t n_batch, int32_t t_len, int64_t hw, int32_t channels,
                                             int32_t heads, float temporal_scale, void* stream) {
     return tattn_launch(x, out, cross, 2, lk, cross_scale, temporal, n_batch, t_len, hw, channels, heads, temporal_scale, stream);
+}
+
+extern "C" int uav_ff_sublayer_f32(const float* x, float* out, void* out_hilo, const uav_ff_params* q, int64_t rows, int32_t channels,
+                                   int32_t inner, void* stream) {
+    if (!x || !q || (!out && !out_hilo) || !q->ln_gamma || !q->ln_beta || !q->w_packed || !q->up_bias || !q->down_bias) return UAV_EINVAL;
+    if (channels != XC || inner != FINNER || rows <= 0 || (rows % 128) || rows / 128 >= (1ll << 31)) return UAV_ESHAPE;
+    if (((size_t)x | (size_t)out | (size_t)out_hilo | (size_t)q->up_bias | (size_t)q->down_bias | (size_t)q->w_packed) & 15) return UAV_EALIGN;
+    FfArgs a{x, out, (half_t*)out_hilo, q->ln_gamma, q->ln_beta, q->down_bias, q->up_bias, (const char*)q->w_packed, q->ln_eps};
+    static UavDynLds lds;
+    if (int rc = uav_set_dyn_lds(lds, (const void*)ff_sublayer_kernel, FSMEM)) return rc;
+    hipLaunchKernelGGL(ff_sublayer_kernel, dim3((unsigned)(rows / 128)), dim3(256), FSMEM, (hipStream_t)stream, a);
+    return uav_launch_status();
 }
 
 #ifdef UAV_DEV_KERNELS

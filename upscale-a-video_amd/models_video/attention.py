@@ -214,8 +214,24 @@ class FeedForward(E.EngineModule):
         inner = int(dim * mult)
         self.net = nn.ModuleList([GEGLU(dim, inner), nn.Dropout(dropout), nn.Linear(inner, dim_out or dim)])
 
+    def fused_params(self, x, ln):
+        """(gamma, beta, eps, packed W_up | W_down fragments, b_up, b_down) for the fused feed-forward kernel (ops.ff_sublayer), or None where it
+        does not apply (fp32 stream of 512 channels, 2 048 hidden channels, whole 128-row tiles)."""
+        up, down = self.net[0].proj, self.net[2]
+        if (ln is None or not E.FF_FUSED or E.LN_FOLD or up.bias is None or down.bias is None or up.out_features != 2 * down.in_features
+                or not ops.ff_ok(x, inner=down.in_features)):
+            return None
+        dev = E._dev(up.weight)
+        w = self._cache().get(("ff", "w"), lambda: ops.pack_ff_weights(up.weight, down.weight, dev), (up.weight, down.weight))
+        return (E.f32_param(self, "ff.g", ln.weight), E.f32_param(self, "ff.b", ln.bias), ln.eps, w,
+                E.f32_param(self, "ff.ub", up.bias), E.f32_param(self, "ff.db", down.bias))
+
     def run(self, x, residual, out_f32=None, ln=None, out_hilo=False):
         """out_hilo (fp32 stream): the fp32 sum leaves as the fp16 hi | lo operand pair of proj_out ([M][2 C], engine.tail_hilo)."""
+        if residual is x and out_f32 is not False:
+            fp = self.fused_params(x, ln)
+            if fp is not None:      # the whole sub-layer in one launch (csrc/xattn_fused.hip, ff_sublayer_kernel)
+                return ops.ff_sublayer(x, *fp, out_f32=not out_hilo, out_hilo=out_hilo)
         h = ops.linear(x, E.packed_conv(self, "up", self.net[0].proj, geglu=True)) if ln is None else \
             E.ln_linear(self, "up", ln, x, [self.net[0].proj], geglu=True)
         if out_hilo:
@@ -277,6 +293,8 @@ class BasicTransformerBlock(E.EngineModule):
         if self.attn2 is not None:
             k, v, kvp = self._text_kv(self.attn2, ehs_rows, "a2", n_text)
             t2 = (k, v, n_text, kvp)
+        # (the feed-forward as one launch does its own LayerNorm: norm3 is then not asked of the attention kernels' epilogue)
+        ff_fused = out_f32 is not False and self.ff.fused_params(x, self.norm3) is not None
         pair = None
         if t1 is not None and t2 is not None and E.XATTN_PAIR:
             # attn1 (only_cross_attention) and attn2 are both text cross-attention: ONE launch for the two sub-layers, the rows between
@@ -292,7 +310,7 @@ class BasicTransformerBlock(E.EngineModule):
             if tp is not None:
                 # (+ norm3 of the finished rows for the feed-forward: the same parameter tensors FeedForward.run -> engine.ln_linear looks up)
                 nxt = (E.f32_param(self.ff, "up.ln.g", self.norm3.weight), E.f32_param(self.ff, "up.ln.b", self.norm3.bias), self.norm3.eps) \
-                    if E.NEXT_LN else None
+                    if E.NEXT_LN and not ff_fused else None
                 x = ops.block_attn_sublayers(x, list(pair), tp, n_batch=g.b, t_len=g.t, hw=g.hw, lk=n_text, cross_scale=self.attn1.scale,
                                              temporal_scale=self.attn_temporal.scale, next_ln=nxt)
                 return self.ff.run(x, x, out_f32, ln=self.norm3, out_hilo=out_hilo)
@@ -305,7 +323,8 @@ class BasicTransformerBlock(E.EngineModule):
                 x = self.attn1.run(x, x, bq=bq, lq=lq, ln=self.norm1)
             if t2 is not None:
                 x = self.attn2.run(x, x, bq=bq, lq=lq, text=t2, q_per_kv=g.t, ln=self.norm2)
-        nxt = (E.f32_param(self.ff, "up.ln.g", self.norm3.weight), E.f32_param(self.ff, "up.ln.b", self.norm3.bias), self.norm3.eps) if E.NEXT_LN else None
+        nxt = (E.f32_param(self.ff, "up.ln.g", self.norm3.weight), E.f32_param(self.ff, "up.ln.b", self.norm3.bias), self.norm3.eps) \
+            if E.NEXT_LN and not ff_fused else None
         x = self.attn_temporal.run_temporal(x, x, g, ln=self.norm_temporal, next_ln=nxt)
         return self.ff.run(x, x, out_f32, ln=self.norm3, out_hilo=out_hilo)
 

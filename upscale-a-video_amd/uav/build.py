@@ -83,12 +83,14 @@ def _build_locked(objdir, verbose):
         return obj
 
     with ThreadPoolExecutor(max_workers=8) as ex:
+        asm_jobs = {f: ex.submit(_device_assembly, f) for f in NAMED_ACC_KERNELS}      # the audit's `hipcc -S` runs beside the compiles
         objs = list(ex.map(cc, sources()))
+        asm = {f: j.result() for f, j in asm_jobs.items()}
     cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    audit_accumulator_file()
+    audit_accumulator_file(asm)
     audit_conv_scratch()
     audit_no_scratch()
     with open(STAMP, "w") as fh:
@@ -98,23 +100,34 @@ def _build_locked(objdir, verbose):
     return LIB
 
 
-def audit_accumulator_file():
-    """attn512w_kernel (csrc/attention.hip), xattn_sublayer_kernel and tattn_sublayer_kernel (csrc/xattn_fused.hip) keep their 256 fp32 accumulators in
-    a[0:255] BY NAME from inline asm.  That is only sound while hipcc itself never touches the accumulator file in those kernels
-    (it would treat the registers as free between our statements): compile the file to assembly and fail the build if any
-    compiler-generated instruction of the kernel names an AGPR."""
-    _audit_named_accumulators("attention.hip", "attn512w_kernel")
-    _audit_named_accumulators("xattn_fused.hip", "xattn_sublayer_kernelILi0E")
-    _audit_named_accumulators("xattn_fused.hip", "tattn_sublayer_kernelILi0E")
-    _audit_named_accumulators("xattn_fused.hip", "tattn_sublayer_kernelILi2E")
+NAMED_ACC_KERNELS = {"attention.hip": ["attn512w_kernel"],
+                     "xattn_fused.hip": ["xattn_sublayer_kernelILi0E", "tattn_sublayer_kernelILi0E", "tattn_sublayer_kernelILi2E", "ff_sublayer_kernel"]}
 
 
-def _audit_named_accumulators(fname, kernel):
+def audit_accumulator_file(asm=None):
+    """attn512w_kernel (csrc/attention.hip), xattn_sublayer_kernel, tattn_sublayer_kernel and ff_sublayer_kernel (csrc/xattn_fused.hip) keep their
+    256 fp32 accumulators in a[0:255] BY NAME from inline asm.  That is only sound while hipcc itself never touches the accumulator file in
+    those kernels (it would treat the registers as free between our statements): compile the file to assembly (once per file: `asm` =
+    {file: text} when the caller already did) and fail the build if any compiler-generated instruction of the kernel names an AGPR."""
+    if asm is None:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(len(NAMED_ACC_KERNELS)) as ex:
+            asm = dict(zip(NAMED_ACC_KERNELS, ex.map(_device_assembly, NAMED_ACC_KERNELS)))
+    for fname, kernels in NAMED_ACC_KERNELS.items():
+        for k in kernels:
+            _audit_named_accumulators(fname, k, asm[fname])
+
+
+def _device_assembly(fname):
     src = os.path.join(CSRC, fname)
     r = subprocess.run([HIPCC] + FLAGS + ["-S", "--cuda-device-only", "-o", "-", src], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc -S failed on {src}:\n{r.stderr}")
-    lines = r.stdout.splitlines()
+    return r.stdout
+
+
+def _audit_named_accumulators(fname, kernel, text):
+    lines = text.splitlines()
     inside = in_asm = False
     bad = []
     asm_blocks = 0

@@ -673,6 +673,56 @@ def pack_xattn_weight(weight, kind, device=None):
     return out.to(device if device is not None else weight.device)
 
 
+FF_INNER = 2048
+
+
+def pack_ff_weights(w_up, w_down, device=None):
+    """GEGLU proj weight [4096][512] (value rows | gate rows) and the down Linear weight [512][2048] -> the fragment stream of the fused
+    feed-forward kernel (csrc/xattn_fused.hip ff_sublayer_kernel): per slice c of 32 hidden channels 96 KiB — 64 KiB of 'q' fragments
+    (k-step, channel tile: tile 0 = value rows 32 c .., tile 1 = gate rows 2048 + 32 c ..) and 32 KiB of 'out' fragments of columns
+    32 c .. of w_down (fragment g = (channel tile 2 (g >> 2) + (g & 1), k-step (g >> 1) & 1))."""
+    wu, wd = w_up.detach().float(), w_down.detach().float()
+    if tuple(wu.shape) != (2 * FF_INNER, XATTN_C) or tuple(wd.shape) != (XATTN_C, FF_INNER):
+        raise _lib.UavError(f"fused feed-forward weights must be {2 * FF_INNER}x{XATTN_C} / {XATTN_C}x{FF_INNER}, got {tuple(wu.shape)} / {tuple(wd.shape)}")
+    ns = FF_INNER // 32
+    # rows = (vg, c, l32); k = (ks, e2, hi, e1)  ->  [c][ks][vg][hi][l32][e2][e1]
+    u = wu.reshape(2, ns, 32, 32, 2, 2, 4).permute(1, 3, 0, 5, 2, 4, 6).reshape(ns, -1)
+    # rows = (npair, par, l32); k = (c, ks, e2, hi, e1)  ->  [c][npair][ks][par][hi][l32][e2][e1]
+    d = wd.reshape(8, 2, 32, ns, 2, 2, 2, 4).permute(3, 0, 4, 1, 6, 2, 5, 7).reshape(ns, -1)
+    out = torch.cat([u, d], dim=1).contiguous().to(HALF).reshape(-1)
+    assert out.numel() == 3 * FF_INNER * XATTN_C
+    return out.to(device if device is not None else w_up.device)
+
+
+def ff_ok(x, *, inner):
+    """Shapes the fused feed-forward kernel takes."""
+    return x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == XATTN_C and inner == FF_INNER and x.shape[0] % XATTN_TILE == 0
+
+
+def ff_sublayer(x, gamma, beta, eps, w_packed, up_bias, down_bias, *, out_f32=True, out_hilo=False):
+    """x + down(GEGLU(up(LayerNorm(x)))) on fp32 stream rows [M][512] in one launch.  Returns the fp32 rows, or (out_hilo) their fp16
+    hi | lo operand pair [M][1024] (cast_hilo's layout), or (both flags) the tuple (rows, pair)."""
+    lib = _lib.load()
+    _req(x, torch.float32, "x")
+    m = x.shape[0]
+    if not (out_f32 or out_hilo):
+        raise _lib.UavError("ff_sublayer: nothing to write")
+    y = torch.empty_like(x) if out_f32 else None
+    yh = torch.empty((m, 2 * XATTN_C), dtype=HALF, device=x.device) if out_hilo else None
+    q = _lib.FfParams()
+    q.ln_gamma, q.ln_beta, q.ln_eps = _p(gamma), _p(beta), float(eps)
+    q.w_packed, q.up_bias, q.down_bias = _p(w_packed), _p(up_bias), _p(down_bias)
+    ev = PROFILER.begin("ff_sublayer")
+    rc = lib.uav_ff_sublayer_f32(_p(x), _p(y) if y is not None else None, _p(yh) if yh is not None else None, C.byref(q), m, XATTN_C, FF_INNER,
+                                 _stream())
+    _lib.check(rc, "uav_ff_sublayer_f32")
+    PROFILER.end(ev, "ff_sublayer" if not PROFILER.detail else f"ff_sublayer M={m}", 2.0 * m * XATTN_C * 3 * FF_INNER,
+                 4.0 * m * XATTN_C * (1 + (1 if out_f32 else 0) + (1 if out_hilo else 0)))
+    if out_f32 and out_hilo:
+        return y, yh
+    return y if out_f32 else yh
+
+
 def xattn_pack_kv(k, v, *, n_batch, lk, k_stride=None, v_stride=None):
     """Text K / V rows (fp16 views of the fused k|v projection) -> fragment stream [n_batch][8][32 KiB]."""
     lib = _lib.load()
