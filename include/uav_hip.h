@@ -62,9 +62,10 @@ int  uav_device_check(int dev, char* name_out);
 #define UAV_CONV_GELU       256u /* out = gelu_erf(conv + bias + rowbias) (+ residual) * scale  (CLIP ViT-H MLP) */
 #define UAV_CONV_QUICK_GELU 512u /* x * sigmoid(1.702 x) (OpenAI CLIP MLP) */
 #define UAV_CONV_RES_F32  128u /* `residual` is fp32 [M][res_stride] (fp32 residual stream of the VAE decoder) */
-/* Round 5: 1x1 / stride-1 launches with K = c1 + c2 <= 1024 and n a multiple of 256 run in the short-K kernel (128 x 256
- * tile, two workgroups per CU, attention.py:523-564 / resnet.py:286-292) — same results bit for bit.  This flag keeps such a
- * launch in the general 256x256 kernel (A/B measurements and the bit-identity test). */
+/* Round 5's short-K kernel (1x1 / stride-1 launches with K = c1 + c2 <= 1024 and n a multiple of 256: 128 x 256 tile, two workgroups per
+ * CU) is a DEVELOPMENT kernel since round 6: it is compiled only into tools/ab/libuav_hip_dev.so (-DUAV_DEV_KERNELS) and even there off
+ * unless UAV_CONV_SK=1 — the product library runs these launches in the four-wave kernel (and the 512-channel transformer sub-layers in
+ * the fused kernels below).  The flag keeps a launch out of the short-K kernel where that kernel exists; the product ignores it. */
 #define UAV_CONV_NO_SHORTK 1024u
 /* Round 5: launches of the 256x256-tile class run in the four-wave kernel (conv_gemm256w_kernel: one wave per SIMD, 128 x 128 wave
  * tiles, accumulators in the accumulator file) — same results bit for bit as the 8-wave kernel.  This flag keeps a launch in the
