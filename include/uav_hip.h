@@ -304,6 +304,12 @@ typedef struct uav_ff_params {
 } uav_ff_params;
 int uav_ff_sublayer_f32(const float* x, float* out, void* out_hilo, const uav_ff_params* p, int64_t rows, int32_t channels,
                         int32_t inner, void* stream);
+/* The WHOLE BasicTransformerBlock (attention.py:523-564: attn1 -> attn2 -> attn_temporal -> ff, only_cross_attention) in ONE launch: the
+ * stream is read once; `out` (fp32 rows, may be NULL) and / or `out_hilo` (fp16 hi | lo pair, see uav_ff_sublayer_f32) are written once.
+ * Same shape contract as uav_block_attn_sublayers_f32; temporal->next_ln_out must be NULL; inner must be 2048. */
+int uav_block_sublayers_f32(const float* x, float* out, void* out_hilo, const uav_xattn_params* cross, int32_t lk, float cross_scale,
+                            const uav_tattn_params* temporal, const uav_ff_params* ff, int32_t n_batch, int32_t t_len, int64_t hw,
+                            int32_t channels, int32_t heads, int32_t inner, float temporal_scale, void* stream);
 /* k, v: fp16 rows [n_batch * lk][stride] (head h in columns h*head_dim ..) -> out: n_batch * heads * 32 KiB */
 int uav_xattn_pack_kv(const void* k, int64_t k_stride, const void* v, int64_t v_stride, int32_t n_batch, int32_t lk,
                       int32_t heads, int32_t head_dim, void* out, void* stream);

@@ -393,6 +393,11 @@ def ff_sublayer(x, gamma, beta, eps, w_packed, up_bias, down_bias, *, out_f32=Tr
     return y if out_f32 else cast_hilo(y)
 
 
+def block_sublayers(x, cross, temporal, ff, *, n_batch, t_len, hw, lk, cross_scale, temporal_scale, out_f32=True, out_hilo=False):
+    y = block_attn_sublayers(x, cross, temporal, n_batch=n_batch, t_len=t_len, hw=hw, lk=lk, cross_scale=cross_scale, temporal_scale=temporal_scale)
+    return ff_sublayer(y, *ff, out_f32=out_f32, out_hilo=out_hilo)
+
+
 def cast_f16(x):
     return x if x.dtype == HALF else _h(x)
 
@@ -409,7 +414,7 @@ def sft_fuse(dec, scale, shift, w, out_f32=False):
     return y if out_f32 else _h(y)
 
 
-_OPS = ("ln_fold_ok", "resize_area_f32", "cast_f16", "cast_hilo", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "xattn_pack_kv", "xattn_sublayer", "xattn_sublayers", "tattn_sublayer", "block_attn_sublayers", "ff_sublayer", "temporal_attention", "linear_small",
+_OPS = ("ln_fold_ok", "resize_area_f32", "cast_f16", "cast_hilo", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "xattn_pack_kv", "xattn_sublayer", "xattn_sublayers", "tattn_sublayer", "block_attn_sublayers", "block_sublayers", "ff_sublayer", "temporal_attention", "linear_small",
         "timestep_embedding", "pack_nhwc", "unpack_ncthw", "axpby", "cfg_ddim_v0", "ddim_vt")
 
 

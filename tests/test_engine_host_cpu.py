@@ -464,3 +464,14 @@ def test_transformer_block_fused_feed_forward_host_side(cpu_engine):
     assert y1.dtype == y0.dtype == torch.float32 and h1.dtype == h0.dtype == torch.float16 and h1.shape == (geom.rows, 1024)
     assert rel_l2(y1, y0) < 2e-4                                # the two forms on the CPU: fp32 summation order only
     assert torch.equal(h1, ops.cast_hilo(y1))
+    # ... and the whole block as one launch on / off (ops.block_sublayers against the attention launch + the feed-forward launch)
+    oldb = E.BLOCK_FF_FUSED
+    try:
+        E.BLOCK_FF_FUSED = False
+        E.invalidate_packed(blk)
+        with torch.no_grad():
+            y2, h2 = blk.run(x.clone(), geom, ehs, 7), blk.run(x.clone(), geom, ehs, 7, out_hilo=True)
+    finally:
+        E.BLOCK_FF_FUSED = oldb
+        E.invalidate_packed(blk)
+    assert torch.equal(y2, y1) and torch.equal(h2, h1)          # the stand-ins compose the same arithmetic

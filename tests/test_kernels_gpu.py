@@ -1304,3 +1304,52 @@ def test_transformer_block_with_fused_feed_forward_matches_three_launch_chain(op
     e = rel_l2(y1, y0)
     assert e < 5e-4, e
     assert torch.equal(h1, ops.cast_hilo(y1)) and torch.equal(h0, ops.cast_hilo(y0))
+
+
+@pytest.mark.parametrize("mode", ["f32", "hilo", "both"])
+def test_whole_transformer_block_in_one_launch_equals_attention_launch_then_feed_forward_launch(ops, dev, mode):
+    """uav_block_sublayers_f32 (attn1 -> attn2 -> attn_temporal -> ff of a BasicTransformerBlock in one launch, attention.py:523-564) against
+    the three-attention launch followed by the feed-forward launch on the same rows; the hi | lo pair is cast_hilo of the fp32 rows."""
+    g = torch.Generator().manual_seed(123)
+    C, H, D, T, nb, hh, ww, lk, I = 512, 8, 64, 8, 2, 24, 16, 77, 2048
+    hw = hh * ww
+    M = nb * T * hw
+    x = (torch.randn(M, C, generator=g) * 1.3 + 0.4).to(dev)
+    cross = []
+    for _ in range(2):
+        gamma = (torch.randn(C, generator=g) * 0.2 + 1.0).to(dev); beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+        wq = h16(C, C, dev=dev, scale=C ** -0.5, gen=g); wo = h16(C, C, dev=dev, scale=C ** -0.5, gen=g)
+        bo = (torch.randn(C, generator=g) * 0.1).to(dev)
+        kv = (torch.randn(nb * lk, 2 * C, generator=g) * 1.5).half().to(dev)
+        kvp = ops.xattn_pack_kv(kv[:, :C], kv[:, C:], n_batch=nb, lk=lk, k_stride=2 * C, v_stride=2 * C)
+        cross.append((gamma, beta, 1e-5, ops.pack_xattn_weight(wq, "q", dev), kvp, ops.pack_xattn_weight(wo, "out", dev), bo))
+    gamma = (torch.randn(C, generator=g) * 0.2 + 1.0).to(dev); beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+    ws = [h16(C, C, dev=dev, scale=C ** -0.5, gen=g) for _ in range(4)]
+    bo = (torch.randn(C, generator=g) * 0.1).to(dev)
+    relb = (torch.randn(H, T, T, generator=g) * 0.5).to(dev).contiguous()
+    fr = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    ang = torch.arange(T).float()[:, None] * fr[None, :]
+    cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
+    temporal = (gamma, beta, 1e-5, *[ops.pack_xattn_weight(w_, "q", dev) for w_ in ws[:3]], ops.pack_xattn_weight(ws[3], "out", dev), bo, relb, cos, sin, 32)
+    g3 = (torch.randn(C, generator=g) * 0.2 + 1.0).to(dev); b3 = (torch.randn(C, generator=g) * 0.1).to(dev)
+    wu = h16(2 * I, C, dev=dev, scale=C ** -0.5, gen=g); wd = h16(C, I, dev=dev, scale=I ** -0.5, gen=g)
+    bu = (torch.randn(2 * I, generator=g) * 0.2).to(dev); bd = (torch.randn(C, generator=g) * 0.1).to(dev)
+    ff = (g3, b3, 1e-5, ops.pack_ff_weights(wu, wd, dev), bu, bd)
+    scale = D ** -0.5
+    kw = dict(n_batch=nb, t_len=T, hw=hw, lk=lk, cross_scale=scale, temporal_scale=scale)
+    y3 = ops.block_attn_sublayers(x, cross, temporal, **kw)
+    y4 = ops.ff_sublayer(y3, *ff)
+    r = ops.block_sublayers(x, cross, temporal, ff, out_f32=mode != "hilo", out_hilo=mode != "f32", **kw)
+    y, yh = (r, None) if mode == "f32" else (None, r) if mode == "hilo" else r
+    if y is not None:
+        assert bool(torch.isfinite(y).all())
+        e, e_upd = rel_l2(y, y4), rel_l2(y - x, y4 - x)
+        assert e < 1e-4 and e_upd < 1.5e-3, (e, e_upd)        # the feed-forward's LayerNorm statistics from the accumulators vs from its own first read
+    if yh is not None:
+        assert yh.shape == (M, 2 * C) and yh.dtype == torch.float16
+        if y is not None:
+            assert torch.equal(yh, ops.cast_hilo(y))
+        else:
+            assert rel_l2(yh[:, :C].float() + yh[:, C:].float(), y4) < 1e-4
+    r2 = ops.block_sublayers(x, cross, temporal, ff, out_f32=mode != "hilo", out_hilo=mode != "f32", **kw)
+    assert all(torch.equal(a, b) for a, b in zip(r if isinstance(r, tuple) else (r,), r2 if isinstance(r2, tuple) else (r2,)))

@@ -10,7 +10,7 @@
 R=$(cd "$(dirname "$0")/../.." && pwd)
 set -e
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -Wno-comment -Wno-unused-function -DUAV_DEV_KERNELS"
-/opt/rocm/bin/hipcc $F -shared -o $R/tools/ab/libuav_xattn_dev.so $R/upscale-a-video_amd/csrc/xattn_fused.hip
+/opt/rocm/bin/hipcc $F -I$R/include -shared -o $R/tools/ab/libuav_xattn_dev.so $R/upscale-a-video_amd/csrc/xattn_fused.hip
 echo built $R/tools/ab/libuav_xattn_dev.so
 if [ "$1" = "all" ]; then
   mkdir -p /tmp/uav_dev_obj

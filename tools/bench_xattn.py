@@ -106,8 +106,17 @@ def tcase(name, nb, hh, ww):
     def pair(): st["p"] = ops.xattn_sublayers(x, [xs, xs], rows_per_kv=T * hw, lk=LK, scale=scale)
     def block(): st["b"] = ops.block_attn_sublayers(x, [xs, xs], tp, n_batch=nb, t_len=T, hw=hw, lk=LK, cross_scale=scale, temporal_scale=scale)
 
-    fns = {"fused": fused, "cross_pair": pair, "block_of_three": block, "chain": chain, "layernorm": ln, "qkv": qkv, "temporal_attention": att, "to_out": out}
-    chain(); fused(); pair(); block(); chain(); fused()
+    I = 2048
+    wu = (torch.randn(2 * I, C, generator=g) * C ** -0.5).half().float().to(dev); wd = (torch.randn(C, I, generator=g) * I ** -0.5).half().float().to(dev)
+    bu = (torch.randn(2 * I, generator=g) * 0.2).to(dev); bd = (torch.randn(C, generator=g) * 0.1).to(dev)
+    ffp = (gamma, beta, 1e-5, ops.pack_ff_weights(wu, wd, dev), bu, bd)
+    def ff(): st["ff"] = ops.ff_sublayer(st["b"], *ffp)
+    def whole(): st["w"] = ops.block_sublayers(x, [xs, xs], tp, ffp, n_batch=nb, t_len=T, hw=hw, lk=LK, cross_scale=scale, temporal_scale=scale)
+    def whole_hilo(): st["wh"] = ops.block_sublayers(x, [xs, xs], tp, ffp, n_batch=nb, t_len=T, hw=hw, lk=LK, cross_scale=scale, temporal_scale=scale,
+                                                     out_f32=False, out_hilo=True)
+
+    fns = {"fused": fused, "cross_pair": pair, "block_of_three": block, "feed_forward": ff, "whole_block": whole, "whole_block_hilo_out": whole_hilo, "chain": chain, "layernorm": ln, "qkv": qkv, "temporal_attention": att, "to_out": out}
+    chain(); fused(); pair(); block(); ff(); whole(); whole_hilo(); chain(); fused()
     torch.cuda.synchronize()
     t = {kk: [] for kk in fns}
     for _ in range(ROUNDS):

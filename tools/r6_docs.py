@@ -48,6 +48,10 @@ peak, {N['n_tests']} GPU tests + smoke green.
 | 4, 5 | block tails as hi \\| lo pairs from the producer's epilogue (`UAV_CONV_OUT_HILO`), default on; T = 32 parity (`r06_parity_headline_tail_hilo_on_run4.jsonl`, `r06_parity_configs3_t32_320x320_30steps_vs_gpu_oracle_run5.jsonl`, `r06_parity_full_suite_run5_*.jsonl`, `r06_bench1_run5_*.json`) | bit-identical to fp32 result + cast pass (after keeping hipcc from contracting `v·scale − hi` into one fma); headline 8.2e-4 / 9.5e-4 / 1.23e-3 → **7.3e-4 / 8.7e-4 / 1.12e-3**, full-width forward 8.5e-4 → 6.5e-4, configs[0] 1.55e-3 → 1.25e-3, tiled 30-step fixture 1.25e-3 → 1.12e-3; 1.1484 → 1.1352 frames/s (−1.2 %) same box; **T = 32 at 320²: latents 7.0e-4, `.images` 8.5e-4 / 1.09e-3**, 35.3 s serial, 34.2 s with the windows on two streams (bit-identical) |
 | 6 | two cross-attention sub-layers in one launch: accumulators by NAME in the accumulator file, second LayerNorm on them (`r06_bench1_run6_cross_pair_fused.json`) | pair 1.40 ms against 2 × 0.90 single / 2 × 1.22 chain at M = 409 600; clip **1.158**; as C++ tuples that asm statements hold as `"+a"` AND the VALU reads, the accumulators cost 34 … 1 679 spilled registers per lane — by name, 0 |
 | 7 | temporal sub-layer kernel (`r06_fused_sublayers_vs_chains_run7_cross_pair_and_temporal.jsonl`, `r06_bench1_run7_*.json`, `r06_tests_gpu_suite_and_smoke_run7.log`) | all four cases green on the first run; **1.14 ms against 1.85 ms** (LayerNorm 0.23 + q\\|k\\|v 0.83 + attention 0.34 + to_out 0.45) at M = 409 600, 0.35 / 0.53 at 102 400; clip **1.193 frames/s**, conv 0.371; 214 GPU tests + smoke |
+| 8 | block kernel: attn1 → attn2 → attn_temporal of a block in one launch (`r06_fused_sublayers_vs_chains_run8_block_of_three.jsonl`, `r06_bench1_run8_block_kernel.json`) | 2.22 ms against 1.42 (pair) + 1.13 (temporal) at M = 409 600; 469 ms per clip in this class against 521; 215 GPU tests + smoke.  131 spilled registers in the first form — the temporal loop's fragments went into other registers than the cross loops' and the move between the two sets went through scratch; a second fragment array (the third LayerNorm writes `xt`, not `xn`): 0 |
+| 9, 10 | norm3 (the LayerNorm in front of the feed-forward) written by that launch's epilogue; per-shape table; PMC traffic of the conv kernels re-taken for the new sources (`r06_bench1_run9_*.json`, `r06_run10_per_shape_table_before_fused_feed_forward.txt`) | 300 LayerNorm launches per clip gone, clip **1.190**; where the clip goes now: GroupNorm apply 10.8 %, the 3×3 convs at 1.15–1.25 PFLOP/s, the block kernel 722 TFLOP/s, GEGLU 512 → 4 096 still 704 TFLOP/s (2.44 ms a launch) and 2 048 → 512 890: the feed-forward is the worst class left |
+| 11, 12 | feed-forward sub-layer kernel (`r06_fused_feed_forward_vs_three_launch_chain_run11.jsonl`, `r06_bench1_run12_ab_feed_forward_fused_{on,on_repeat,off}.json`, `r06_tests_gpu_suite_and_smoke_run12.log`, `r06_parity_full_suite_run12_fused_feed_forward.jsonl`) | every kernel test green on the first run; **2.80 ms against 3.60** (LayerNorm 0.22 + GEGLU GEMM 2.46 + down GEMM 0.98) at M = 409 600 = 921 against 717 TFLOP/s, 0.84 / 0.96 at 102 400 (800 tiles on 256 CUs: 3.1 rounds); same-box A/B **1.172 → 1.201 / 1.202 frames/s (+2.5 %)**; 221 GPU tests + smoke; headline parity unchanged (latents 7.30e-4, `.images` 8.69e-4; configs[2] 6.70e-4 / 8.76e-4).  The first form (slices of 64: value and gate as two "Q" steps, 64 fp32 results live) spilled 4 registers and, with the audit compiling the file to assembly once per KERNEL, took 12 minutes to build; slices of 32 with value \| gate as the two channel tiles of one step: 0 spills, and the audit now compiles each file once, beside the object compiles |
+@@ROUND6_LEDGER_TAIL@@
 """
     s = s.replace("@@ROUND6_LEDGER@@", ledger)
     open(p, "w").write(s)

@@ -307,6 +307,11 @@ class BasicTransformerBlock(E.EngineModule):
             # ... and the temporal sub-layer behind them in the same launch (tattn_sublayer_kernel<2>): x is read once and written once for
             # the three attention sub-layers of the block
             tp = self.attn_temporal.fused_temporal_params(x, self.norm_temporal, g)
+            if tp is not None and ff_fused and E.BLOCK_FF_FUSED:
+                # ... and the feed-forward behind them: the whole block in one launch (tattn_sublayer_kernel<2, 1>)
+                return ops.block_sublayers(x, list(pair), tp, self.ff.fused_params(x, self.norm3), n_batch=g.b, t_len=g.t, hw=g.hw, lk=n_text,
+                                           cross_scale=self.attn1.scale, temporal_scale=self.attn_temporal.scale,
+                                           out_f32=not out_hilo, out_hilo=out_hilo)
             if tp is not None:
                 # (+ norm3 of the finished rows for the feed-forward: the same parameter tensors FeedForward.run -> engine.ln_linear looks up)
                 nxt = (E.f32_param(self.ff, "up.ln.g", self.norm3.weight), E.f32_param(self.ff, "up.ln.b", self.norm3.bias), self.norm3.eps) \

@@ -88,6 +88,7 @@ SIGNATURES = {
     "uav_xattn_sublayers_f32": (C.c_int, [c_p, c_p, c_p, i32, i64, i32, i32, i32, i32, f32, c_p]),
     "uav_block_attn_sublayers_f32": (C.c_int, [c_p, c_p, c_p, i32, f32, c_p, i32, i32, i64, i32, i32, f32, c_p]),
     "uav_ff_sublayer_f32": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, i32, c_p]),
+    "uav_block_sublayers_f32": (C.c_int, [c_p, c_p, c_p, c_p, i32, f32, c_p, c_p, i32, i32, i64, i32, i32, i32, f32, c_p]),
     "uav_tattn_sublayer_f32": (C.c_int, [c_p, c_p, c_p, i32, i32, i64, i32, i32, f32, c_p]),
     "uav_xattn_pack_kv": (C.c_int, [c_p, i64, c_p, i64, i32, i32, i32, i32, c_p, c_p]),
     "uav_temporal_attention_f16": (C.c_int, [c_p, c_p, i32, i32, i64, i32, i32, f32, c_p, c_p, i32, c_p, c_p]),

@@ -101,11 +101,13 @@ def _build_locked(objdir, verbose):
 
 
 NAMED_ACC_KERNELS = {"attention.hip": ["attn512w_kernel"],
-                     "xattn_fused.hip": ["xattn_sublayer_kernelILi0E", "tattn_sublayer_kernelILi0E", "tattn_sublayer_kernelILi2E", "ff_sublayer_kernel"]}
+                     "xattn_fused.hip": ["xattn_sublayer_kernelILi0E", "ff_sublayer_kernel"],
+                     "tattn_fused.hip": ["tattn_sublayer_kernelILi0ELi0E", "tattn_sublayer_kernelILi2ELi0E"],
+                     "tattn_block_fused.hip": ["tattn_sublayer_kernelILi2ELi1E"]}
 
 
 def audit_accumulator_file(asm=None):
-    """attn512w_kernel (csrc/attention.hip), xattn_sublayer_kernel, tattn_sublayer_kernel and ff_sublayer_kernel (csrc/xattn_fused.hip) keep their
+    """attn512w_kernel (csrc/attention.hip) and the fused sub-layer kernels (csrc/xattn_fused.hip, tattn_fused.hip, tattn_block_fused.hip) keep their
     256 fp32 accumulators in a[0:255] BY NAME from inline asm.  That is only sound while hipcc itself never touches the accumulator file in
     those kernels (it would treat the registers as free between our statements): compile the file to assembly (once per file: `asm` =
     {file: text} when the caller already did) and fail the build if any compiler-generated instruction of the kernel names an AGPR."""

@@ -377,6 +377,9 @@ BLOCK_ATTN_FUSED = _os.environ.get("UAV_BLOCK_ATTN_FUSED", "1") != "0"
 # ... and the feed-forward sub-layer behind them (LayerNorm -> GEGLU 512 -> 2 x 2048 -> Linear 2048 -> 512 -> + residual) as one launch
 # (ff_sublayer_kernel: the hidden activations never leave the registers).  UAV_FF_FUSED=0 keeps LayerNorm + the two conv-GEMM launches.
 FF_FUSED = _os.environ.get("UAV_FF_FUSED", "1") != "0"
+# ... and the four sub-layers of such a block in ONE launch (tattn_sublayer_kernel<2, 1>).  UAV_BLOCK_FF_FUSED=0 keeps the attention launch +
+# the feed-forward launch.
+BLOCK_FF_FUSED = _os.environ.get("UAV_BLOCK_FF_FUSED", "1") != "0"
 # ... and (where the feed-forward is NOT fused) the LayerNorm in front of the feed-forward (norm3) written by that launch's epilogue (fp16 rows beside the fp32 ones): the
 # LayerNorm pass of the block's last sub-layer disappears.  UAV_NEXT_LN=0 keeps the pass.
 NEXT_LN = _os.environ.get("UAV_NEXT_LN", "1") != "0"

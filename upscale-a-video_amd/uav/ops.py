@@ -862,6 +862,39 @@ def block_attn_sublayers(x, cross, temporal, *, n_batch, t_len, hw, lk, cross_sc
     return y
 
 
+def block_sublayers(x, cross, temporal, ff, *, n_batch, t_len, hw, lk, cross_scale, temporal_scale, out_f32=True, out_hilo=False):
+    """The whole BasicTransformerBlock (attn1 -> attn2 -> attn_temporal -> ff) on fp32 stream rows [B*T*hw][512] in ONE launch: `cross`,
+    `temporal` as for block_attn_sublayers, `ff` = (gamma, beta, eps, w_packed, up_bias, down_bias) as for ff_sublayer.  Returns the fp32
+    rows, or (out_hilo) their fp16 hi | lo pair, or (both) the tuple."""
+    lib = _lib.load()
+    _req(x, torch.float32, "x")
+    if len(cross) != 2:
+        raise _lib.UavError("block_sublayers takes the two cross-attention sub-layers of a block")
+    if not (out_f32 or out_hilo):
+        raise _lib.UavError("block_sublayers: nothing to write")
+    m = x.shape[0]
+    y = torch.empty_like(x) if out_f32 else None
+    yh = torch.empty((m, 2 * XATTN_C), dtype=HALF, device=x.device) if out_hilo else None
+    arr = (_lib.XattnParams * 2)()
+    for i, (gamma, beta, eps, wq_packed, kv_packed, wo_packed, out_bias) in enumerate(cross):
+        arr[i].ln_gamma, arr[i].ln_beta, arr[i].ln_eps = _p(gamma), _p(beta), float(eps)
+        arr[i].wq_packed, arr[i].kv_packed, arr[i].wo_packed, arr[i].out_bias = _p(wq_packed), _p(kv_packed), _p(wo_packed), _p(out_bias)
+    q = _tattn_params(temporal)
+    f = _lib.FfParams()
+    f.ln_gamma, f.ln_beta, f.ln_eps, f.w_packed, f.up_bias, f.down_bias = _p(ff[0]), _p(ff[1]), float(ff[2]), _p(ff[3]), _p(ff[4]), _p(ff[5])
+    ev = PROFILER.begin("block_sublayers")
+    rc = lib.uav_block_sublayers_f32(_p(x), _p(y) if y is not None else None, _p(yh) if yh is not None else None, C.cast(arr, C.c_void_p), lk,
+                                     cross_scale, C.byref(q), C.byref(f), n_batch, t_len, hw, XATTN_C, XATTN_HEADS, FF_INNER, temporal_scale,
+                                     _stream())
+    _lib.check(rc, "uav_block_sublayers_f32")
+    PROFILER.end(ev, "block_sublayers" if not PROFILER.detail else f"block_sublayers M={m}",
+                 2.0 * m * (8 * XATTN_C * XATTN_C) + 2 * 4.0 * m * lk * XATTN_C + 4.0 * m * t_len * XATTN_C + 2.0 * m * XATTN_C * 3 * FF_INNER,
+                 4.0 * m * XATTN_C * (1 + (1 if out_f32 else 0) + (1 if out_hilo else 0)))
+    if out_f32 and out_hilo:
+        return y, yh
+    return y if out_f32 else yh
+
+
 def temporal_attention(qkv, *, n_batch, t_len, hw, c, heads, scale, rope_cos, rope_sin, rot_dim, bias):
     lib = _lib.load()
     _req(qkv, HALF, "qkv")
