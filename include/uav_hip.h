@@ -306,10 +306,20 @@ int uav_ff_sublayer_f32(const float* x, float* out, void* out_hilo, const uav_ff
                         int32_t inner, void* stream);
 /* The WHOLE BasicTransformerBlock (attention.py:523-564: attn1 -> attn2 -> attn_temporal -> ff, only_cross_attention) in ONE launch: the
  * stream is read once; `out` (fp32 rows, may be NULL) and / or `out_hilo` (fp16 hi | lo pair, see uav_ff_sublayer_f32) are written once.
- * Same shape contract as uav_block_attn_sublayers_f32; temporal->next_ln_out must be NULL; inner must be 2048. */
-int uav_block_sublayers_f32(const float* x, float* out, void* out_hilo, const uav_xattn_params* cross, int32_t lk, float cross_scale,
-                            const uav_tattn_params* temporal, const uav_ff_params* ff, int32_t n_batch, int32_t t_len, int64_t hw,
-                            int32_t channels, int32_t heads, int32_t inner, float temporal_scale, void* stream);
+ * Same shape contract as uav_block_attn_sublayers_f32; temporal->next_ln_out must be NULL; inner must be 2048.
+ * proj_in != NULL: x is the fp32 INPUT of the Transformer3DModel's GroupNorm (attention.py:389-393) and the launch starts with GroupNorm
+ * apply -> proj_in: gn_scale / gn_shift = the per-instance rows [n_batch * t_len][512] that uav_groupnorm_scale_shift /
+ * uav_groupnorm_finalize_partials write (one instance per frame), w_packed = proj_in's weight as 'out'-kind fragments
+ * (uav.ops.pack_xattn_weight), bias fp32 [512]. */
+typedef struct uav_projin_params {
+    const float* gn_scale;
+    const float* gn_shift;
+    const void*  w_packed;
+    const float* bias;
+} uav_projin_params;
+int uav_block_sublayers_f32(const float* x, const uav_projin_params* proj_in, float* out, void* out_hilo, const uav_xattn_params* cross,
+                            int32_t lk, float cross_scale, const uav_tattn_params* temporal, const uav_ff_params* ff, int32_t n_batch,
+                            int32_t t_len, int64_t hw, int32_t channels, int32_t heads, int32_t inner, float temporal_scale, void* stream);
 /* k, v: fp16 rows [n_batch * lk][stride] (head h in columns h*head_dim ..) -> out: n_batch * heads * 32 KiB */
 int uav_xattn_pack_kv(const void* k, int64_t k_stride, const void* v, int64_t v_stride, int32_t n_batch, int32_t lk,
                       int32_t heads, int32_t head_dim, void* out, void* stream);

@@ -147,6 +147,26 @@ def groupnorm(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps, silu, x2=N
     return _h(y)
 
 
+def groupnorm_scale_shift(x1, gamma, beta, *, n_inst, rows_per_inst, groups, eps, x2=None, c_real=None):
+    """Per-instance rows [n_inst][c]: y = x * scale + shift (single fp32 source only: what the fused transformer launch asks for)."""
+    assert x2 is None and c_real is None
+    c = x1.shape[-1]
+    xr = x1.float().reshape(n_inst, rows_per_inst, groups, c // groups).double()
+    mean = xr.mean(dim=(1, 3)); var = xr.var(dim=(1, 3), unbiased=False)            # [n_inst][groups]
+    rstd = 1.0 / torch.sqrt(var + eps)
+    scale = (rstd.repeat_interleave(c // groups, 1) * gamma.double()).float()
+    shift = (beta.double() - (mean * rstd).repeat_interleave(c // groups, 1) * gamma.double()).float()
+    return scale.contiguous(), shift.contiguous()
+
+
+def groupnorm_apply(x1, scale, shift, *, n_inst, rows_per_inst, silu, x2=None, want_raw=False):
+    assert x2 is None and not want_raw
+    c = x1.shape[-1]
+    y = x1.float().reshape(n_inst, rows_per_inst, c) * scale[:, None, :] + shift[:, None, :]
+    y = y.reshape(-1, c)
+    return _h(F.silu(y) if silu else y)
+
+
 def layernorm(x, gamma, beta, eps=1e-5):
     return _h(F.layer_norm(x.float(), (x.shape[-1],), gamma.float(), beta.float(), eps))
 
@@ -393,7 +413,11 @@ def ff_sublayer(x, gamma, beta, eps, w_packed, up_bias, down_bias, *, out_f32=Tr
     return y if out_f32 else cast_hilo(y)
 
 
-def block_sublayers(x, cross, temporal, ff, *, n_batch, t_len, hw, lk, cross_scale, temporal_scale, out_f32=True, out_hilo=False):
+def block_sublayers(x, cross, temporal, ff, *, n_batch, t_len, hw, lk, cross_scale, temporal_scale, out_f32=True, out_hilo=False, proj_in=None):
+    if proj_in is not None:
+        sc, sh, wp, bi = proj_in
+        n = _h(groupnorm_apply(x, sc, sh, n_inst=n_batch * t_len, rows_per_inst=hw, silu=False)).float()
+        x = n @ _unpack_xattn_weight(wp, "out").t() + bi.float()
     y = block_attn_sublayers(x, cross, temporal, n_batch=n_batch, t_len=t_len, hw=hw, lk=lk, cross_scale=cross_scale, temporal_scale=temporal_scale)
     return ff_sublayer(y, *ff, out_f32=out_f32, out_hilo=out_hilo)
 
@@ -414,7 +438,7 @@ def sft_fuse(dec, scale, shift, w, out_f32=False):
     return y if out_f32 else _h(y)
 
 
-_OPS = ("ln_fold_ok", "resize_area_f32", "cast_f16", "cast_hilo", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "layernorm", "attention", "xattn_pack_kv", "xattn_sublayer", "xattn_sublayers", "tattn_sublayer", "block_attn_sublayers", "block_sublayers", "ff_sublayer", "temporal_attention", "linear_small",
+_OPS = ("ln_fold_ok", "resize_area_f32", "cast_f16", "cast_hilo", "sft_fuse", "propagate_step", "conv_gemm", "linear", "groupnorm", "groupnorm_scale_shift", "groupnorm_apply", "layernorm", "attention", "xattn_pack_kv", "xattn_sublayer", "xattn_sublayers", "tattn_sublayer", "block_attn_sublayers", "block_sublayers", "ff_sublayer", "temporal_attention", "linear_small",
         "timestep_embedding", "pack_nhwc", "unpack_ncthw", "axpby", "cfg_ddim_v0", "ddim_vt")
 
 

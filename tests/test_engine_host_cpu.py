@@ -475,3 +475,37 @@ def test_transformer_block_fused_feed_forward_host_side(cpu_engine):
         E.BLOCK_FF_FUSED = oldb
         E.invalidate_packed(blk)
     assert torch.equal(y2, y1) and torch.equal(h2, h1)          # the stand-ins compose the same arithmetic
+
+
+def test_transformer3d_groupnorm_proj_in_inside_the_block_launch_host_side(cpu_engine):
+    """Transformer3DModel at the 512-channel width: GroupNorm apply -> proj_in -> the whole block as ONE launch (ops.block_sublayers with
+    proj_in) against the GroupNorm pass + proj_in launch + block launch — the host side: scale | shift rows per frame, proj_in re-packed as
+    'out' fragments, the hi | lo pair handed to proj_out, the switch."""
+    from uav import engine as E
+    from models_video.attention import Transformer3DModel
+    g = torch.Generator().manual_seed(9)
+    m = Transformer3DModel(num_attention_heads=8, attention_head_dim=64, in_channels=512, num_layers=1, cross_attention_dim=64,
+                           use_linear_projection=True, only_cross_attention=True)
+    with torch.no_grad():
+        for p_ in m.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.04 if p_.dim() > 1 else 0.2))
+        for mod in m.modules():
+            if isinstance(mod, (torch.nn.LayerNorm, torch.nn.GroupNorm)):
+                mod.weight.add_(1.0)
+    m = m.half().eval()
+    geom = E.Geom(1, 8, 4, 4)
+    x = torch.randn(geom.rows, 512, generator=g) * 1.5
+    ehs = torch.randn(7, 64, generator=g).half()
+    old = E.PROJ_IN_FUSED
+    res = {}
+    try:
+        for on in (True, False):
+            E.PROJ_IN_FUSED = on
+            E.invalidate_packed(m)
+            with torch.no_grad():
+                res[on] = m.run(x.clone(), geom, ehs, 7)
+    finally:
+        E.PROJ_IN_FUSED = old
+        E.invalidate_packed(m)
+    assert res[True].dtype == res[False].dtype == torch.float32
+    assert rel_l2(res[True], res[False]) < 2e-4, rel_l2(res[True], res[False])

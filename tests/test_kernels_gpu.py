@@ -1353,3 +1353,51 @@ def test_whole_transformer_block_in_one_launch_equals_attention_launch_then_feed
             assert rel_l2(yh[:, :C].float() + yh[:, C:].float(), y4) < 1e-4
     r2 = ops.block_sublayers(x, cross, temporal, ff, out_f32=mode != "hilo", out_hilo=mode != "f32", **kw)
     assert all(torch.equal(a, b) for a, b in zip(r if isinstance(r, tuple) else (r,), r2 if isinstance(r2, tuple) else (r2,)))
+
+
+def test_whole_block_launch_with_groupnorm_apply_and_proj_in_in_front(ops, dev):
+    """uav_block_sublayers_f32 with proj_in: GroupNorm apply -> proj_in -> attn1 -> attn2 -> attn_temporal -> ff in one launch (Transformer3DModel,
+    attention.py:389-398 up to proj_out) against GroupNorm (scale / shift + apply pass), the proj_in GEMM launch and the whole-block launch."""
+    g = torch.Generator().manual_seed(321)
+    C, H, D, T, nb, hh, ww, lk, I = 512, 8, 64, 8, 2, 16, 16, 77, 2048
+    hw = hh * ww
+    M = nb * T * hw
+    x = (torch.randn(M, C, generator=g) * 1.7 + 0.6).to(dev)
+    gg = (torch.randn(C, generator=g) * 0.2 + 1.0).to(dev); gb = (torch.randn(C, generator=g) * 0.1).to(dev)
+    w_in = h16(C, C, dev=dev, scale=C ** -0.5, gen=g); b_in = (torch.randn(C, generator=g) * 0.1).to(dev)
+    cross = []
+    for _ in range(2):
+        gamma = (torch.randn(C, generator=g) * 0.2 + 1.0).to(dev); beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+        wq = h16(C, C, dev=dev, scale=C ** -0.5, gen=g); wo = h16(C, C, dev=dev, scale=C ** -0.5, gen=g)
+        bo = (torch.randn(C, generator=g) * 0.1).to(dev)
+        kv = (torch.randn(nb * lk, 2 * C, generator=g) * 1.5).half().to(dev)
+        kvp = ops.xattn_pack_kv(kv[:, :C], kv[:, C:], n_batch=nb, lk=lk, k_stride=2 * C, v_stride=2 * C)
+        cross.append((gamma, beta, 1e-5, ops.pack_xattn_weight(wq, "q", dev), kvp, ops.pack_xattn_weight(wo, "out", dev), bo))
+    gamma = (torch.randn(C, generator=g) * 0.2 + 1.0).to(dev); beta = (torch.randn(C, generator=g) * 0.1).to(dev)
+    ws = [h16(C, C, dev=dev, scale=C ** -0.5, gen=g) for _ in range(4)]
+    bo = (torch.randn(C, generator=g) * 0.1).to(dev)
+    relb = (torch.randn(H, T, T, generator=g) * 0.5).to(dev).contiguous()
+    fr = 1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32))
+    ang = torch.arange(T).float()[:, None] * fr[None, :]
+    cos, sin = ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
+    temporal = (gamma, beta, 1e-5, *[ops.pack_xattn_weight(w_, "q", dev) for w_ in ws[:3]], ops.pack_xattn_weight(ws[3], "out", dev), bo, relb, cos, sin, 32)
+    g3 = (torch.randn(C, generator=g) * 0.2 + 1.0).to(dev); b3 = (torch.randn(C, generator=g) * 0.1).to(dev)
+    wu = h16(2 * I, C, dev=dev, scale=C ** -0.5, gen=g); wd = h16(C, I, dev=dev, scale=I ** -0.5, gen=g)
+    bu = (torch.randn(2 * I, generator=g) * 0.2).to(dev); bd = (torch.randn(C, generator=g) * 0.1).to(dev)
+    ff = (g3, b3, 1e-5, ops.pack_ff_weights(wu, wd, dev), bu, bd)
+    scale = D ** -0.5
+    kw = dict(n_batch=nb, t_len=T, hw=hw, lk=lk, cross_scale=scale, temporal_scale=scale)
+    # the three-launch form
+    sc, sh = ops.groupnorm_scale_shift(x, gg, gb, n_inst=nb * T, rows_per_inst=hw, groups=32, eps=1e-6)
+    n = ops.groupnorm_apply(x, sc, sh, n_inst=nb * T, rows_per_inst=hw, silu=False)
+    tok = ops.linear(n, ops.pack_conv(w_in, b_in, device=dev), out_f32=True)
+    y_ref, h_ref = ops.block_sublayers(tok, cross, temporal, ff, out_f32=True, out_hilo=True, **kw)
+    # one launch
+    pi = (sc, sh, ops.pack_xattn_weight(w_in, "out", dev), b_in)
+    y, yh = ops.block_sublayers(x, cross, temporal, ff, out_f32=True, out_hilo=True, proj_in=pi, **kw)
+    assert bool(torch.isfinite(y).all())
+    e, e_upd = rel_l2(y, y_ref), rel_l2(y - tok, y_ref - tok)
+    assert e < 1e-4 and e_upd < 1.5e-3, (e, e_upd)            # tok to fp32 summation order; norm1 statistics from the accumulators
+    assert torch.equal(yh, ops.cast_hilo(y))
+    yh2 = ops.block_sublayers(x, cross, temporal, ff, out_f32=False, out_hilo=True, proj_in=pi, **kw)
+    assert torch.equal(yh2, yh)

@@ -102,7 +102,7 @@ PY
       cat $L ;;
     xattn)    timeout 300 python $R/tools/bench_xattn.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_xattn_fused_vs_chain.jsonl ;;
     xtrace)   timeout 300 python $R/tools/trace_xattn.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_xattn_phase_trace.jsonl ;;
-    xtests)   timeout 600 python -m pytest $R/tests/test_kernels_gpu.py -m gpu -x -q -k "fused_cross or fused_temporal or fused_block or attention or hilo or fused_sublayer or fused_feed or whole_transformer" 2>&1 | tail -8 | tee $O/${TAG}_xattn_tests.log ;;
+    xtests)   timeout 600 python -m pytest $R/tests/test_kernels_gpu.py -m gpu -x -q -k "fused_cross or fused_temporal or fused_block or attention or hilo or fused_sublayer or fused_feed or whole_transformer or whole_block" 2>&1 | tail -8 | tee $O/${TAG}_xattn_tests.log ;;
     bench1_tail) (cd $R && UAV_TAIL_HILO=0 timeout 400 python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-throughput-mode 2> /dev/null | tee $O/${TAG}_bench1_tail_hilo_off.json) ;;
     parity_head) (cd $R && rm -f gpurun_out/parity.jsonl; timeout 900 python -m pytest tests/test_parity_r4_gpu.py -m gpu -q -k "headline" 2>&1 | tail -6 | tee $O/${TAG}_parity_headline.log; mv gpurun_out/parity.jsonl $O/${TAG}_parity_headline.jsonl 2> /dev/null) ;;
     parity_head_tail) (cd $R && rm -f gpurun_out/parity.jsonl; UAV_TAIL_HILO=0 timeout 900 python -m pytest tests/test_parity_r4_gpu.py -m gpu -q -k "headline" 2>&1 | tail -6 | tee $O/${TAG}_parity_headline_tail_hilo_off.log; mv gpurun_out/parity.jsonl $O/${TAG}_parity_headline_tail_hilo_off.jsonl 2> /dev/null) ;;

@@ -43,6 +43,9 @@ struct TattnArgs {
     // FF = 1: the block's feed-forward sub-layer behind the three attention sub-layers (the whole BasicTransformerBlock in one launch)
     const float* ff_gamma; const float* ff_beta; const float* ff_down_bias; const float* ff_up_bias; const char* ff_w; float ff_eps;
     half_t* out_hilo;                            // FF = 1: the result as the fp16 hi | lo pair [M][1024] (instead of / beside out)
+    // PI = 1: x is the INPUT of the Transformer3DModel's GroupNorm (fp32 rows); the kernel applies the GroupNorm (per-frame scale | shift
+    // rows [B*T][512] from the statistics finalize), proj_in ('out'-packed fragments, bias) and goes on with the block on the result
+    const float* gn_scale; const float* gn_shift; const char* w_in; const float* b_in;
 };
 
 // NX = 0: the temporal sub-layer alone.  NX = 2: attn1 -> attn2 -> attn_temporal of one BasicTransformerBlock (only_cross_attention) in ONE
@@ -50,7 +53,10 @@ struct TattnArgs {
 // loop asks of its 32 tokens —: the stream is read once and written once for three sub-layers, the rows between them stay in the
 // accumulators and every LayerNorm but the first runs on them in registers.
 // FF = 1 (with NX = 2): ... -> ff in the same launch: the whole block reads the stream once and writes it once (or only its hi | lo pair).
-template <int NX, int FF>
+// PI = 1 (with NX = 2, FF = 1): GroupNorm apply -> proj_in in front: from the Transformer3DModel's GroupNorm input to the last block's output
+// in one launch (attention.py:389-398 minus proj_out, whose residual + GroupNorm-statistics epilogue stays a conv launch).
+constexpr int PIG = 16;                        // groups of proj_in: 8 k slices of 64 x (W_out-type groups 0, 1)
+template <int NX, int FF, int PI = 0>
 __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, l32 = lane & 31, hi = lane >> 5;
@@ -63,12 +69,15 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
     const long long row = rowbase + (long long)(l32 >> 2) * p.hw + (l32 & 3);
 
     const unsigned voff = (unsigned)(wave * XPPW * XFRAG + lane * 16);
-    constexpr int SG_T = NX * XNG;                         // first group of the temporal sub-layer in the stream
+    constexpr int SG_X = PI * PIG;                         // first group of the first cross-attention sub-layer in the stream
+    constexpr int SG_T = SG_X + NX * XNG;                  // first group of the temporal sub-layer
     auto next_of = [&](int s) -> XNext {
         XNext n;
         n.ldsn = lds0 + (unsigned)((s & (XRING - 1)) * XGROUP + wave * XPPW * XFRAG);
+        if (PI && s < SG_X) { n.srd = make_srd(p.w_in, PIG * XGROUP); n.so = (unsigned)s * XGROUP; return n; }
         if (NX > 0 && s < SG_T) {                          // a cross-attention sub-layer: head r / 5, group j = r % 5 (0, 1: W_q; 2: K | V; 3, 4: W_out)
-            const int u = s >= XNG ? 1 : 0, r = s - u * XNG;
+            const int sx = s - SG_X;
+            const int u = sx >= XNG ? 1 : 0, r = sx - u * XNG;
             const int h = r / XGPH, j = r - h * XGPH;
             const XattnSub& S = p.xs[u];
             if (j < 2) { n.srd = make_srd(S.wq, XHEADS * 2 * XGROUP); n.so = (unsigned)((h * 2 + j) * XGROUP); }
@@ -118,10 +127,11 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
         *(lds_f4wptr_t)(size_t)(lds0 + TT_LN + tid * 16) = ((const float4_t*)p.gamma)[tid];
         *(lds_f4wptr_t)(size_t)(lds0 + TT_LN + 2048 + tid * 16) = ((const float4_t*)p.beta)[tid];
         *(lds_f4wptr_t)(size_t)(lds0 + TT_LN + 4096 + tid * 16) = ((const float4_t*)p.bias)[tid];
-        if (p.ln_out) {
+        if (!PI && p.ln_out) {
             *(lds_f4wptr_t)(size_t)(lds0 + TTAB_LN3 + tid * 16) = ((const float4_t*)p.ln_gamma)[tid];
             *(lds_f4wptr_t)(size_t)(lds0 + TTAB_LN3 + 2048 + tid * 16) = ((const float4_t*)p.ln_beta)[tid];
         }
+        if (PI) *(lds_f4wptr_t)(size_t)(lds0 + TTAB_LN3 + tid * 16) = ((const float4_t*)p.b_in)[tid];     // proj_in bias where norm3's tables would be
     } else {
         typedef __attribute__((address_space(3))) float* lds_fptr_t;
         const int u = tid - 128;                            // 128 threads: 512 bias entries (4 each), 128 cos + 128 sin (1 + 1 each)
@@ -138,43 +148,94 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
             *(lds_fptr_t)(size_t)(lds0 + TTAB_COS + 512 + u * 4) = p.rope_sin[t * 16 + pair];
         }
     }
-    // ---- LayerNorm statistics (first read), operand fragments + accumulators (second read): as in the kernel above -------------------
-    const float* xr = p.x + row * XC + 4 * hi;
-    const float c0 = p.x[row * XC];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int jb = 0; jb < 16; jb += 4) {
-#pragma unroll
-        for (int j = jb; j < jb + 4; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4_t v = *(const float4_t*)(xr + 32 * j + 8 * q);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { const float d = v[i] - c0; s1 += d; s2 += d * d; }
-            }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    s1 = half_sum(s1); s2 = half_sum(s2);
-    const float m1 = s1 * (1.0f / XC);
-    const float mean = c0 + m1;
-    const float rstd = rsqrtf(fmaxf(s2 * (1.0f / XC) - m1 * m1, 0.f) + (NX > 0 ? p.xs[0].eps : p.eps));      // (the tables at XTAB are the first sub-layer's)
-    __syncthreads();                                        // tables visible
     half8_t xn[32];
-    static_for<16>([&](auto J) {
-        constexpr int j = J;
-        static_for<4>([&](auto Q) {
-            constexpr int q = Q;
-            const float4_t v = *(const float4_t*)(xr + 32 * j + 8 * q);
-            const unsigned ta = lds0 + XTAB + (32 * j + 8 * q + 4 * hi) * 4;
-            const float4_t g = lds_f4(ta), be = lds_f4(ta + 2048), bo = lds_f4(ta + 4096);
-            static_for<4>([&](auto I) {
-                constexpr int i = I;
-                xn[2 * j + (q >> 1)][4 * (q & 1) + i] = (half_t)((v[i] - mean) * rstd * g[i] + be[i]);
-                acc_set<16 * j + 4 * q + i>(v[i] + bo[i]);
+    if constexpr (PI) {
+        // ---- GroupNorm apply + proj_in: the scale | shift rows of the workgroup's 8 frames (32 KiB) sit in ring slot 3, which the stream
+        // does not touch before the first group is walked (its pieces go out between the MFMAs of group 0, behind a barrier every wave
+        // reaches with its rows normalised); ONE read of x (the statistics are the GroupNorm's, already finalized) ---------------------------
+        {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {                   // 2048 16-B units: frame f, part (scale / shift), channel quad c4
+                const int idx = k * 256 + tid, f = idx >> 8, part = (idx >> 7) & 1, c4 = idx & 127;
+                const float* src = (part ? p.gn_shift : p.gn_scale) + ((long long)(bb * TT + f) * XC + c4 * 4);
+                *(lds_f4wptr_t)(size_t)(lds0 + 3 * XGROUP + f * 4096 + part * 2048 + c4 * 16) = *(const float4_t*)src;
+            }
+        }
+        __syncthreads();                                    // tables visible
+        const float* xr = p.x + row * XC + 4 * hi;
+        const unsigned gt = lds0 + 3 * XGROUP + (l32 >> 2) * 4096 + 16 * hi;
+        static_for<16>([&](auto J) {
+            constexpr int j = J;
+            static_for<4>([&](auto Q) {
+                constexpr int q = Q;
+                const float4_t v = *(const float4_t*)(xr + 32 * j + 8 * q);
+                const float4_t sc = lds_f4(gt + (32 * j + 8 * q) * 4), sh = lds_f4(gt + 2048 + (32 * j + 8 * q) * 4);
+                const float4_t bi = lds_f4(lds0 + TTAB_LN3 + (32 * j + 8 * q + 4 * hi) * 4);
+                static_for<4>([&](auto I) {
+                    constexpr int i = I;
+                    xn[2 * j + (q >> 1)][4 * (q & 1) + i] = (half_t)(v[i] * sc[i] + sh[i]);      // gn_apply_kernel's arithmetic and rounding
+                    acc_set<16 * j + 4 * q + i>(bi[i]);
+                });
             });
+            if (j & 1) __builtin_amdgcn_sched_barrier(0);
         });
-        if (j & 1) __builtin_amdgcn_sched_barrier(0);       // batches of 8 loads (this prologue carries the row arithmetic of the frame-strided tile on top)
-    });
+        // tok^T [512 ch][32 tokens] = W_in . N^T + b_in: 8 k slices of 64 = 8 x (W_out-type groups 0, 1) on the named accumulators
+        {
+            half8_t t0, t1, t2, t3, t4, t5;
+            static_for<8>([&](auto Hh) {
+                constexpr int h = Hh;
+                {
+                    const unsigned st = group_sync(2 * h);
+                    asm volatile(XG_WO0 : XTMP_OUT : [st] "v"(st), [b0] "v"(xn[4 * h]), [b1] "v"(xn[4 * h + 1]), [b2] "v"(xn[4 * h + 2]),
+                                 [b3] "v"(xn[4 * h + 3]), XDMA_IN : "memory", "scc", XACC_CLOBBERS);
+                }
+                {
+                    const unsigned st = group_sync(2 * h + 1);
+                    asm volatile(XG_WO1 : XTMP_OUT : [st] "v"(st), [b0] "v"(xn[4 * h]), [b1] "v"(xn[4 * h + 1]), [b2] "v"(xn[4 * h + 2]),
+                                 [b3] "v"(xn[4 * h + 3]), XDMA_IN : "memory", "scc", XACC_CLOBBERS);
+                }
+            });
+        }
+        // norm1 on the token rows the accumulators hold (+ attn1's output bias): from here on as if they had been read from HBM
+        mid_layernorm(xn, lds0 + XTAB, p.xs[0].eps, hi);
+    } else {
+        // ---- LayerNorm statistics (first read), operand fragments + accumulators (second read): as in the kernel above -------------------
+        const float* xr = p.x + row * XC + 4 * hi;
+        const float c0 = p.x[row * XC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int jb = 0; jb < 16; jb += 4) {
+#pragma unroll
+            for (int j = jb; j < jb + 4; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4_t v = *(const float4_t*)(xr + 32 * j + 8 * q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { const float d = v[i] - c0; s1 += d; s2 += d * d; }
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        s1 = half_sum(s1); s2 = half_sum(s2);
+        const float m1 = s1 * (1.0f / XC);
+        const float mean = c0 + m1;
+        const float rstd = rsqrtf(fmaxf(s2 * (1.0f / XC) - m1 * m1, 0.f) + (NX > 0 ? p.xs[0].eps : p.eps));      // (the tables at XTAB are the first sub-layer's)
+        __syncthreads();                                        // tables visible
+        static_for<16>([&](auto J) {
+            constexpr int j = J;
+            static_for<4>([&](auto Q) {
+                constexpr int q = Q;
+                const float4_t v = *(const float4_t*)(xr + 32 * j + 8 * q);
+                const unsigned ta = lds0 + XTAB + (32 * j + 8 * q + 4 * hi) * 4;
+                const float4_t g = lds_f4(ta), be = lds_f4(ta + 2048), bo = lds_f4(ta + 4096);
+                static_for<4>([&](auto I) {
+                    constexpr int i = I;
+                    xn[2 * j + (q >> 1)][4 * (q & 1) + i] = (half_t)((v[i] - mean) * rstd * g[i] + be[i]);
+                    acc_set<16 * j + 4 * q + i>(v[i] + bo[i]);
+                });
+            });
+            if (j & 1) __builtin_amdgcn_sched_barrier(0);       // batches of 8 loads (this prologue carries the row arithmetic of the frame-strided tile on top)
+        });
+    }
 
     auto temporal_heads = [&](half8_t (&xn)[32]) {
     // (the lane's pixel / frame from a fresh lane id: kept live from the row computation at the top they were spilled across the prologue)
@@ -329,9 +390,9 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
     if constexpr (NX > 0) {
         // ---- attn1, attn2 (text cross-attention) on the same tile, then the temporal sub-layer's LayerNorm on their output ---------------
         unsigned long long ts_[12];
-        xattn_heads<0>(0, xn, group_sync, nx, voff, hi, p.lk, p.xscale_log2, ts_, false);
+        xattn_heads<0>(SG_X, xn, group_sync, nx, voff, hi, p.lk, p.xscale_log2, ts_, false);
         mid_layernorm(xn, lds0 + XTAB + XTABS, p.xs[1].eps, hi);
-        xattn_heads<0>(XNG, xn, group_sync, nx, voff, hi, p.lk, p.xscale_log2, ts_, false);
+        xattn_heads<0>(SG_X + XNG, xn, group_sync, nx, voff, hi, p.lk, p.xscale_log2, ts_, false);
         // (a second fragment array: hipcc gives the temporal loop's fragments other registers than the cross loops', and moving one set
         //  onto the other through the full register file went through scratch — 33 spilled fragments)
         half8_t xt[32];
@@ -476,3 +537,4 @@ __global__ __launch_bounds__(256, 1) void tattn_sublayer_kernel(TattnArgs p) {
 // cross the TU boundary as an opaque pointer to a struct both sides compile from this header)
 int uav_tattn_run_attn(const void* tattn_args, int nx, dim3 grid, hipStream_t stream);       // tattn_fused.hip: <0,0>, <2,0>
 int uav_tattn_run_block_ff(const void* tattn_args, dim3 grid, hipStream_t stream);           // tattn_block_fused.hip: <2,1>
+int uav_tattn_run_block_pi(const void* tattn_args, dim3 grid, hipStream_t stream);           // tattn_block_pi_fused.hip: <2,1,1>

@@ -279,6 +279,23 @@ class BasicTransformerBlock(E.EngineModule):
         c.store[("textkv", tag)] = ((ehs_rows, ehs_rows._version, kv, wstamp),) + tuple(hits)[:TEXT_KV_ENTRIES - 1]
         return kv
 
+    def whole_block_params(self, x, g: E.Geom, ehs_rows, n_text):
+        """(cross pair, temporal params, feed-forward params) when the whole block runs as ONE launch on fp32 rows shaped like x
+        (ops.block_sublayers), else None."""
+        if not (self.only_cross_attention and self.attn2 is not None and E.XATTN_PAIR and E.BLOCK_ATTN_FUSED and E.BLOCK_FF_FUSED):
+            return None
+        ffp = self.ff.fused_params(x, self.norm3)
+        if ffp is None or self.attn1.scale != self.attn2.scale:
+            return None
+        k, v, kvp = self._text_kv(self.attn1, ehs_rows, "a1", n_text)
+        s1 = self.attn1.fused_params(x, self.norm1, (k, v, n_text, kvp), rows_per_kv=g.t * g.hw)
+        if s1 is None:
+            return None
+        k, v, kvp = self._text_kv(self.attn2, ehs_rows, "a2", n_text)
+        s2 = self.attn2.fused_params(x, self.norm2, (k, v, n_text, kvp), rows_per_kv=g.t * g.hw)
+        tp = self.attn_temporal.fused_temporal_params(x, self.norm_temporal, g) if s2 is not None else None
+        return None if tp is None else ([s1, s2], tp, ffp)
+
     def run(self, x, g: E.Geom, ehs_rows, n_text, out_f32=None, out_hilo=False):
         """x: tokens [B*T*HW][C] (rows ordered b,t,p), fp16 or fp32 (residual stream); ehs_rows: [B*n_text][Cx] fp16.
         out_f32=False: the block's output is only read as an MFMA operand (proj_out) -> written in fp16;
@@ -359,12 +376,31 @@ class Transformer3DModel(ModelMixin, ConfigMixin, E.EngineModule):
     def run(self, x, g: E.Geom, ehs_rows, n_text):
         x = self.resblock_temporal.run(x, g, None)
         res = x
-        n = E.group_norm(self, "norm", self.norm, x, n_inst=g.n_img, rows_per_inst=g.hw, silu=False)   # per frame
         s32 = res.dtype == torch.float32         # fp32 residual stream: the token stream is one too (LayerNorm inputs)
         tok32 = s32 and E.TOKEN_F32 and (E.TOKEN_F32_MAX_HW <= 0 or g.hw <= E.TOKEN_F32_MAX_HW)
-        tok = ops.linear(n, E.packed_conv(self, "proj_in", self.proj_in), out_f32=tok32, ln_produce=tok32 and E.LN_FOLD)
+        if tok32 and E.PROJ_IN_FUSED and len(self.transformer_blocks) == 1 and not E.LN_FOLD and self.proj_in.bias is not None \
+                and tuple(self.proj_in.weight.shape) == (x.shape[1], x.shape[1]):
+            # GroupNorm apply -> proj_in -> the whole block in ONE launch (tattn_sublayer_kernel<2, 1, 1>): the kernel reads the GroupNorm's
+            # input once, normalises with the per-frame scale | shift rows of the statistics finalize and multiplies by proj_in on the way in
+            blk = self.transformer_blocks[0]
+            wb = blk.whole_block_params(x, g, ehs_rows, n_text)
+            if wb is not None:
+                sc, sh = ops.groupnorm_scale_shift(x, E.f32_param(self, "norm.g", self.norm.weight), E.f32_param(self, "norm.b", self.norm.bias),
+                                                   n_inst=g.n_img, rows_per_inst=g.hw, groups=self.norm.num_groups, eps=self.norm.eps)
+                dev = E._dev(self.proj_in.weight)
+                wp = self._cache().get(("projin", "w"), lambda: ops.pack_xattn_weight(self.proj_in.weight, "out", dev), (self.proj_in.weight,))
+                th = E.tail_hilo()
+                tok = ops.block_sublayers(x, wb[0], wb[1], wb[2], n_batch=g.b, t_len=g.t, hw=g.hw, lk=n_text, cross_scale=blk.attn1.scale,
+                                          temporal_scale=blk.attn_temporal.scale, out_f32=not th, out_hilo=th,
+                                          proj_in=(sc, sh, wp, E.f32_param(self, "proj_in.b", self.proj_in.bias)))
+                cw = E.packed_conv_hilo(self, "proj_out", self.proj_out) if th else E.packed_conv(self, "proj_out", self.proj_out)
+                if not th:
+                    tok = ops.cast_f16(tok)          # (TAIL_HILO off: proj_out reads fp16 rows)
+                return ops.linear(tok, cw, residual=res, out_f32=s32, gn_groups=self.norm.num_groups)
+        n = E.group_norm(self, "norm", self.norm, x, n_inst=g.n_img, rows_per_inst=g.hw, silu=False)   # per frame
         last = len(self.transformer_blocks) - 1
         tail_hilo = tok32 and E.tail_hilo()
+        tok = ops.linear(n, E.packed_conv(self, "proj_in", self.proj_in), out_f32=tok32, ln_produce=tok32 and E.LN_FOLD)
         for i, blk in enumerate(self.transformer_blocks):
             # proj_out reads the last block's output as an operand: fp16, or (TAIL_HILO) the fp32 rows as a hi | lo pair
             tok = blk.run(tok, g, ehs_rows, n_text, out_f32=False if (i == last and not tail_hilo) else None,

@@ -51,6 +51,11 @@ class TattnParams(C.Structure):
                 ("next_ln_out", c_p), ("next_ln_gamma", c_p), ("next_ln_beta", c_p), ("next_ln_eps", f32)]
 
 
+class ProjInParams(C.Structure):
+    """Mirror of `uav_projin_params` (include/uav_hip.h): GroupNorm apply + proj_in in front of the whole-block launch."""
+    _fields_ = [("gn_scale", c_p), ("gn_shift", c_p), ("w_packed", c_p), ("bias", c_p)]
+
+
 class FfParams(C.Structure):
     """Mirror of `uav_ff_params` (include/uav_hip.h): the fused feed-forward sub-layer."""
     _fields_ = [("ln_gamma", c_p), ("ln_beta", c_p), ("ln_eps", f32), ("w_packed", c_p), ("up_bias", c_p), ("down_bias", c_p)]
@@ -88,7 +93,7 @@ SIGNATURES = {
     "uav_xattn_sublayers_f32": (C.c_int, [c_p, c_p, c_p, i32, i64, i32, i32, i32, i32, f32, c_p]),
     "uav_block_attn_sublayers_f32": (C.c_int, [c_p, c_p, c_p, i32, f32, c_p, i32, i32, i64, i32, i32, f32, c_p]),
     "uav_ff_sublayer_f32": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, i32, c_p]),
-    "uav_block_sublayers_f32": (C.c_int, [c_p, c_p, c_p, c_p, i32, f32, c_p, c_p, i32, i32, i64, i32, i32, i32, f32, c_p]),
+    "uav_block_sublayers_f32": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i32, f32, c_p, c_p, i32, i32, i64, i32, i32, i32, f32, c_p]),
     "uav_tattn_sublayer_f32": (C.c_int, [c_p, c_p, c_p, i32, i32, i64, i32, i32, f32, c_p]),
     "uav_xattn_pack_kv": (C.c_int, [c_p, i64, c_p, i64, i32, i32, i32, i32, c_p, c_p]),
     "uav_temporal_attention_f16": (C.c_int, [c_p, c_p, i32, i32, i64, i32, i32, f32, c_p, c_p, i32, c_p, c_p]),

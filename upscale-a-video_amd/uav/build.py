@@ -102,8 +102,9 @@ def _build_locked(objdir, verbose):
 
 NAMED_ACC_KERNELS = {"attention.hip": ["attn512w_kernel"],
                      "xattn_fused.hip": ["xattn_sublayer_kernelILi0E", "ff_sublayer_kernel"],
-                     "tattn_fused.hip": ["tattn_sublayer_kernelILi0ELi0E", "tattn_sublayer_kernelILi2ELi0E"],
-                     "tattn_block_fused.hip": ["tattn_sublayer_kernelILi2ELi1E"]}
+                     "tattn_fused.hip": ["tattn_sublayer_kernelILi0ELi0ELi0E", "tattn_sublayer_kernelILi2ELi0ELi0E"],
+                     "tattn_block_fused.hip": ["tattn_sublayer_kernelILi2ELi1ELi0E"],
+                     "tattn_block_pi_fused.hip": ["tattn_sublayer_kernelILi2ELi1ELi1E"]}
 
 
 def audit_accumulator_file(asm=None):

@@ -380,6 +380,9 @@ FF_FUSED = _os.environ.get("UAV_FF_FUSED", "1") != "0"
 # ... and the four sub-layers of such a block in ONE launch (tattn_sublayer_kernel<2, 1>).  UAV_BLOCK_FF_FUSED=0 keeps the attention launch +
 # the feed-forward launch.
 BLOCK_FF_FUSED = _os.environ.get("UAV_BLOCK_FF_FUSED", "1") != "0"
+# ... and GroupNorm apply -> proj_in of the Transformer3DModel in front of it in the same launch (tattn_sublayer_kernel<2, 1, 1>: from the
+# GroupNorm's input to the block's output).  UAV_PROJ_IN_FUSED=0 keeps the GroupNorm-apply pass and the proj_in launch.
+PROJ_IN_FUSED = _os.environ.get("UAV_PROJ_IN_FUSED", "1") != "0"
 # ... and (where the feed-forward is NOT fused) the LayerNorm in front of the feed-forward (norm3) written by that launch's epilogue (fp16 rows beside the fp32 ones): the
 # LayerNorm pass of the block's last sub-layer disappears.  UAV_NEXT_LN=0 keeps the pass.
 NEXT_LN = _os.environ.get("UAV_NEXT_LN", "1") != "0"

@@ -862,10 +862,12 @@ def block_attn_sublayers(x, cross, temporal, *, n_batch, t_len, hw, lk, cross_sc
     return y
 
 
-def block_sublayers(x, cross, temporal, ff, *, n_batch, t_len, hw, lk, cross_scale, temporal_scale, out_f32=True, out_hilo=False):
+def block_sublayers(x, cross, temporal, ff, *, n_batch, t_len, hw, lk, cross_scale, temporal_scale, out_f32=True, out_hilo=False, proj_in=None):
     """The whole BasicTransformerBlock (attn1 -> attn2 -> attn_temporal -> ff) on fp32 stream rows [B*T*hw][512] in ONE launch: `cross`,
     `temporal` as for block_attn_sublayers, `ff` = (gamma, beta, eps, w_packed, up_bias, down_bias) as for ff_sublayer.  Returns the fp32
-    rows, or (out_hilo) their fp16 hi | lo pair, or (both) the tuple."""
+    rows, or (out_hilo) their fp16 hi | lo pair, or (both) the tuple.  proj_in = (gn_scale, gn_shift, w_packed, bias): x is the input of
+    the Transformer3DModel's GroupNorm and the launch starts with GroupNorm apply -> proj_in (scale / shift: groupnorm_scale_shift's per-frame
+    rows; w_packed: pack_xattn_weight(proj_in.weight, 'out'))."""
     lib = _lib.load()
     _req(x, torch.float32, "x")
     if len(cross) != 2:
@@ -882,13 +884,18 @@ def block_sublayers(x, cross, temporal, ff, *, n_batch, t_len, hw, lk, cross_sca
     q = _tattn_params(temporal)
     f = _lib.FfParams()
     f.ln_gamma, f.ln_beta, f.ln_eps, f.w_packed, f.up_bias, f.down_bias = _p(ff[0]), _p(ff[1]), float(ff[2]), _p(ff[3]), _p(ff[4]), _p(ff[5])
+    pi = None
+    if proj_in is not None:
+        pi = _lib.ProjInParams()
+        pi.gn_scale, pi.gn_shift, pi.w_packed, pi.bias = _p(proj_in[0]), _p(proj_in[1]), _p(proj_in[2]), _p(proj_in[3])
     ev = PROFILER.begin("block_sublayers")
-    rc = lib.uav_block_sublayers_f32(_p(x), _p(y) if y is not None else None, _p(yh) if yh is not None else None, C.cast(arr, C.c_void_p), lk,
+    rc = lib.uav_block_sublayers_f32(_p(x), C.byref(pi) if pi is not None else None, _p(y) if y is not None else None, _p(yh) if yh is not None else None, C.cast(arr, C.c_void_p), lk,
                                      cross_scale, C.byref(q), C.byref(f), n_batch, t_len, hw, XATTN_C, XATTN_HEADS, FF_INNER, temporal_scale,
                                      _stream())
     _lib.check(rc, "uav_block_sublayers_f32")
     PROFILER.end(ev, "block_sublayers" if not PROFILER.detail else f"block_sublayers M={m}",
-                 2.0 * m * (8 * XATTN_C * XATTN_C) + 2 * 4.0 * m * lk * XATTN_C + 4.0 * m * t_len * XATTN_C + 2.0 * m * XATTN_C * 3 * FF_INNER,
+                 2.0 * m * ((9 if pi is not None else 8) * XATTN_C * XATTN_C) + 2 * 4.0 * m * lk * XATTN_C + 4.0 * m * t_len * XATTN_C
+                 + 2.0 * m * XATTN_C * 3 * FF_INNER,
                  4.0 * m * XATTN_C * (1 + (1 if out_f32 else 0) + (1 if out_hilo else 0)))
     if out_f32 and out_hilo:
         return y, yh
