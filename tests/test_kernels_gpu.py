@@ -1397,7 +1397,10 @@ def test_whole_block_launch_with_groupnorm_apply_and_proj_in_in_front(ops, dev):
     y, yh = ops.block_sublayers(x, cross, temporal, ff, out_f32=True, out_hilo=True, proj_in=pi, **kw)
     assert bool(torch.isfinite(y).all())
     e, e_upd = rel_l2(y, y_ref), rel_l2(y - tok, y_ref - tok)
-    assert e < 1e-4 and e_upd < 1.5e-3, (e, e_upd)            # tok to fp32 summation order; norm1 statistics from the accumulators
+    # tok agrees to fp32 summation order, but norm1's statistics now come from the accumulators (two passes) instead of the shifted one-pass
+    # first read: fp16 rounding flips of the LayerNorm rows in ALL four sub-layers (measured 3.3e-4 / 4.5e-4 with these unscaled random
+    # weights, whose updates are as large as the stream; a wrong table, bias or frame mapping would show as 1e-1)
+    assert e < 6e-4 and e_upd < 1.5e-3, (e, e_upd)
     assert torch.equal(yh, ops.cast_hilo(y))
     yh2 = ops.block_sublayers(x, cross, temporal, ff, out_f32=False, out_hilo=True, proj_in=pi, **kw)
     assert torch.equal(yh2, yh)
