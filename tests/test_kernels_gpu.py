@@ -55,6 +55,12 @@ CONV_CASES = [
     ("small_cin3_3x3x3", 3, 64, (3, 3, 3), 1, False, 3, 3, 12, 12),
     ("out4", 128, 4, (1, 3, 3), 1, False, 2, 2, 16, 16),
     ("out3", 128, 3, (1, 3, 3), 1, False, 2, 1, 16, 16),
+    # (conv_out shapes: rows that are no multiple of 8 / 64, two images, every channel count of the UNet / VAE conv_out.  A vector-ALU kernel
+    #  for these 4-channel convs was tried in round 6 — 1.08 against 1.15 ms at M = 1 638 400: both re-read the input once per tap from L2,
+    #  which is what bounds them — and dropped)
+    ("out4_c256_row_tails", 256, 4, (1, 3, 3), 1, False, 2, 1, 17, 19),
+    ("out4_c64_small", 64, 4, (1, 3, 3), 1, False, 3, 3, 9, 11),
+    ("out4_c128_wide", 128, 4, (1, 3, 3), 1, False, 2, 2, 40, 72),
     # cout % 256 == 0: also run by the 256x256-tile kernel when UAV_CONV_TILE=256 (or a large grid)
     ("big_3x3_c128_n256", 128, 256, (1, 3, 3), 1, False, 2, 2, 23, 17),
     ("big_t3_c256_n256", 256, 256, (3, 1, 1), 1, False, 6, 3, 9, 11),
