@@ -324,6 +324,17 @@ int uav_block_sublayers_f32(const float* x, const uav_projin_params* proj_in, fl
 int uav_xattn_pack_kv(const void* k, int64_t k_stride, const void* v, int64_t v_stride, int32_t n_batch, int32_t lk,
                       int32_t heads, int32_t head_dim, void* out, void* stream);
 
+/* Single-head d = 512 attention (the VAE mid block: reference vae.py AttentionBlock, softmax(Q K^T / sqrt(512)) V over the L = H W pixels of a
+ * frame) on pre-packed operands: uav_attention512_pack_kv turns the K / V rows [bq * lk][stride] (fp16, 512 channels) into two MFMA-fragment
+ * streams of uav_attention512_pack_bytes(bq, lk) bytes EACH (caller-allocated, 16-B aligned; [bq][ceil(lk / 32)][32 KiB]), and
+ * uav_attention512_packed_f16 walks them: q, o fp16 rows [bq * lq][stride >= 512].  Same arithmetic as uav_attention_f16 at head_dim 512
+ * (fp16 operands and P, fp32 scores / accumulators / online softmax with exact deferred rescale); another summation order. */
+int64_t uav_attention512_pack_bytes(int32_t bq, int32_t lk);
+int uav_attention512_pack_kv(const void* k, int64_t k_stride, const void* v, int64_t v_stride, int32_t bq, int32_t lk, void* k_packed,
+                             void* v_packed, void* stream);
+int uav_attention512_packed_f16(const void* q, int64_t q_stride, const void* k_packed, const void* v_packed, void* o, int64_t o_stride,
+                                int32_t bq, int32_t lq, int32_t lk, float scale, void* stream);
+
 /* ---- K7: per-pixel temporal attention --------------------------------------------------
  * Replaces TemporalAttention._attention (attention.py:699-733): q*scale -> RoPE on the first
  * rot_dim dims of each head (interleaved pairs) -> QK^T + bias[h][i][j] -> -max -> softmax -> V,

@@ -206,6 +206,8 @@ def test_layernorm(ops, dev, c):
     (128, 2, 1, 1600, 1600, 1),
     (512, 1, 2, 160, 160, 1),      # VAE mid-block attention, single head
     (512, 1, 1, 100, 1000, 1),
+    (512, 1, 2, 300, 2000, 1),     # lk >= 1024: the ring kernel on pre-packed K / V^T (csrc/attn512x.hip); ragged query block and key tile
+    (512, 1, 3, 256, 4096, 1),
 ])
 def test_attention(ops, dev, d, heads, bq, lq, lk, qpk):
     g = torch.Generator().manual_seed(d + lq)
@@ -1410,3 +1412,24 @@ def test_whole_block_launch_with_groupnorm_apply_and_proj_in_in_front(ops, dev):
     assert torch.equal(yh, ops.cast_hilo(y))
     yh2 = ops.block_sublayers(x, cross, temporal, ff, out_f32=False, out_hilo=True, proj_in=pi, **kw)
     assert torch.equal(yh2, yh)
+
+
+def test_attention_d512_ring_kernel_on_fused_qkv_rows_and_against_the_old_kernel(ops, dev):
+    """uav_attention512_pack_kv + uav_attention512_packed_f16 (VAE mid-block attention, vae.py AttentionBlock) on q | k | v slices of one fused
+    projection (row stride 1536) against fp32 torch and against attn512w_kernel (uav_attention_f16) on the same rows."""
+    from uav import _lib
+    g = torch.Generator().manual_seed(512)
+    bq, L, d = 2, 1500, 512
+    qkv = (torch.randn(bq * L, 3 * d, generator=g) * 0.9).half().to(dev)
+    q, k, v = qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]
+    out = ops.attention(q, k, v, bq=bq, lq=L, lk=L, heads=1, head_dim=d, q_stride=3 * d, k_stride=3 * d, v_stride=3 * d)
+    qf, kf, vf = (t.float().reshape(bq, L, d) for t in (q, k, v))
+    ref = (torch.softmax(qf @ kf.transpose(-1, -2) * d ** -0.5, dim=-1) @ vf).reshape(bq * L, d)
+    assert rel_l2(out, ref) < 3e-3
+    lib = _lib.load()
+    old = torch.empty_like(out)
+    rc = lib.uav_attention_f16(q.data_ptr(), 3 * d, k.data_ptr(), 3 * d, v.data_ptr(), 3 * d, old.data_ptr(), d, bq, L, L, 1, 1, d, d ** -0.5, 0,
+                               ops.zero_page(dev).data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    assert rel_l2(out, old) < 1.5e-3                          # both round P to fp16; another key-tile size and summation order
+    assert torch.equal(ops.attention(q, k, v, bq=bq, lq=L, lk=L, heads=1, head_dim=d, q_stride=3 * d, k_stride=3 * d, v_stride=3 * d), out)

@@ -62,5 +62,10 @@ if __name__ == "__main__":
     txt += fmt("XG_V", group(12, 12, lambda f: (f"c{f & 1}", f"b{f >> 1}"), dv, first=True, tail_nop=True)) + "\n"
     # feed-forward kernel, W_down over ONE 32-wide k slice (half a chunk: two k-steps) onto all 16 accumulator tiles: fragment
     # f = (channel tile 2 (f >> 2) + (f & 1), k-step (f >> 1) & 1)
-    txt += fmt("XG_WD32", group(32, 0, lambda f: (f"A{16 * (2 * (f >> 2) + (f & 1))}", f"b{(f >> 1) & 1}"), d32))
+    txt += fmt("XG_WD32", group(32, 0, lambda f: (f"A{16 * (2 * (f >> 2) + (f & 1))}", f"b{(f >> 1) & 1}"), d32)) + "\n"
+    # d = 512 attention (csrc/attn512x.hip): S^T = K . Q^T over k = 512 — the 32 K fragments of a 32-key tile as two statements of 16 (an asm
+    # statement takes at most 30 operands), even / odd k-steps on two accumulators (no MFMA waits for its predecessor's result)
+    dh = {3: 0, 7: 1, 11: 2, 15: 3}
+    txt += fmt("XG_SA", group(16, 0, lambda f: (f"c{f & 1}", f"b{f}"), dh, first=True)) + "\n"
+    txt += fmt("XG_SB", group(16, 16, lambda f: (f"c{f & 1}", f"b{f}"), {k: v + 4 for k, v in dh.items()}, tail_nop=True))
     print(txt, end="")

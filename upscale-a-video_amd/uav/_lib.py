@@ -93,6 +93,9 @@ SIGNATURES = {
     "uav_xattn_sublayers_f32": (C.c_int, [c_p, c_p, c_p, i32, i64, i32, i32, i32, i32, f32, c_p]),
     "uav_block_attn_sublayers_f32": (C.c_int, [c_p, c_p, c_p, i32, f32, c_p, i32, i32, i64, i32, i32, f32, c_p]),
     "uav_ff_sublayer_f32": (C.c_int, [c_p, c_p, c_p, c_p, i64, i32, i32, c_p]),
+    "uav_attention512_pack_bytes": (C.c_int64, [i32, i32]),
+    "uav_attention512_pack_kv": (C.c_int, [c_p, i64, c_p, i64, i32, i32, c_p, c_p, c_p]),
+    "uav_attention512_packed_f16": (C.c_int, [c_p, i64, c_p, c_p, c_p, i64, i32, i32, i32, f32, c_p]),
     "uav_block_sublayers_f32": (C.c_int, [c_p, c_p, c_p, c_p, c_p, i32, f32, c_p, c_p, i32, i32, i64, i32, i32, i32, f32, c_p]),
     "uav_tattn_sublayer_f32": (C.c_int, [c_p, c_p, c_p, i32, i32, i64, i32, i32, f32, c_p]),
     "uav_xattn_pack_kv": (C.c_int, [c_p, i64, c_p, i64, i32, i32, i32, i32, c_p, c_p]),

@@ -101,6 +101,7 @@ def _build_locked(objdir, verbose):
 
 
 NAMED_ACC_KERNELS = {"attention.hip": ["attn512w_kernel"],
+                     "attn512x.hip": ["attn512x_kernel"],
                      "xattn_fused.hip": ["xattn_sublayer_kernelILi0E", "ff_sublayer_kernel"],
                      "tattn_fused.hip": ["tattn_sublayer_kernelILi0ELi0ELi0E", "tattn_sublayer_kernelILi2ELi0ELi0E"],
                      "tattn_block_fused.hip": ["tattn_sublayer_kernelILi2ELi1ELi0E"],

@@ -627,6 +627,10 @@ def layernorm(x, gamma, beta, eps=1e-5):
 
 
 # ------------------------------------------------------------------------------------------------
+# d = 512 single-head attention (VAE) on the ring kernel of csrc/attn512x.hip; UAV_ATTN512X=0 keeps attn512w_kernel (attention.hip)
+ATTN512X = os.environ.get("UAV_ATTN512X", "1") != "0"
+
+
 def attention(q, k, v, *, bq, lq, lk, heads, head_dim, q_per_kv=1, scale=None,
               q_stride=None, k_stride=None, v_stride=None, causal=False):
     """softmax(scale*QK^T)V.  q/k/v are fp16 views whose row strides (in elements) may exceed
@@ -639,6 +643,17 @@ def attention(q, k, v, *, bq, lq, lk, heads, head_dim, q_per_kv=1, scale=None,
     out = torch.empty((bq * lq, c), dtype=HALF, device=q.device)
     if scale is None:
         scale = head_dim ** -0.5
+    if ATTN512X and heads == 1 and head_dim == 512 and q_per_kv == 1 and not causal and lk >= 1024:
+        # the VAE mid-block attention (d = 512, L = H W): K / V^T re-packed once per call into the MFMA-fragment streams the ring kernel walks
+        # (csrc/attn512x.hip); the 0.2 GB per frame of workspace comes from the caching allocator and is released on return
+        nb = lib.uav_attention512_pack_bytes(bq, lk)
+        kp = torch.empty(nb, dtype=torch.uint8, device=q.device); vp = torch.empty(nb, dtype=torch.uint8, device=q.device)
+        ev = PROFILER.begin("attention")
+        _lib.check(lib.uav_attention512_pack_kv(_p(k), k_stride, _p(v), v_stride, bq, lk, _p(kp), _p(vp), _stream()), "uav_attention512_pack_kv")
+        _lib.check(lib.uav_attention512_packed_f16(_p(q), q_stride, _p(kp), _p(vp), _p(out), c, bq, lq, lk, scale, _stream()),
+                   "uav_attention512_packed_f16")
+        PROFILER.end(ev, "attention_d512", 4.0 * bq * lq * lk * head_dim, 2.0 * (2 * bq * lq * c + 6 * bq * lk * c))
+        return out
     ev = PROFILER.begin("attention")
     rc = lib.uav_attention_f16(_p(q), q_stride, _p(k), k_stride, _p(v), v_stride, _p(out), c, bq, lq, lk, q_per_kv,
                                heads, head_dim, scale, int(causal), _p(zero_page(q.device)), _stream())
