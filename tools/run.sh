@@ -22,6 +22,7 @@
 #   bench1_cfgsplit one 8-frame clip with its two guidance branches on two HIP streams
 #   bench_noev      event-overhead A/B: default vs --no-kernel-events, twice interleaved
 #   bench_c3 / bench_c4 / bench_2clips   configs[3] schedule on one GPU / one configs[4] tile with vae_video / two clips per GPU
+#   xpmc / attn512   SQ counters of the fused transformer / attention kernels (own --pmc pass);  d = 512 attention at L = 102 400, ring kernel vs attn512w
 #   bench1_lnfold / parity_lnfold   the LayerNorm-fold switch (UAV_LN_FOLD=1): clip time and the headline parity test
 # Environment: any UAV_* variable is passed through to every step.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
@@ -127,6 +128,19 @@ PY
               db=$(find /tmp/prof -name "*.db" | head -1)
               [ -n "$db" ] && python $R/tools/rocpd_top_kernels.py "$db" $O/${TAG}_rocprofv3_kernel_stats.csv "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-throughput-mode (MI355X; rocpd view top_kernels; 1 warm-up + 2 timed clips + 1 instrumented clip, all serial)" && head -14 $O/${TAG}_rocprofv3_kernel_stats.csv | cut -c1-200 ;;
     traffic)  (cd $R && bash tools/pmc_traffic.sh 2>&1 | tail -5); cp $O/pmc_conv_traffic.json $O/${TAG}_pmc_conv_traffic.json 2> /dev/null ;;
+    xpmc)     # SQ counters of the round-6 kernels: matrix-pipe busy, parked / stalled / issuing wave cycles, LDS activity and bank conflicts
+      L=$O/${TAG}_pmc_sq_fused_kernels.jsonl; : > $L
+      C="SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"
+      rm -rf /tmp/pmc_x; UAV_XA_ROUNDS=1 UAV_XA_PER=2 timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_x -o sq -- python $R/tools/bench_xattn.py > /dev/null 2>&1
+      db="$(find /tmp/pmc_x -name '*.db' | head -1)"
+      for pat in "tattn_sublayer_kernel<2, 1, 0>" "tattn_sublayer_kernel<2, 0, 0>" "tattn_sublayer_kernel<0, 0, 0>" "ff_sublayer_kernel" "xattn_sublayer_kernel<0>" "conv_gemm256w_kernel"; do
+        python $R/tools/pmc_reduce.py "$db" "$pat" "%$pat%" >> $L; done
+      rm -rf /tmp/pmc_x; UAV_XA_ROUNDS=1 timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_x -o sq -- python $R/tools/bench_attn512.py > /dev/null 2>&1
+      python $R/tools/pmc_reduce.py "$(find /tmp/pmc_x -name '*.db' | head -1)" "attn512x_kernel" "%attn512x_kernel%" >> $L
+      rm -rf /tmp/pmc_x; UAV_ATTN512X=0 UAV_XA_ROUNDS=1 timeout 300 rocprofv3 --kernel-trace --pmc $C -d /tmp/pmc_x -o sq -- python $R/tools/bench_attn512.py > /dev/null 2>&1
+      python $R/tools/pmc_reduce.py "$(find /tmp/pmc_x -name '*.db' | head -1)" "attn512w_kernel" "%attn512w_kernel%" >> $L
+      cat $L ;;
+    attn512)  timeout 300 python $R/tools/bench_attn512.py 3 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_attn512.jsonl; UAV_ATTN512X=0 timeout 300 python $R/tools/bench_attn512.py 3 2>&1 | grep -v amdgpu.ids | tee -a $O/${TAG}_attn512.jsonl ;;
     digest)   timeout 200 python $R/tools/conv_digest.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_digest.log ;;
     *)        echo "unknown step $step" ;;
   esac
